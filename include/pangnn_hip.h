@@ -1,0 +1,130 @@
+/*
+ * pangnn_hip.h — C ABI of libpangnn_hip.so, the MI355X (gfx950) implementation of panGNN's
+ * edge-weighted message-passing hot path.
+ *
+ * Every entry point is plain C: device pointers + sizes + a hipStream_t passed as void*.
+ * No torch types cross this boundary.  All pointers are DEVICE pointers unless stated otherwise.
+ * Every call only ENQUEUES work on `stream` (no synchronisation, no allocation) and returns
+ *   0                      on success,
+ *   a positive hipError_t  if a HIP runtime call / launch failed,
+ *   a negative PANGNN_E_*  on an argument error (nothing was launched).
+ * `pangnn_last_error()` returns a thread-local human-readable message for the last non-zero return.
+ *
+ * The reference (fischer-hub/panGNN) is pure Python; the operator it calls for this path is the
+ * third-party torch_geometric GCNConv.  Each function below cites the reference call site / PyG
+ * stage it replaces (paths relative to /root/reference, stage names k1..k7 from SURVEY.md §2.2).
+ */
+#ifndef PANGNN_HIP_H
+#define PANGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANGNN_ABI_VERSION 1
+
+#define PANGNN_E_BADARG    (-1)  /* null pointer / negative size / unsupported feature width */
+#define PANGNN_E_TOOLARGE  (-2)  /* size exceeds an int32 index range used by the kernels    */
+#define PANGNN_E_WORKSPACE (-3)  /* workspace smaller than *_workspace_bytes() asked for     */
+#define PANGNN_E_ALIGN     (-4)  /* pointer / leading dimension not 16-byte aligned          */
+
+typedef void* pangnn_stream_t;   /* hipStream_t */
+
+int         pangnn_abi_version(void);
+const char* pangnn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph structure (one-time per edge_index; replaces the implicit COO handling of
+ * MessagePassing.propagate, src/gnn.py:158,165 -> PyG).
+ *
+ * Stable counting of a COO edge list edge_index[2][E] (row 0 = source j, row 1 = target i,
+ * PyG flow 'source_to_target') into CSR grouped by `group_by`:
+ *   group_by = 1: rows are TARGET nodes  (forward propagate,  out[i] += w * x[j])
+ *   group_by = 0: rows are SOURCE nodes  (backward propagate, gx[j]  += w * g[i])
+ * Outputs: rowptr[N+1] (int64), other[E] (int32: the opposite endpoint of every sorted edge),
+ *          perm[E] (int32: original edge id of every sorted edge; stable => ascending in a row).
+ * `ld` = element distance between row 0 and row 1 of edge_index (E when contiguous).
+ * ---------------------------------------------------------------------------------------- */
+size_t pangnn_csr_build_workspace_bytes(int64_t num_edges, int64_t num_nodes);
+int    pangnn_csr_build(const int64_t* edge_index, int64_t ld, int64_t num_edges, int64_t num_nodes,
+                        int group_by, int64_t* rowptr, int32_t* other, int32_t* perm,
+                        void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+
+/* Device address of the 4-byte validity flag of the last pangnn_csr_build that used `workspace`
+ * (non-zero = some node id was outside [0, N) and was clamped).  Read it after synchronising. */
+const void* pangnn_csr_build_flag_ptr(void* workspace, int64_t num_edges);
+
+/* ------------------------------------------------------------------------------------------
+ * gcn_norm (k1-k3; PyG gcn_norm as called by GCNConv.forward, src/gnn.py:158):
+ *   deg[i]  = sum over in-edges of w        (w = 1 when edge_weight == NULL, src/gnn.py:165)
+ *   dis[i]  = deg[i]^-1/2, 0 where deg == 0
+ *   norm[e] = dis[src_e] * w_e * dis[dst_e]
+ * Input structure is the target-grouped CSR from pangnn_csr_build(group_by=1).
+ * Outputs: deg_inv_sqrt[N]; norm_sorted[E] in CSR order; norm_orig[E] in the caller's edge order
+ * (nullable).  Deterministic: per-row sums run in ascending original edge id.
+ * ---------------------------------------------------------------------------------------- */
+int pangnn_gcn_norm_f32(const int64_t* rowptr_dst, const int32_t* src_sorted, const int32_t* perm_dst,
+                        const float* edge_weight, int64_t num_nodes, int64_t num_edges,
+                        float* deg_inv_sqrt, float* norm_sorted, float* norm_orig,
+                        pangnn_stream_t stream);
+
+/* out[i] = in[perm[i]]  (re-orders per-edge values into another CSR's order) */
+int pangnn_permute_f32(const float* in, const int32_t* perm, float* out, int64_t n,
+                       pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * propagate (k5+k6, and k5^T for backward; MessagePassing.propagate + GCNConv.message + 'add'
+ * aggregation + bias, src/gnn.py:158,165):
+ *   out[r, 0:F] (+)= bias[0:F] + sum_{e in [rowptr[r], rowptr[r+1])} val[e] * x[idx[e], 0:F]
+ * val == NULL means 1.0; bias == NULL means none; accumulate != 0 adds into `out`.
+ * F in {16, 32, 64, 128, 256}; x/out/bias 16-byte aligned, ldx/ldo multiples of 4 floats.
+ * No atomics: bitwise reproducible for a fixed structure.
+ * ---------------------------------------------------------------------------------------- */
+int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, const float* val,
+                        const float* x, int64_t ldx, int64_t n_src_rows,
+                        const float* bias, float* out, int64_t ldo, int64_t n_rows,
+                        int32_t F, int accumulate, pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * edge decoder gather (k7; src/gnn.py:171-177):
+ *   out[e, 0:D]   = z[src_e], out[e, D:2D] = z[dst_e], out[e, 2D] = extra[e] (if extra != NULL)
+ * for e in [e_begin, e_begin + n_edges) of edge_index[2][ld]; out has leading dimension ldo.
+ * ---------------------------------------------------------------------------------------- */
+int pangnn_edge_gather_concat_f32(const float* z, int64_t ldz, int64_t num_nodes,
+                                  const int64_t* edge_index, int64_t ld, int64_t e_begin,
+                                  int64_t n_edges, const float* extra, float* out, int64_t ldo,
+                                  int32_t D, pangnn_stream_t stream);
+
+/* Re-associated first decoder layer: Linear(cat(z_s, z_d, w)) == P[s] + Q[d] + w*c with
+ * P = z W_a^T, Q = z W_b^T + b (node-level GEMMs done by the caller).
+ *   out[e, 0:D] = p[src_e] + q[dst_e] (+ extra[e] * cvec[0:D])
+ * ---------------------------------------------------------------------------------------- */
+int pangnn_edge_pair_add_f32(const float* p, const float* q, int64_t ldpq, int64_t num_nodes,
+                             const int64_t* edge_index, int64_t ld, int64_t e_begin, int64_t n_edges,
+                             const float* extra, const float* cvec, float* out, int64_t ldo,
+                             int32_t D, pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Segment reductions over per-edge rows selected through a CSR permutation (backward of the edge
+ * gathers above, and 'max' aggregation of src/convolution.py:7):
+ *   sum : out[r, 0:F] (+)= sum_{k in row r} m[perm[k], col_off : col_off+F]   (m has n_m_rows rows)
+ *   max : out[r, 0:F]   = max_{k in row r} m[perm[k], 0:F] (0 for empty rows), arg[r,f] = perm[k*]
+ * ---------------------------------------------------------------------------------------- */
+int pangnn_segment_sum_rows_f32(const int64_t* rowptr, const int32_t* perm, const float* m,
+                                int64_t ldm, int64_t n_m_rows, int64_t col_off, float* out, int64_t ldo,
+                                int64_t n_rows, int32_t F, int accumulate, pangnn_stream_t stream);
+int pangnn_segment_max_rows_f32(const int64_t* rowptr, const int32_t* perm, const float* m,
+                                int64_t ldm, float* out, int32_t* arg, int64_t ldo,
+                                int64_t n_rows, int32_t F, pangnn_stream_t stream);
+/* gm[arg[r,f], f] = g[r,f] for non-empty rows; gm must be zero-filled by the caller */
+int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t* rowptr,
+                               float* gm, int64_t ldm, int64_t ldo, int64_t n_rows, int32_t F,
+                               pangnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANGNN_HIP_H */

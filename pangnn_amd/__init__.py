@@ -1,0 +1,15 @@
+"""pangnn_amd — MI355X-native implementation of panGNN's edge-weighted message-passing hot path.
+
+Importing the package loads libpangnn_hip.so (the HIP kernels behind the C ABI in
+include/pangnn_hip.h) and raises if it has not been built: there is no CPU / eager fallback."""
+from . import _lib
+
+_lib.load()
+
+from .convolution import EdgeConv, GCNConv, MessagePassing   # noqa: E402
+from .data import Batch, Data, DataLoader                    # noqa: E402
+from .gnn import AlternateGCN                                 # noqa: E402
+from .graph import EdgeStructure, structure_of                # noqa: E402
+
+__all__ = ["AlternateGCN", "GCNConv", "MessagePassing", "EdgeConv", "Data", "Batch", "DataLoader",
+           "EdgeStructure", "structure_of"]

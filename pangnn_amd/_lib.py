@@ -1,0 +1,85 @@
+"""ctypes binding of libpangnn_hip.so (C ABI declared in include/pangnn_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing the
+operators raises.  Tensors cross the boundary as raw device pointers (`tensor.data_ptr()`), sizes
+and the current HIP stream handle; PyTorch is only the allocator / stream owner.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpangnn_hip.so")
+
+_i64, _i32, _p, _sz = C.c_int64, C.c_int32, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pangnn_hip.h one to one
+SIGNATURES = {
+    "pangnn_abi_version": (C.c_int, []),
+    "pangnn_last_error": (C.c_char_p, []),
+    "pangnn_csr_build_workspace_bytes": (_sz, [_i64, _i64]),
+    "pangnn_csr_build": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p, _p, _p, _sz, _p]),
+    "pangnn_csr_build_flag_ptr": (_p, [_p, _i64]),
+    "pangnn_gcn_norm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
+    "pangnn_permute_f32": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "pangnn_spmm_csr_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i32, C.c_int, _p]),
+    "pangnn_edge_gather_concat_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _i32, _p]),
+    "pangnn_edge_pair_add_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _i32, _p]),
+    "pangnn_segment_sum_rows_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32, C.c_int, _p]),
+    "pangnn_segment_max_rows_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _p]),
+    "pangnn_segment_max_bwd_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+}
+
+_lib = None
+
+
+class PangnnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PangnnHipError(
+            f"pangnn_amd: HIP extension {LIB_PATH} is missing. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C pangnn_amd/csrc`). "
+            f"There is no CPU / PyTorch fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pangnn_abi_version() != 1:
+        raise PangnnHipError(f"pangnn_amd: ABI version {lib.pangnn_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pangnn_last_error().decode("utf-8", "replace")
+        raise PangnnHipError(f"{what or 'pangnn_hip'} failed (rc={rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None."""
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PangnnHipError(
+                "pangnn_amd: operands must live on the GPU (HIP device tensors); this package has "
+                "no CPU fallback. Got a tensor on " + str(t.device))

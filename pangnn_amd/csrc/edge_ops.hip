@@ -1,0 +1,286 @@
+// gcn_norm (k1-k3), per-edge gathers for the link decoder (k7) and 'max' segment reduction.
+#include <stdarg.h>
+#include "common.h"
+
+namespace pangnn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// deg[i] = sum_{in-edges} w ; dis = deg^-1/2 (0 when deg == 0).  One wave per target row; lanes
+// stride the row (fixed order => reproducible).
+__global__ __launch_bounds__(kBlock) void degree_kernel(const int64_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ perm,
+                                                        const float* __restrict__ w,
+                                                        float* __restrict__ dis, int64_t n) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  float s = 0.f;
+  if (w) {
+    for (int64_t e = beg + lane; e < end; e += kWave) s += w[perm[e]];
+    s = wave_sum(s);
+  } else {
+    s = (float)(end - beg);
+  }
+  if (lane == 0) {
+    // PyG: deg.pow(-0.5); masked_fill(== inf, 0).  pow(x,-0.5) == 1/sqrt(x) for x > 0.
+    float d = 1.0f / sqrtf(s);
+    if (isinf(d)) d = 0.f;
+    dis[row] = d;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void edge_norm_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ perm, const float* __restrict__ w, const float* __restrict__ dis,
+    float* __restrict__ norm_sorted, float* __restrict__ norm_orig, int64_t n) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  const float dc = dis[row];
+  for (int64_t e = beg + lane; e < end; e += kWave) {
+    const int32_t o = perm[e];
+    const float we = w ? w[o] : 1.f;
+    const float v = dis[src[e]] * we * dc;  // PyG order: (dis[row] * w) * dis[col]
+    norm_sorted[e] = v;
+    if (norm_orig) norm_orig[o] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void permute_kernel(const float* __restrict__ in,
+                                                         const int32_t* __restrict__ perm,
+                                                         float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlock)
+    out[i] = in[perm[i]];
+}
+
+// out[e, 0:D] = z[src], out[e, D:2D] = z[dst], (out[e,2D] = extra[e]).  VEC: float4 per lane.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void gather_concat_kernel(
+    const float* __restrict__ z, int64_t ldz, const int64_t* __restrict__ ei, int64_t ld,
+    int64_t e_begin, int64_t n_edges, const float* __restrict__ extra, float* __restrict__ out,
+    int64_t ldo, int D) {
+  const int per_edge = VEC ? (2 * D / 4) : (2 * D);
+  const int64_t total = n_edges * per_edge;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int64_t el = t / per_edge;
+    const int c = (int)(t - el * per_edge);
+    const int64_t e = e_begin + el;
+    if (VEC) {
+      const int half = c >= D / 4;
+      const int64_t node = ei[half ? ld + e : e];
+      const int cc = half ? c - D / 4 : c;
+      const float4 v = reinterpret_cast<const float4*>(z + node * ldz)[cc];
+      reinterpret_cast<float4*>(out + el * ldo)[c] = v;
+    } else {
+      const int half = c >= D;
+      const int64_t node = ei[half ? ld + e : e];
+      out[el * ldo + c] = z[node * ldz + (half ? c - D : c)];
+      if (extra && c == 0) out[el * ldo + 2 * D] = extra[e];
+    }
+  }
+}
+
+// out[e, 0:D] = p[src] + q[dst] (+ extra[e] * cvec).  D % 4 == 0, float4 per lane.
+__global__ __launch_bounds__(kBlock) void pair_add_kernel(
+    const float* __restrict__ p, const float* __restrict__ q, int64_t ldpq,
+    const int64_t* __restrict__ ei, int64_t ld, int64_t e_begin, int64_t n_edges,
+    const float* __restrict__ extra, const float* __restrict__ cvec, float* __restrict__ out,
+    int64_t ldo, int D) {
+  const int per_edge = D / 4;
+  const int64_t total = n_edges * per_edge;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int64_t el = t / per_edge;
+    const int c = (int)(t - el * per_edge);
+    const int64_t e = e_begin + el;
+    const int64_t s = ei[e], d = ei[ld + e];
+    const float4 a = reinterpret_cast<const float4*>(p + s * ldpq)[c];
+    const float4 b = reinterpret_cast<const float4*>(q + d * ldpq)[c];
+    float4 r = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    if (extra) {
+      const float w = extra[e];
+      const float4 cv = reinterpret_cast<const float4*>(cvec)[c];
+      r.x = fmaf(w, cv.x, r.x); r.y = fmaf(w, cv.y, r.y);
+      r.z = fmaf(w, cv.z, r.z); r.w = fmaf(w, cv.w, r.w);
+    }
+    reinterpret_cast<float4*>(out + el * ldo)[c] = r;
+  }
+}
+
+// 'max' aggregation over the edges of a target row (convolution.py:7).  Wave per row, lanes stride
+// the feature dim, edges serial in ascending original id (first maximum wins, as a sequential
+// scatter would).
+__global__ __launch_bounds__(kBlock) void segment_max_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+    const float* __restrict__ m, int64_t ldm, float* __restrict__ out, int32_t* __restrict__ arg,
+    int64_t ldo, int64_t n_rows, int F) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  for (int f = lane; f < F; f += kWave) {
+    float best = 0.f;
+    int32_t bi = -1;
+    for (int64_t k = beg; k < end; ++k) {
+      const int32_t o = perm[k];
+      const float v = m[(int64_t)o * ldm + f];
+      if (bi < 0 || v > best || (v != v && best == best)) { best = v; bi = o; }  // NaN propagates
+    }
+    out[row * ldo + f] = best;
+    if (arg) arg[row * ldo + f] = bi;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
+    const float* __restrict__ g, const int32_t* __restrict__ arg, float* __restrict__ gm,
+    int64_t ldm, int64_t ldo, int64_t n_rows, int F) {
+  const int64_t total = n_rows * F;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = t / F;
+    const int f = (int)(t - r * F);
+    const int32_t a = arg[r * ldo + f];
+    if (a >= 0) gm[(int64_t)a * ldm + f] = g[r * ldo + f];  // every (edge, f) has one owner row
+  }
+}
+
+static inline unsigned grid_for(int64_t total) {
+  int64_t b = (total + kBlock - 1) / kBlock;
+  const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace pangnn
+
+using namespace pangnn;
+
+extern "C" int pangnn_abi_version(void) { return PANGNN_ABI_VERSION; }
+extern "C" const char* pangnn_last_error(void) { return g_err; }
+
+extern "C" int pangnn_gcn_norm_f32(const int64_t* rowptr_dst, const int32_t* src_sorted,
+                                   const int32_t* perm_dst, const float* edge_weight,
+                                   int64_t num_nodes, int64_t num_edges, float* deg_inv_sqrt,
+                                   float* norm_sorted, float* norm_orig, pangnn_stream_t stream) {
+  PG_CHECK_ARG(num_nodes >= 0 && num_edges >= 0, PANGNN_E_BADARG, "pangnn_gcn_norm_f32: negative size");
+  if (num_nodes == 0) return 0;
+  PG_CHECK_ARG(rowptr_dst && deg_inv_sqrt && (num_edges == 0 || (src_sorted && perm_dst && norm_sorted)),
+               PANGNN_E_BADARG, "pangnn_gcn_norm_f32: null pointer");
+  const int64_t blocks = (num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+  PG_CHECK_ARG(blocks < 2147483647LL, PANGNN_E_TOOLARGE, "pangnn_gcn_norm_f32: too many nodes");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(degree_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, rowptr_dst, perm_dst,
+                     edge_weight, deg_inv_sqrt, num_nodes);
+  PG_CHECK_LAUNCH("pangnn_gcn_norm_f32(degree)");
+  if (num_edges > 0) {
+    hipLaunchKernelGGL(edge_norm_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, rowptr_dst,
+                       src_sorted, perm_dst, edge_weight, deg_inv_sqrt, norm_sorted, norm_orig,
+                       num_nodes);
+    PG_CHECK_LAUNCH("pangnn_gcn_norm_f32(norm)");
+  }
+  return 0;
+}
+
+extern "C" int pangnn_permute_f32(const float* in, const int32_t* perm, float* out, int64_t n,
+                                  pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_permute_f32: negative size");
+  if (n == 0) return 0;
+  PG_CHECK_ARG(in && perm && out, PANGNN_E_BADARG, "pangnn_permute_f32: null pointer");
+  hipLaunchKernelGGL(permute_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, in,
+                     perm, out, n);
+  PG_CHECK_LAUNCH("pangnn_permute_f32");
+  return 0;
+}
+
+extern "C" int pangnn_edge_gather_concat_f32(const float* z, int64_t ldz, int64_t num_nodes,
+                                             const int64_t* edge_index, int64_t ld, int64_t e_begin,
+                                             int64_t n_edges, const float* extra, float* out,
+                                             int64_t ldo, int32_t D, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_edges >= 0 && e_begin >= 0 && D > 0 && num_nodes >= 0, PANGNN_E_BADARG,
+               "pangnn_edge_gather_concat_f32: bad size");
+  if (n_edges == 0) return 0;
+  PG_CHECK_ARG(z && edge_index && out, PANGNN_E_BADARG, "pangnn_edge_gather_concat_f32: null pointer");
+  PG_CHECK_ARG(e_begin + n_edges <= ld, PANGNN_E_BADARG,
+               "pangnn_edge_gather_concat_f32: edge window [%lld,%lld) outside ld=%lld",
+               (long long)e_begin, (long long)(e_begin + n_edges), (long long)ld);
+  PG_CHECK_ARG(ldo >= 2 * D + (extra ? 1 : 0) && ldz >= D, PANGNN_E_BADARG,
+               "pangnn_edge_gather_concat_f32: leading dimension too small");
+  const bool vec = !extra && D % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 && aligned16(z) && aligned16(out);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL((gather_concat_kernel<true>), dim3(grid_for(n_edges * (2 * D / 4))), dim3(kBlock),
+                       0, s, z, ldz, edge_index, ld, e_begin, n_edges, extra, out, ldo, (int)D);
+  else
+    hipLaunchKernelGGL((gather_concat_kernel<false>), dim3(grid_for(n_edges * 2 * D)), dim3(kBlock), 0,
+                       s, z, ldz, edge_index, ld, e_begin, n_edges, extra, out, ldo, (int)D);
+  PG_CHECK_LAUNCH("pangnn_edge_gather_concat_f32");
+  return 0;
+}
+
+extern "C" int pangnn_edge_pair_add_f32(const float* p, const float* q, int64_t ldpq,
+                                        int64_t num_nodes, const int64_t* edge_index, int64_t ld,
+                                        int64_t e_begin, int64_t n_edges, const float* extra,
+                                        const float* cvec, float* out, int64_t ldo, int32_t D,
+                                        pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_edges >= 0 && e_begin >= 0 && D > 0 && num_nodes >= 0, PANGNN_E_BADARG,
+               "pangnn_edge_pair_add_f32: bad size");
+  if (n_edges == 0) return 0;
+  PG_CHECK_ARG(p && q && edge_index && out && (!extra || cvec), PANGNN_E_BADARG,
+               "pangnn_edge_pair_add_f32: null pointer");
+  PG_CHECK_ARG(e_begin + n_edges <= ld, PANGNN_E_BADARG, "pangnn_edge_pair_add_f32: edge window outside ld");
+  PG_CHECK_ARG(D % 4 == 0 && ldpq % 4 == 0 && ldo % 4 == 0 && ldpq >= D && ldo >= D, PANGNN_E_BADARG,
+               "pangnn_edge_pair_add_f32: D / leading dimensions must be multiples of 4");
+  PG_CHECK_ARG(aligned16(p) && aligned16(q) && aligned16(out) && (!cvec || aligned16(cvec)),
+               PANGNN_E_ALIGN, "pangnn_edge_pair_add_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(pair_add_kernel, dim3(grid_for(n_edges * (D / 4))), dim3(kBlock), 0,
+                     (hipStream_t)stream, p, q, ldpq, edge_index, ld, e_begin, n_edges, extra, cvec,
+                     out, ldo, (int)D);
+  PG_CHECK_LAUNCH("pangnn_edge_pair_add_f32");
+  return 0;
+}
+
+extern "C" int pangnn_segment_max_rows_f32(const int64_t* rowptr, const int32_t* perm, const float* m,
+                                           int64_t ldm, float* out, int32_t* arg, int64_t ldo,
+                                           int64_t n_rows, int32_t F, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_rows >= 0 && F > 0 && ldm >= F && ldo >= F, PANGNN_E_BADARG,
+               "pangnn_segment_max_rows_f32: bad size");
+  if (n_rows == 0) return 0;
+  PG_CHECK_ARG(rowptr && out, PANGNN_E_BADARG, "pangnn_segment_max_rows_f32: null pointer");
+  const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  PG_CHECK_ARG(blocks < 2147483647LL, PANGNN_E_TOOLARGE, "pangnn_segment_max_rows_f32: too many rows");
+  hipLaunchKernelGGL(segment_max_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                     rowptr, perm, m, ldm, out, arg, ldo, n_rows, (int)F);
+  PG_CHECK_LAUNCH("pangnn_segment_max_rows_f32");
+  return 0;
+}
+
+extern "C" int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t* rowptr,
+                                          float* gm, int64_t ldm, int64_t ldo, int64_t n_rows,
+                                          int32_t F, pangnn_stream_t stream) {
+  (void)rowptr;
+  PG_CHECK_ARG(n_rows >= 0 && F > 0, PANGNN_E_BADARG, "pangnn_segment_max_bwd_f32: bad size");
+  if (n_rows == 0) return 0;
+  PG_CHECK_ARG(g && arg && gm, PANGNN_E_BADARG, "pangnn_segment_max_bwd_f32: null pointer");
+  hipLaunchKernelGGL(segment_max_bwd_kernel, dim3(grid_for(n_rows * F)), dim3(kBlock), 0,
+                     (hipStream_t)stream, g, arg, gm, ldm, ldo, n_rows, (int)F);
+  PG_CHECK_LAUNCH("pangnn_segment_max_bwd_f32");
+  return 0;
+}

@@ -1,0 +1,195 @@
+// propagate (k5/k6/k5^T): CSR gather - scale - per-destination reduce, fp32, gfx950.
+//
+// Layout: one 64-lane wavefront owns one destination row.  A source row of F floats is covered by
+// G = F/4 lanes with one 16-byte load each (global_load_dwordx4), so a wave-instruction gathers
+// EPS = 64/G different source rows = 1 KiB of row data.  The row's (idx, val) list is read 64 entries
+// at a time with one coalesced load per array and handed to the G-lane groups by ds_bpermute
+// (cross-lane, no memory); the next 64 entries are prefetched while the current ones are consumed.
+// U independent gathers per lane are kept in flight (U KiB per wave).  The EPS partial sums are
+// combined with log2(EPS) xor-shuffles at the end of the row; no atomics, fixed summation order.
+#include "common.h"
+
+namespace pangnn {
+
+template <int F, int U, bool BIG>
+__global__ __launch_bounds__(kBlock) void spmm_row_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
+    const float* __restrict__ val, const float* __restrict__ x, int64_t ldx,
+    const float* __restrict__ bias, float* __restrict__ out, int64_t ldo, int64_t n_rows,
+    int accumulate) {
+  constexpr int G = F / 4;        // lanes per source row
+  constexpr int EPS = kWave / G;  // source rows per wave-instruction
+  static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "F must be 4 * power of two, <= 256");
+  static_assert(EPS * U <= 64, "unroll too deep for this feature width");
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_rows) return;  // whole wave exits together (row is wave-uniform)
+  const int sub = lane / G;   // which of the EPS rows of a step this lane helps with
+  const int fl = lane % G;    // which float4 of that row
+
+  const int64_t beg = rowptr[row];
+  const int64_t end = rowptr[row + 1];
+
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const char* xbase = reinterpret_cast<const char*>(x) + fl * 16;
+  const uint32_t ldx_b32 = (uint32_t)(ldx * 4);
+
+  // prefetch first block of 64 list entries
+  int c_nxt = 0;
+  float v_nxt = 0.f;
+  if (beg + lane < end) {
+    c_nxt = idx[beg + lane];
+    v_nxt = val ? val[beg + lane] : 1.f;
+  }
+  for (int64_t e0 = beg; e0 < end; e0 += kWave) {
+    const int c_cur = c_nxt;
+    const float v_cur = v_nxt;
+    const int64_t rem = end - e0;
+    const int cnt = rem < kWave ? (int)rem : kWave;
+    {
+      const int64_t en = e0 + kWave + lane;
+      c_nxt = 0;
+      v_nxt = 0.f;
+      if (en < end) {
+        c_nxt = idx[en];
+        v_nxt = val ? val[en] : 1.f;
+      }
+    }
+    for (int s = 0; s < cnt; s += EPS * U) {
+      float4 xv[U];
+      float vv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = s + u * EPS + sub;  // < 64 by construction
+        const int c = __shfl(c_cur, k);
+        vv[u] = __shfl(v_cur, k);
+        if (k < cnt) {
+          if (BIG) {
+            xv[u] = *reinterpret_cast<const float4*>(xbase + (int64_t)c * ldx * 4);
+          } else {
+            xv[u] = *reinterpret_cast<const float4*>(xbase + (uint32_t)c * ldx_b32);
+          }
+        } else {
+          xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          vv[u] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc.x = fmaf(vv[u], xv[u].x, acc.x);
+        acc.y = fmaf(vv[u], xv[u].y, acc.y);
+        acc.z = fmaf(vv[u], xv[u].z, acc.z);
+        acc.w = fmaf(vv[u], xv[u].w, acc.w);
+      }
+    }
+  }
+  // combine the EPS partial rows (fixed tree order)
+#pragma unroll
+  for (int off = 32; off >= G; off >>= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+  }
+  if (lane < G) {
+    if (bias) {
+      const float4 b = reinterpret_cast<const float4*>(bias)[fl];
+      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out + row * ldo) + fl;
+    if (accumulate) {
+      const float4 p = *o;
+      acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    *o = acc;
+  }
+}
+
+// Any feature width: lanes stride over features, edges serial.  Correctness path for odd F.
+__global__ __launch_bounds__(kBlock) void spmm_row_generic_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
+    const float* __restrict__ val, const float* __restrict__ x, int64_t ldx,
+    const float* __restrict__ bias, float* __restrict__ out, int64_t ldo, int64_t n_rows, int F,
+    int accumulate) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  for (int f = lane; f < F; f += kWave) {
+    float acc = 0.f;
+    for (int64_t e = beg; e < end; ++e) {
+      const float v = val ? val[e] : 1.f;
+      acc = fmaf(v, x[(int64_t)idx[e] * ldx + f], acc);
+    }
+    if (bias) acc += bias[f];
+    if (accumulate) acc += out[row * ldo + f];
+    out[row * ldo + f] = acc;
+  }
+}
+
+template <int F, int U>
+static int launch_spmm(const int64_t* rowptr, const int32_t* idx, const float* val, const float* x,
+                       int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
+                       int64_t n_rows, int accumulate, hipStream_t s) {
+  const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  const bool big = (double)n_src_rows * (double)ldx * 4.0 >= 4294967296.0;
+  if (big)
+    hipLaunchKernelGGL((spmm_row_kernel<F, U, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       rowptr, idx, val, x, ldx, bias, out, ldo, n_rows, accumulate);
+  else
+    hipLaunchKernelGGL((spmm_row_kernel<F, U, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       rowptr, idx, val, x, ldx, bias, out, ldo, n_rows, accumulate);
+  PG_CHECK_LAUNCH("pangnn_spmm_csr_f32");
+  return 0;
+}
+
+}  // namespace pangnn
+
+using namespace pangnn;
+
+extern "C" int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, const float* val,
+                                   const float* x, int64_t ldx, int64_t n_src_rows,
+                                   const float* bias, float* out, int64_t ldo, int64_t n_rows,
+                                   int32_t F, int accumulate, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_rows >= 0 && n_src_rows >= 0 && F > 0, PANGNN_E_BADARG,
+               "pangnn_spmm_csr_f32: negative size (n_rows=%lld n_src_rows=%lld F=%d)",
+               (long long)n_rows, (long long)n_src_rows, (int)F);
+  if (n_rows == 0) return 0;
+  PG_CHECK_ARG(rowptr && out && (x || n_src_rows == 0), PANGNN_E_BADARG,
+               "pangnn_spmm_csr_f32: null pointer");
+  PG_CHECK_ARG(ldx >= F && ldo >= F, PANGNN_E_BADARG,
+               "pangnn_spmm_csr_f32: leading dimension smaller than F");
+  PG_CHECK_ARG((n_rows + kWavesPerBlock - 1) / kWavesPerBlock < 2147483647LL, PANGNN_E_TOOLARGE,
+               "pangnn_spmm_csr_f32: too many rows for one launch");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec_ok = aligned16(x) && aligned16(out) && (!bias || aligned16(bias)) &&
+                      (ldx % 4 == 0) && (ldo % 4 == 0);
+  if (vec_ok) {
+    switch (F) {
+      case 16:  return launch_spmm<16, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+      case 32:  return launch_spmm<32, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+      case 64:  return launch_spmm<64, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+      case 128: return launch_spmm<128, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+      case 256: return launch_spmm<256, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+      default: break;
+    }
+  }
+  const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  hipLaunchKernelGGL(spmm_row_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, rowptr,
+                     idx, val, x, ldx, bias, out, ldo, n_rows, (int)F, accumulate);
+  PG_CHECK_LAUNCH("pangnn_spmm_csr_f32(generic)");
+  return 0;
+}
+
+extern "C" int pangnn_segment_sum_rows_f32(const int64_t* rowptr, const int32_t* perm,
+                                           const float* m, int64_t ldm, int64_t n_m_rows,
+                                           int64_t col_off, float* out,
+                                           int64_t ldo, int64_t n_rows, int32_t F, int accumulate,
+                                           pangnn_stream_t stream) {
+  PG_CHECK_ARG(col_off >= 0 && col_off + F <= ldm, PANGNN_E_BADARG,
+               "pangnn_segment_sum_rows_f32: column window [%lld,%lld) outside ldm=%lld",
+               (long long)col_off, (long long)(col_off + F), (long long)ldm);
+  return pangnn_spmm_csr_f32(rowptr, perm, nullptr, m + col_off, ldm, n_m_rows, nullptr,
+                             out, ldo, n_rows, F, accumulate, stream);
+}

@@ -1,0 +1,211 @@
+"""autograd glue over the C ABI: each Function enqueues HIP kernels from libpangnn_hip.so on torch's
+current stream.  No torch-native arithmetic stands in for a kernel here."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .graph import CSR, EdgeStructure, GcnNorm
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int,
+             bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+             accumulate: bool = False) -> torch.Tensor:
+    """out[r] (+)= bias + sum_e val[e] * x[other[e]]  — pangnn_spmm_csr_f32."""
+    lib = _lib.load()
+    _lib.require_device(x, csr.rowptr, val, bias)
+    x = _f32c(x)
+    f = x.shape[1]
+    if out is None:
+        out = torch.empty(n_rows, f, dtype=torch.float32, device=x.device)
+        accumulate = False
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pangnn_spmm_csr_f32(csr.rowptr.data_ptr(), _lib.ptr(csr.other), _lib.ptr(val),
+                                           x.data_ptr(), x.stride(0), x.shape[0], _lib.ptr(bias),
+                                           out.data_ptr(), out.stride(0), n_rows, f, int(accumulate),
+                                           _lib.stream_ptr()), "pangnn_spmm_csr_f32")
+    return out
+
+
+def segment_sum_rows(csr: CSR, m: torch.Tensor, col_off: int, f: int, n_rows: int,
+                     out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[r] (+)= sum_{k in row r} m[perm[k], col_off:col_off+f] — pangnn_segment_sum_rows_f32."""
+    lib = _lib.load()
+    _lib.require_device(m)
+    assert m.dtype == torch.float32 and m.stride(1) == 1
+    if out is None:
+        out = torch.empty(n_rows, f, dtype=torch.float32, device=m.device)
+        accumulate = False
+    with torch.cuda.device(m.device):
+        _lib.check(lib.pangnn_segment_sum_rows_f32(csr.rowptr.data_ptr(), _lib.ptr(csr.perm), m.data_ptr(),
+                                                   m.stride(0), m.shape[0], col_off, out.data_ptr(),
+                                                   out.stride(0), n_rows, f, int(accumulate),
+                                                   _lib.stream_ptr()), "pangnn_segment_sum_rows_f32")
+    return out
+
+
+class _Propagate(torch.autograd.Function):
+    """out = A_hat @ x + bias with A_hat given by (structure, norm).  Backward is the transposed
+    propagate over the source-grouped CSR (k5^T); edge weights are not differentiated (they are a
+    leaf without grad in the reference: SURVEY.md §8 a6)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm):
+        ctx.st, ctx.norm = st, norm
+        ctx.has_bias = bias is not None
+        return spmm_csr(st.by_dst, norm.by_dst, x, st.num_nodes, bias=None if bias is None else _f32c(bias))
+
+    @staticmethod
+    def backward(ctx, g):
+        st, norm = ctx.st, ctx.norm
+        g = _f32c(g)
+        gx = spmm_csr(st.by_src, norm.by_src, g, st.num_nodes) if ctx.needs_input_grad[0] else None
+        gb = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return gx, gb, None, None
+
+
+def propagate(x, bias, st: EdgeStructure, norm: GcnNorm):
+    return _Propagate.apply(x, bias, st, norm)
+
+
+class _EdgeGatherConcat(torch.autograd.Function):
+    """cat(z[src], z[dst] [, extra]) per edge (gnn.py:173-175).  Backward = two segment sums."""
+
+    @staticmethod
+    def forward(ctx, z, st: EdgeStructure, extra):
+        lib = _lib.load()
+        _lib.require_device(z, extra)
+        z = _f32c(z)
+        e, d = st.num_edges, z.shape[1]
+        width = 2 * d + (1 if extra is not None else 0)
+        out = torch.empty(e, width, dtype=torch.float32, device=z.device)
+        ex = None if extra is None else _f32c(extra)
+        with torch.cuda.device(z.device):
+            _lib.check(lib.pangnn_edge_gather_concat_f32(z.data_ptr(), z.stride(0), z.shape[0],
+                                                         st.edge_index.data_ptr(), e, 0, e, _lib.ptr(ex),
+                                                         out.data_ptr(), out.stride(0), d,
+                                                         _lib.stream_ptr()), "pangnn_edge_gather_concat_f32")
+        ctx.st, ctx.d = st, d
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        st, d = ctx.st, ctx.d
+        g = _f32c(g)
+        gz = segment_sum_rows(st.by_src, g, 0, d, st.num_nodes)
+        segment_sum_rows(st.by_dst, g, d, d, st.num_nodes, out=gz, accumulate=True)
+        return gz, None, None
+
+
+def edge_gather_concat(z, st: EdgeStructure, extra=None):
+    return _EdgeGatherConcat.apply(z, st, extra)
+
+
+class _EdgePairAdd(torch.autograd.Function):
+    """h[e] = p[src_e] + q[dst_e] (+ extra[e] * cvec): the decoder's first Linear re-associated onto
+    nodes.  Backward = segment sums of g over out-edges (p) and in-edges (q)."""
+
+    @staticmethod
+    def forward(ctx, p, q, st: EdgeStructure, extra, cvec):
+        lib = _lib.load()
+        _lib.require_device(p, q, extra, cvec)
+        p, q = _f32c(p), _f32c(q)
+        assert p.shape == q.shape and p.stride(0) == q.stride(0)
+        e, d = st.num_edges, p.shape[1]
+        out = torch.empty(e, d, dtype=torch.float32, device=p.device)
+        ex = None if extra is None else _f32c(extra)
+        cv = None if cvec is None else _f32c(cvec)
+        with torch.cuda.device(p.device):
+            _lib.check(lib.pangnn_edge_pair_add_f32(p.data_ptr(), q.data_ptr(), p.stride(0), p.shape[0],
+                                                    st.edge_index.data_ptr(), e, 0, e, _lib.ptr(ex),
+                                                    _lib.ptr(cv), out.data_ptr(), out.stride(0), d,
+                                                    _lib.stream_ptr()), "pangnn_edge_pair_add_f32")
+        ctx.st, ctx.d = st, d
+        ctx.save_for_backward(ex)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        st, d = ctx.st, ctx.d
+        (ex,) = ctx.saved_tensors
+        g = _f32c(g)
+        gp = segment_sum_rows(st.by_src, g, 0, d, st.num_nodes) if ctx.needs_input_grad[0] else None
+        gq = segment_sum_rows(st.by_dst, g, 0, d, st.num_nodes) if ctx.needs_input_grad[1] else None
+        gc = (ex[: g.shape[0]].unsqueeze(0) @ g).squeeze(0) if (ex is not None and ctx.needs_input_grad[4]) else None
+        return gp, gq, None, None, gc
+
+
+def edge_pair_add(p, q, st: EdgeStructure, extra=None, cvec=None):
+    return _EdgePairAdd.apply(p, q, st, extra, cvec)
+
+
+class _SegmentMax(torch.autograd.Function):
+    """'max' aggregation of per-edge messages at the target node (convolution.py:7).  Rows without
+    in-edges are 0.  The gradient goes to the arg-max edge (first maximum on ties)."""
+
+    @staticmethod
+    def forward(ctx, msg, st: EdgeStructure):
+        lib = _lib.load()
+        _lib.require_device(msg)
+        msg = _f32c(msg)
+        n, f = st.num_nodes, msg.shape[1]
+        d = st.by_dst
+        out = torch.empty(n, f, dtype=torch.float32, device=msg.device)
+        arg = torch.empty(n, f, dtype=torch.int32, device=msg.device)
+        with torch.cuda.device(msg.device):
+            _lib.check(lib.pangnn_segment_max_rows_f32(d.rowptr.data_ptr(), _lib.ptr(d.perm), msg.data_ptr(),
+                                                       msg.stride(0), out.data_ptr(), arg.data_ptr(),
+                                                       out.stride(0), n, f, _lib.stream_ptr()),
+                       "pangnn_segment_max_rows_f32")
+        ctx.st, ctx.e = st, msg.shape[0]
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (arg,) = ctx.saved_tensors
+        st = ctx.st
+        g = _f32c(g)
+        n, f = g.shape
+        gm = torch.zeros(ctx.e, f, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.pangnn_segment_max_bwd_f32(g.data_ptr(), arg.data_ptr(), st.by_dst.rowptr.data_ptr(),
+                                                      gm.data_ptr(), gm.stride(0), g.stride(0), n, f,
+                                                      _lib.stream_ptr()), "pangnn_segment_max_bwd_f32")
+        return gm, None
+
+
+def segment_max(msg, st: EdgeStructure):
+    return _SegmentMax.apply(msg, st)
+
+
+class _SegmentSum(torch.autograd.Function):
+    """'add' aggregation of arbitrary per-edge messages at the target node (generic MessagePassing)."""
+
+    @staticmethod
+    def forward(ctx, msg, st: EdgeStructure):
+        msg = _f32c(msg)
+        ctx.st = st
+        return segment_sum_rows(st.by_dst, msg, 0, msg.shape[1], st.num_nodes)
+
+    @staticmethod
+    def backward(ctx, g):
+        # d out[i] / d msg[e] = [dst_e == i]  =>  gmsg[e] = g[dst_e]: a row gather
+        st = ctx.st
+        g = _f32c(g)
+        cat = _EdgeGatherConcat.apply(g, st, None)      # [E, 2F]: (g[src], g[dst])
+        return cat[:, g.shape[1]:], None
+
+
+def segment_sum(msg, st: EdgeStructure):
+    return _SegmentSum.apply(msg, st)

@@ -1,0 +1,149 @@
+"""`AlternateGCN` — drop-in for /root/reference/src/gnn.py:84-207 on MI355X.
+
+Same constructor signature (`device, dataset, categorical_nodes, dims=[node_dim, hidden_dim]`), same
+`forward(graph) -> logits [E]`, same `state_dict` keys and shapes:
+
+  embedding.{weight[D,1],bias[D]}   conv_in.{bias[H],lin.weight[H,D]}   conv_hidden.{bias[H],lin.weight[H,H]}
+  conv_out.{bias[D],lin.weight[D,H]}   linear_out.{weight[D,H],bias[D]}
+  mlp.0.{weight[D,2D(+1)],bias[D]}   mlp.2.{weight[D,D],bias[D]}   mlp.4.{weight[1,D],bias[1]}
+
+The reference reads its topology flags from a module-global argparse namespace
+(gnn.py:5,111,128,132,143,171-180); here they are constructor kwargs, and `args=` accepts that same
+namespace (anything with the attributes) so the reference's call site works unchanged.
+
+Decoder: `mlp.0` applied to cat(z[src], z[dst] [, w]) is computed in the re-associated form
+P[src] + Q[dst] (+ w*c) with P = z W_a^T, Q = z W_b^T + b — identical algebra, E*2D*D fewer
+multiply-adds and no [E, 2D] intermediate (pangnn_edge_pair_add_f32).  `fused_decoder=False`
+selects the literal gather-concat-Linear form (pangnn_edge_gather_concat_f32).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from . import functional as PF
+from .convolution import GCNConv
+from .graph import structure_of
+
+_FLAG_DEFAULTS = dict(union_edge_weights=False, base_model=False, skip_connections=False,
+                      decoder="mlp", neighbours=1)
+
+
+class AlternateGCN(nn.Module):
+    def __init__(self, device=None, dataset=None, categorical_nodes: bool = False, dims=(64, 128),
+                 args=None, num_nodes: Optional[int] = None, fused_decoder: bool = True, **flags):
+        super().__init__()
+        self.device = device
+        cfg = dict(_FLAG_DEFAULTS)
+        if args is not None:
+            for k in cfg:
+                if hasattr(args, k):
+                    cfg[k] = getattr(args, k)
+        unknown = set(flags) - set(cfg)
+        if unknown:
+            raise TypeError(f"unknown flags: {sorted(unknown)}")
+        cfg.update(flags)
+        self.flags = SimpleNamespace(**cfg)
+        self.fused_decoder = fused_decoder
+        node_embedding_dim, hidden_dim = dims
+
+        if categorical_nodes:
+            # The reference's categorical path cannot run (gnn.py:93 takes len() of a list of graphs,
+            # and x is float ones, dataset.py:369).  Build-defined semantics:
+            # x holds integer gene positions, one embedding row per node.
+            if num_nodes is None:
+                num_nodes = len(dataset.x) if hasattr(dataset, "x") else None
+            if num_nodes is None:
+                raise ValueError("categorical_nodes=True needs num_nodes=")
+            self.embedding = nn.Embedding(int(num_nodes), node_embedding_dim)
+        else:
+            self.embedding = nn.Linear(1, node_embedding_dim)
+        self.categorical_nodes = categorical_nodes
+
+        self.conv_in = GCNConv(node_embedding_dim, hidden_dim, add_self_loops=False)
+        self.conv_hidden = GCNConv(hidden_dim, hidden_dim, add_self_loops=False)
+        self.conv_out = GCNConv(hidden_dim, node_embedding_dim, add_self_loops=False)
+        self.linear_out = nn.Linear(hidden_dim, node_embedding_dim)
+        self.activation_fct = nn.ELU()
+        d = node_embedding_dim
+        self.mlp = nn.Sequential(
+            nn.Linear(2 * d + (1 if self.flags.skip_connections else 0), d), nn.ReLU(),
+            nn.Linear(d, d), nn.ReLU(), nn.Linear(d, 1))
+        self.epoch = 0
+        if device is not None:
+            self.to(device)
+
+    # ---------------------------------------------------------------------------------
+    def encode(self, graph) -> torch.Tensor:
+        fl = self.flags
+        x = graph.x
+        _lib.require_device(x)
+        if self.categorical_nodes:
+            x = x.long().view(-1)
+        h = self.embedding(x)
+        act = self.activation_fct
+        if fl.union_edge_weights:                                              # gnn.py:128-139
+            ei = graph.union_edge_index
+            h = act(self.conv_in(h, ei, graph.edge_attr, graph=graph, name="union"))
+            for _ in range(max(fl.neighbours - 2, 1)):
+                h = act(self.conv_hidden(h, ei, graph.edge_attr, graph=graph, name="union"))
+            h = act(self.conv_out(h, ei, graph=graph, name="union"))
+        elif fl.base_model:                                                    # gnn.py:143-150
+            h = act(self.conv_in(h, graph.edge_index, graph.edge_attr, graph=graph, name="sim"))
+            h = act(self.linear_out(h))
+        else:                                                                  # gnn.py:153-166
+            h = act(self.conv_in(h, graph.edge_index, graph.edge_attr, graph=graph, name="sim"))
+            h = act(self.conv_out(h, graph.neighbour_edge_index, graph=graph, name="nb"))
+        return h
+
+    def decode_mlp(self, z, graph) -> torch.Tensor:
+        fl = self.flags
+        ei = graph.edge_index
+        st = structure_of(ei, z.shape[0], holder=graph, name="sim")
+        d = z.shape[1]
+        extra = graph.edge_attr[: ei.shape[1]] if fl.skip_connections else None   # gnn.py:173
+        lin0 = self.mlp[0]
+        if self.fused_decoder and d % 4 == 0:
+            w = lin0.weight
+            p = z @ w[:, :d].t()
+            q = torch.addmm(lin0.bias, z, w[:, d:2 * d].t())
+            cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
+            h = PF.edge_pair_add(p, q, st, extra, cvec)
+        else:
+            h = lin0(PF.edge_gather_concat(z, st, extra))
+        for layer in list(self.mlp)[1:]:
+            h = layer(h)
+        return h.squeeze(-1)
+
+    def forward(self, graph) -> torch.Tensor:
+        fl = self.flags
+        nodes = self.encode(graph)
+        link_predictions = None
+        if "mlp" in fl.decoder:
+            link_predictions = self.decode_mlp(nodes, graph)
+        if "cosine" in fl.decoder:
+            link_predictions = self.cosine_sim(nodes, graph.edge_index, graph)
+        if "dot" in fl.decoder:
+            link_predictions = self.decode(nodes, graph.edge_index, graph)
+        return link_predictions
+
+    def _pairs(self, z, edge_index, graph=None):
+        st = structure_of(edge_index, z.shape[0], holder=graph, name="sim")
+        both = PF.edge_gather_concat(z, st)
+        d = z.shape[1]
+        return both[:, :d], both[:, d:]
+
+    def decode(self, z, edge_index, graph=None):
+        # gnn.py:202-204 is `z[src] @ z[dst]`, a shape error unless E == D (broken in the
+        # reference); build-defined semantics: per-edge dot product.
+        a, b = self._pairs(z, edge_index, graph)
+        return (a * b).sum(dim=1)
+
+    def cosine_sim(self, z, edge_index, graph=None):
+        a, b = self._pairs(z, edge_index, graph)
+        return F.cosine_similarity(a, b, dim=1)

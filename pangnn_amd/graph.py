@@ -1,0 +1,169 @@
+"""Device-resident graph structure for the message-passing kernels.
+
+The reference hands a COO `edge_index [2,E] int64` to `GCNConv` on every call
+(/root/reference/src/gnn.py:158,165) and PyG walks it with index_select / scatter_add.  The HIP
+kernels instead want the edges grouped by destination (forward) and by source (backward), with
+int32 neighbour ids.  `EdgeStructure` builds both groupings once per `edge_index` tensor on the
+GPU (stable radix sort => deterministic per-row order) and memoises the GCN normalisation per
+`edge_weight` tensor.  The caller's edge order is never changed: per-edge outputs (logits) stay in
+`edge_index` order, `perm` maps sorted positions back.
+"""
+from __future__ import annotations
+
+import weakref
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class CSR:
+    rowptr: torch.Tensor   # int64 [N+1]
+    other: torch.Tensor    # int32 [E]  opposite endpoint of each sorted edge
+    perm: torch.Tensor     # int32 [E]  original edge id of each sorted edge
+
+
+def build_csr(edge_index: torch.Tensor, num_nodes: int, group_by: int, validate: bool = True) -> CSR:
+    """pangnn_csr_build: group_by=1 rows are targets (edge_index[1]), 0 rows are sources."""
+    _lib.require_device(edge_index)
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be int64 [2,E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+    lib = _lib.load()
+    ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
+    e = ei.shape[1]
+    dev = ei.device
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=dev)
+    other = torch.empty(e, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws_bytes = lib.pangnn_csr_build_workspace_bytes(e, num_nodes)
+        if ws_bytes == 0:
+            raise _lib.PangnnHipError("pangnn_csr_build_workspace_bytes failed")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.pangnn_csr_build(ei.data_ptr(), e, e, num_nodes, group_by, rowptr.data_ptr(),
+                                        _lib.ptr(other), _lib.ptr(perm), ws.data_ptr(), ws_bytes,
+                                        _lib.stream_ptr()), "pangnn_csr_build")
+        if validate and e > 0:
+            # the flag lives in the workspace; view it as a tensor slice (device -> host 4 bytes)
+            off = lib.pangnn_csr_build_flag_ptr(ws.data_ptr(), e) - ws.data_ptr()
+            if int(ws[off:off + 4].view(torch.int32).item()) != 0:
+                raise ValueError(f"edge_index contains node ids outside [0, {num_nodes})")
+    return CSR(rowptr, other, perm)
+
+
+class EdgeStructure:
+    """Both groupings of one edge_index plus memoised GCN normalisations."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        self.edge_index = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(edge_index.shape[1])
+        self._by_dst: Optional[CSR] = None
+        self._by_src: Optional[CSR] = None
+        self._norm: Dict[Tuple, "GcnNorm"] = {}
+
+    @property
+    def by_dst(self) -> CSR:
+        if self._by_dst is None:
+            self._by_dst = build_csr(self.edge_index, self.num_nodes, 1)
+        return self._by_dst
+
+    @property
+    def by_src(self) -> CSR:
+        if self._by_src is None:
+            self._by_src = build_csr(self.edge_index, self.num_nodes, 0, validate=False)
+        return self._by_src
+
+    def gcn_norm(self, edge_weight: Optional[torch.Tensor]) -> "GcnNorm":
+        """norm for this edge_weight tensor (None = unit weights); cached on tensor identity."""
+        key = None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version,
+                                                tuple(edge_weight.shape))
+        hit = self._norm.get(key)
+        if hit is None:
+            hit = GcnNorm(self, edge_weight)
+            if len(self._norm) >= 4:
+                self._norm.pop(next(iter(self._norm)))
+            self._norm[key] = hit
+        return hit
+
+
+class GcnNorm:
+    """k1-k3 of SURVEY.md §2.2: deg^-1/2[src] * w * deg^-1/2[dst], in both CSR orders."""
+
+    def __init__(self, st: EdgeStructure, edge_weight: Optional[torch.Tensor]):
+        lib = _lib.load()
+        dev = st.edge_index.device
+        e, n = st.num_edges, st.num_nodes
+        if edge_weight is not None:
+            _lib.require_device(edge_weight)
+            if edge_weight.dim() != 1 or edge_weight.shape[0] < e:
+                raise ValueError(f"edge_weight must be [E>={e}], got {tuple(edge_weight.shape)}")
+            edge_weight = edge_weight.detach().to(torch.float32).contiguous()
+        d = st.by_dst
+        self.deg_inv_sqrt = torch.empty(n, dtype=torch.float32, device=dev)
+        self.by_dst = torch.empty(e, dtype=torch.float32, device=dev)    # CSR(dst) order
+        self.orig = torch.empty(e, dtype=torch.float32, device=dev)      # caller's edge order
+        with torch.cuda.device(dev):
+            _lib.check(lib.pangnn_gcn_norm_f32(d.rowptr.data_ptr(), _lib.ptr(d.other), _lib.ptr(d.perm),
+                                               _lib.ptr(edge_weight), n, e, self.deg_inv_sqrt.data_ptr(),
+                                               _lib.ptr(self.by_dst), _lib.ptr(self.orig),
+                                               _lib.stream_ptr()), "pangnn_gcn_norm_f32")
+        self._st = st
+        self._by_src: Optional[torch.Tensor] = None
+
+    @property
+    def by_src(self) -> torch.Tensor:
+        """norm re-ordered into CSR(src) order (needed by the transposed propagate only)."""
+        if self._by_src is None:
+            st, lib = self._st, _lib.load()
+            s = st.by_src
+            out = torch.empty_like(self.orig)
+            with torch.cuda.device(out.device):
+                _lib.check(lib.pangnn_permute_f32(_lib.ptr(self.orig), _lib.ptr(s.perm), _lib.ptr(out),
+                                                  st.num_edges, _lib.stream_ptr()), "pangnn_permute_f32")
+            self._by_src = out
+        return self._by_src
+
+
+# --------------------------------------------------------------------------------------
+# structure cache: the reference passes raw tensors on every call, so memoise on identity
+# --------------------------------------------------------------------------------------
+_CACHE: Dict[Tuple, EdgeStructure] = {}
+_CACHE_MAX = 16
+
+
+def structure_of(edge_index: torch.Tensor, num_nodes: int, holder=None, name: str = "") -> EdgeStructure:
+    """EdgeStructure for `edge_index`.  If `holder` (a Data/Batch object) is given the structure is
+    kept on it (`holder._pangnn_structs[name]`), otherwise in a small identity-keyed cache."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
+           edge_index.device.index)
+    if holder is not None:
+        d = getattr(holder, "_pangnn_structs", None)
+        if d is None:
+            d = {}
+            try:
+                setattr(holder, "_pangnn_structs", d)
+            except Exception:
+                d = None
+        if d is not None:
+            hit = d.get(name)
+            if hit is not None and hit[0] == key:
+                return hit[1]
+            st = EdgeStructure(edge_index, num_nodes)
+            d[name] = (key, st)
+            return st
+    hit = _CACHE.get(key)
+    if hit is not None:
+        return hit
+    st = EdgeStructure(edge_index, num_nodes)
+    if len(_CACHE) >= _CACHE_MAX:
+        _CACHE.pop(next(iter(_CACHE)))
+    _CACHE[key] = st
+    return st
+
+
+def clear_cache():
+    _CACHE.clear()

@@ -1,0 +1,298 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on identical
+inputs.  Integer / index results bit-exact; fp32 results within the north-star tolerance
+(1e-4 on link-prediction logits; the same bound relative to magnitude for intermediate tensors)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import (copy_graph, load_golden, random_graph, sub_graphs_from_golden,
+                      whole_graph_from_golden)
+from oracle import gcn_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4          # north_star: link-prediction logits within 1e-4 fp32
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, atol=ATOL, rtol=RTOL):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    ok = torch.allclose(a, b, atol=atol, rtol=rtol)
+    if not ok:
+        err = (a - b).abs()
+        print("max abs err", err.max().item(), "max |ref|", b.abs().max().item())
+    return ok
+
+
+# ---------------------------------------------------------------- structure build (bit-exact)
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (7, 1, 1), (100, 999, 2), (5000, 200000, 3), (33, 5000, 4)])
+@pytest.mark.parametrize("group_by", [0, 1])
+def test_csr_build_is_a_stable_sort(n, e, seed, group_by):
+    from pangnn_amd.graph import build_csr
+    ei, _ = random_graph(n, e, seed=seed, hub=min(e, 1500))
+    csr = build_csr(ei.to(dev()), n, group_by)
+    key = ei[group_by].numpy()
+    perm = np.argsort(key, kind="stable")
+    rowptr = np.searchsorted(key[perm], np.arange(n + 1), side="left")
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.perm.cpu().numpy().astype(np.int64), perm)
+    assert np.array_equal(csr.other.cpu().numpy().astype(np.int64), ei[1 - group_by].numpy()[perm])
+
+
+def test_csr_build_rejects_out_of_range_ids():
+    from pangnn_amd.graph import build_csr
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]], device=dev())
+    with pytest.raises(ValueError):
+        build_csr(ei, 5, 1)
+
+
+# ---------------------------------------------------------------- gcn_norm
+@pytest.mark.parametrize("weighted", [True, False])
+def test_gcn_norm_matches_oracle(weighted):
+    from pangnn_amd.graph import EdgeStructure
+    n, e = 3000, 40000
+    ei, w = random_graph(n, e, seed=5, hub=2500)
+    st = EdgeStructure(ei.to(dev()), n)
+    nrm = st.gcn_norm(w.to(dev()) if weighted else None)
+    ref = go.gcn_norm(ei, w if weighted else None, n)
+    assert close(nrm.orig, ref, atol=1e-7, rtol=1e-5)
+    assert close(nrm.by_dst, ref[st.by_dst.perm.cpu().long()], atol=1e-7, rtol=1e-5)
+    assert close(nrm.by_src, ref[st.by_src.perm.cpu().long()], atol=1e-7, rtol=1e-5)
+    deg = torch.zeros(n).scatter_add_(0, ei[1], w if weighted else torch.ones(e))
+    iso = deg == 0
+    assert iso.any() and torch.equal(nrm.deg_inv_sqrt.cpu()[iso], torch.zeros(int(iso.sum())))
+
+
+# ---------------------------------------------------------------- propagate (the ★ kernel)
+@pytest.mark.parametrize("F", [16, 32, 64, 128, 256, 20, 3])
+@pytest.mark.parametrize("n,e,hub", [(64, 0, None), (1, 5, None), (513, 7000, 3000), (2000, 30000, None)])
+def test_spmm_forward_backward_match_oracle(F, n, e, hub):
+    import pangnn_amd
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    torch.manual_seed(F + n)
+    ei, w = random_graph(n, e, seed=F + e, hub=hub)
+    x = torch.randn(n, F)
+    b = torch.randn(F)
+    xg = x.clone().to(dev()).requires_grad_(True)
+    bg = b.clone().to(dev()).requires_grad_(True)
+    st = EdgeStructure(ei.to(dev()), n)
+    out = PF.propagate(xg, bg, st, st.gcn_norm(w.to(dev())))
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = go.propagate_add(xr, ei, go.gcn_norm(ei, w, n)) + br
+    assert close(out, ref)
+    g = torch.randn(n, F)
+    out.backward(g.to(dev()))
+    ref.backward(g)
+    assert close(xg.grad, xr.grad) and close(bg.grad, br.grad)
+
+
+def test_spmm_is_bitwise_reproducible():
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    n, e = 4000, 300000
+    ei, w = random_graph(n, e, seed=11, hub=5000)
+    x = torch.randn(n, 128, device=dev())
+    outs = []
+    for _ in range(3):
+        st = EdgeStructure(ei.to(dev()), n)          # rebuilt: the sort is stable, so is the sum order
+        outs.append(PF.propagate(x, None, st, st.gcn_norm(w.to(dev()))))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_spmm_linearity_at_scale():
+    """size-independent property at a size the oracle would not finish quickly:
+    A(ax + by) == a A x + b A y, and A 1 == row sums of the normalised weights."""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    n, e = 200000, 6000000
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    ei = torch.randint(0, n, (2, e), generator=gen).to(dev())
+    w = (torch.rand(e, generator=gen) * 80 + 1).to(dev())
+    st = EdgeStructure(ei, n)
+    nrm = st.gcn_norm(w)
+    x, y = torch.randn(n, 128, device=dev()), torch.randn(n, 128, device=dev())
+    lhs = PF.propagate(2.0 * x - 3.0 * y, None, st, nrm)
+    rhs = 2.0 * PF.propagate(x, None, st, nrm) - 3.0 * PF.propagate(y, None, st, nrm)
+    assert close(lhs, rhs, atol=1e-4, rtol=1e-4)
+    ones = PF.propagate(torch.ones(n, 16, device=dev()), None, st, nrm)
+    rowsum = torch.zeros(n, device=dev()).index_add_(0, ei[1], nrm.orig)
+    assert close(ones[:, 0], rowsum, atol=1e-4, rtol=1e-4)
+    # transpose identity <A x, y> == <x, A^T y>
+    ax = PF.propagate(x, None, st, nrm)
+    aty = PF.spmm_csr(st.by_src, nrm.by_src, y, n)
+    l, r = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
+    assert abs(l - r) <= 1e-5 * max(abs(l), abs(r), 1.0)
+
+
+# ---------------------------------------------------------------- GCNConv module
+@pytest.mark.parametrize("weighted", [True, False])
+def test_gcnconv_module_matches_oracle_and_dense(weighted):
+    import pangnn_amd
+    torch.manual_seed(1)
+    n, e = 300, 4000
+    ei, w = random_graph(n, e, seed=7)
+    conv = pangnn_amd.GCNConv(64, 128).to(dev())
+    with torch.no_grad():
+        conv.bias.uniform_(-1, 1)
+    x = torch.randn(n, 64)
+    out = conv(x.to(dev()), ei.to(dev()), w.to(dev()) if weighted else None)
+    W, b = conv.lin.weight.detach().cpu(), conv.bias.detach().cpu()
+    assert close(out, go.gcn_conv(x, ei, w if weighted else None, W, b))
+    assert close(out, go.gcn_conv_dense(x.double(), ei, w.double() if weighted else None, W.double(), b.double()))
+
+
+# ---------------------------------------------------------------- whole model on the golden graphs
+def _pair(name_or_graph, dims, flags, seed=0, categorical=False):
+    import pangnn_amd
+    g = whole_graph_from_golden(name_or_graph) if isinstance(name_or_graph, str) else name_or_graph
+    if flags.get("union_edge_weights"):
+        g.edge_attr = g.union_edge_attr       # dataset.py:380: Data(x, ei, union_edge_weights, y)
+    torch.manual_seed(seed)
+    n = g.x.shape[0]
+    oracle = go.AlternateGCNOracle(dims=dims, flags=go.default_flags(**flags), categorical_nodes=categorical,
+                                   num_nodes=n)
+    with torch.no_grad():
+        for k, p in oracle.named_parameters():
+            if k.endswith("bias"):
+                p.uniform_(-0.5, 0.5)         # PyG initialises conv biases to 0; make them count
+    model = pangnn_amd.AlternateGCN(dev(), None, categorical, dims=list(dims), num_nodes=n, **flags)
+    model.load_state_dict(oracle.state_dict())      # identical key names: files interchange
+    if categorical:
+        g.x = torch.arange(n)
+    return g, copy_graph(g, dev()), oracle, model
+
+
+FLAG_SETS = [dict(), dict(skip_connections=True), dict(base_model=True), dict(union_edge_weights=True),
+             dict(union_edge_weights=True, neighbours=4), dict(decoder="cosine"), dict(decoder="dot")]
+
+
+@pytest.mark.parametrize("name,dims", [("sim_200x4", (64, 128)), ("cfg1_2genomes", (64, 128)),
+                                        ("cfg2_sim_1000x5", (64, 64)), ("cfg3_5genomes", (64, 128))])
+@pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k}={v}" for k, v in f.items()) or "default")
+def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
+    g, gd, oracle, model = _pair(name, dims, flags)
+    ref = oracle(g)
+    out = model(gd)
+    assert out.shape == ref.shape == (g.edge_index.shape[1],)
+    assert close(out, ref)
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    lr = torch.nn.functional.binary_cross_entropy_with_logits(ref, g.y, pos_weight=pw)
+    lo = torch.nn.functional.binary_cross_entropy_with_logits(out, gd.y, pos_weight=pw.to(dev()))
+    assert close(lo, lr, atol=1e-5, rtol=1e-5)
+    lr.backward()
+    lo.backward()
+    po = dict(oracle.named_parameters())
+    for k, p in model.named_parameters():
+        if po[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = float(po[k].grad.abs().max()) + 1e-12
+        assert close(p.grad, po[k].grad, atol=1e-4 * scale + 1e-7, rtol=1e-3), k
+
+
+def test_unfused_decoder_equals_fused_decoder():
+    g, gd, oracle, model = _pair("cfg1_2genomes", (64, 128), dict(skip_connections=True))
+    a = model(gd)
+    model.fused_decoder = False
+    b = model(gd)
+    assert close(a, b, atol=2e-5, rtol=1e-5) and close(b, oracle(g))
+
+
+def test_categorical_nodes_build_defined_semantics():
+    g, gd, oracle, model = _pair("sim_200x4", (64, 128), dict(), categorical=True)
+    assert close(model(gd), oracle(g))
+
+
+@pytest.mark.parametrize("name", ["cfg1_2genomes", "cfg3_5genomes", "cfg2_sim_1000x5"])
+def test_minibatch_of_32_subgraphs_matches_oracle(name):
+    """the reference's actual training regime: DataLoader(batch_size=32) over per-group sub-graphs"""
+    import pangnn_amd
+    from pangnn_amd.data import Batch, Data
+    subs = sub_graphs_from_golden(name, count=64)
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 128))
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+    model.load_state_dict(oracle.state_dict())
+    for lo in (0, 32):
+        chunk = subs[lo:lo + 32]
+        if not chunk:
+            continue
+        ref = oracle(go.collate(chunk))
+        b = Batch.from_data_list([Data(s.x, s.edge_index, s.edge_attr, s.y,
+                                       neighbour_edge_index=s.neighbour_edge_index) for s in chunk]).to(dev())
+        assert close(model(b), ref)
+
+
+def test_train_steps_track_the_oracle():
+    from pangnn_amd.train import make_optimizer, train_step
+    g, gd, oracle, model = _pair("cfg2_sim_1000x5", (64, 64), dict())
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    opt_o = torch.optim.Adam(oracle.parameters(), lr=1e-3)
+    opt_m = make_optimizer(model)
+    for step in range(5):
+        lo, _ = go.train_step(oracle, opt_o, g, g.y, pw)
+        lm, out = train_step(model, opt_m, gd, gd.y, pw.to(dev()))
+        assert close(lm, lo, atol=1e-4, rtol=1e-4), step
+    assert close(model(gd), oracle(g), atol=5e-4, rtol=5e-4)   # 5 Adam steps of drift allowed
+
+
+# ---------------------------------------------------------------- EdgeConv / MessagePassing API
+def test_edge_conv_max_aggregation_matches_oracle():
+    import pangnn_amd
+    torch.manual_seed(3)
+    n, e, c, o = 200, 1500, 8, 12
+    ei, _ = random_graph(n, e, seed=9)
+    ref_m = go.EdgeConvOracle(c, o)
+    m = pangnn_amd.EdgeConv(c, o).to(dev())
+    m.load_state_dict(ref_m.state_dict())
+    x = torch.randn(n, c)
+    xr = x.clone().requires_grad_(True)
+    xg = x.clone().to(dev()).requires_grad_(True)
+    ref, out = ref_m(xr, ei), m(xg, ei.to(dev()))
+    assert close(out, ref)
+    gsel = torch.randn(n, o)
+    ref.backward(gsel)
+    out.backward(gsel.to(dev()))
+    assert close(xg.grad, xr.grad)
+    for (k, p), (_, q) in zip(m.named_parameters(), ref_m.named_parameters()):
+        assert close(p.grad, q.grad, atol=1e-4, rtol=1e-3), k
+
+
+def test_generic_message_passing_add():
+    import pangnn_amd
+
+    class WeightedSum(pangnn_amd.MessagePassing):
+        def __init__(self):
+            super().__init__(aggr="add")
+
+        def forward(self, x, edge_index, w):
+            return self.propagate(edge_index, x=x, w=w)
+
+        def message(self, x_j, w):
+            return w.view(-1, 1) * x_j
+
+    n, e = 100, 900
+    ei, w = random_graph(n, e, seed=2)
+    x = torch.randn(n, 16)
+    out = WeightedSum()(x.to(dev()), ei.to(dev()), w.to(dev()))
+    ref = torch.zeros(n, 16).index_add_(0, ei[1], w.view(-1, 1) * x[ei[0]])
+    assert close(out, ref, atol=1e-3, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- decoder gathers, direct C-ABI use
+def test_edge_gather_concat_exact():
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    n, e, d = 500, 4000, 64
+    ei, w = random_graph(n, e, seed=4)
+    z = torch.randn(n, d)
+    st = EdgeStructure(ei.to(dev()), n)
+    a = PF.edge_gather_concat(z.to(dev()), st)
+    assert torch.equal(a.cpu(), torch.cat([z[ei[0]], z[ei[1]]], dim=1))            # pure copies: bit-exact
+    b = PF.edge_gather_concat(z.to(dev()), st, w.to(dev()))
+    assert torch.equal(b.cpu(), torch.cat([z[ei[0]], z[ei[1]], w.unsqueeze(1)], dim=1))
