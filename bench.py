@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — edges/s of the panGNN link-prediction train step (GCNConv propagate fwd+bwd, edge
+decoder, BCE, Adam) on 1..8 MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json: the config the metric is quoted on): `--simulate_dataset 50000 20 0.2 100 20`
+(N = 1e6 genes, ~7.4e7 directed similarity edges, 3e6 neighbour edges), node_dim 64, hidden_dim 128,
+fp32, the whole graph as one batch.  A step = zero_grad -> forward -> BCEWithLogits(pos_weight) ->
+backward -> Adam; inputs are resident in HBM before the timed region; no host sync inside it.
+At N > 1 the same graph is destination-partitioned over the ranks (strong scaling) with RCCL
+all-gather / reduce-scatter of node embeddings (pangnn_amd/dist.py).
+
+One JSON line on rank 0: value = supervised similarity edges per second over the whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (genes/genome, genomes, frac_pos, fragments, shuffled, node_dim, hidden_dim)
+    "cfg4": (50000, 20, 0.2, 100, 20, 64, 128),
+    "cfg2": (1000, 5, 0.3, 10, 2, 64, 64),
+}
+HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def spmm_alg_bytes(e, n, f, s=4):
+    """B_spmm(E,N,F) = E*(4 + 4 + F*s) + N*F*s + (N+1)*8"""
+    return e * (8 + f * s) + n * f * s + (n + 1) * 8
+
+
+def cpu_baseline(args, d, h):
+    """The oracle train step (index_select -> mul -> index_add_ GCNConv, literal cat+MLP decoder) on the
+    host cores of this box, on a bounded sample of the same workload."""
+    from oracle import gcn_oracle as go
+    from pangnn_amd import simulate
+    genes = args.cpu_genes
+    _, G, frac, frags, shuf, _, _ = WORKLOADS[args.workload]
+    g = simulate.simulate_graph(genes, G, frac, frags, shuf, seed=1, device="cpu")
+    torch.manual_seed(0)
+    m = go.AlternateGCNOracle(dims=(d, h))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    go.train_step(m, opt, g, g.y, g.class_balance)
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < args.cpu_steps:
+        go.train_step(m, opt, g, g.y, g.class_balance)
+        steps += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = time.perf_counter() - t0
+    e = g.edge_index.shape[1]
+    return {"value": e * steps / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf} (E_sim={e}), {steps} whole-graph "
+                      f"train steps of oracle/gcn_oracle.py, {dt / steps * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--genes", type=int, default=None, help="override genes per genome (debug)")
+    ap.add_argument("--cpu-genes", type=int, default=1000)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import pangnn_amd
+    from pangnn_amd import functional as PF
+    from pangnn_amd import simulate
+    from pangnn_amd.train import make_optimizer, train_step
+
+    genes, G, frac, frags, shuf, d, h = WORKLOADS[args.workload]
+    if args.genes:
+        genes = args.genes
+    t_gen = time.perf_counter()
+    g = simulate.simulate_graph(genes, G, frac, frags, shuf, seed=args.seed, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    n, e_sim, e_nb = g.num_nodes, g.edge_index.shape[1], g.neighbour_edge_index.shape[1]
+
+    torch.manual_seed(0)
+    if world > 1:
+        from pangnn_amd import dist as pdist
+        part = pdist.partition_graph(g, rank, world)
+        model = pdist.DistAlternateGCN(dev, dims=[d, h], part=part)
+        graph, labels = part, part.y
+        pos_weight = g.class_balance
+        step_fn = lambda: pdist.train_step(model, opt, graph, labels, pos_weight)   # noqa: E731
+        del g
+    else:
+        model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h])
+        graph, labels, pos_weight = g, g.y, g.class_balance
+        step_fn = lambda: train_step(model, opt, graph, labels, pos_weight)         # noqa: E731
+    opt = make_optimizer(model)
+
+    t_struct = time.perf_counter()
+    for _ in range(args.warmup):          # first warm-up step also builds CSR/CSC + norms (cached)
+        step_fn()
+    torch.cuda.synchronize()
+    t_struct = time.perf_counter() - t_struct
+
+    PF.KERNEL_TIMER = {"sim.fwd": [], "sim.bwd": []}
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step_fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    timer, PF.KERNEL_TIMER = PF.KERNEL_TIMER, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    k_fwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["sim.fwd"]]
+    k_bwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["sim.bwd"]]
+    if rank == 0:
+        t_k = sum(k_fwd) / max(len(k_fwd), 1)
+        rows_local = n if world == 1 else graph.n_local
+        e_local = e_sim if world == 1 else graph.e_sim_local
+        b_alg = spmm_alg_bytes(e_local, rows_local, h)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(f"{args.workload}_n{world}_spmm_fwd_bytes")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "edges/sec in GNN forward+backward (link-pred train step)",
+            "value": e_sim * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf}, whole graph as one batch, "
+                                   f"node_dim={d} hidden_dim={h}, AlternateGCN default topology, mlp decoder",
+                       "nodes": n, "sim_edges": e_sim, "neighbour_edges": e_nb,
+                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, all-gather/reduce-scatter",
+                       "graph_build_s": round(t_gen, 3), "warmup_incl_structure_s": round(t_struct, 3),
+                       "final_loss": float(loss.item())},
+            "roofline": {"bound": "hbm", "kernel": f"spmm_row_kernel<{h}> (conv_in propagate fwd)",
+                         "achieved": b_alg / t_k / 1e9 if t_k > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": (b_alg / t_k) / HBM_PEAK if t_k > 0 else None, "traffic": traffic,
+                         "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_k * 1e3,
+                         "bwd_avg_launch_ms": (sum(k_bwd) / max(len(k_bwd), 1)) * 1e3},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, d, h)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

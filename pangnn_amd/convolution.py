@@ -129,7 +129,7 @@ class GCNConv(MessagePassing):
             raise ValueError(f"edge_weight has {edge_weight.shape[0]} entries for {st.num_edges} edges")
         norm = st.gcn_norm(edge_weight)
         xw = self.lin(x.float())
-        return PF.propagate(xw, self.bias, st, norm)
+        return PF.propagate(xw, self.bias, st, norm, tag=name or None)
 
     def message(self, x_j, edge_weight):            # kept for API parity; forward() is fused
         return edge_weight.view(-1, 1) * x_j

@@ -24,10 +24,11 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const int64_t* __rest
 __global__ __launch_bounds__(kBlock) void other_end_kernel(const int64_t* __restrict__ other_row,
                                                            const int32_t* __restrict__ perm,
                                                            int32_t* __restrict__ other, int64_t e,
-                                                           int64_t n) {
+                                                           int64_t n, int* __restrict__ bad) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < e;
        i += (int64_t)gridDim.x * kBlock) {
     int64_t v = other_row[perm[i]];
+    if (v < 0 || v >= n) *bad = 1;
     v = v < 0 ? 0 : (v >= n ? n - 1 : v);  // clamp: an out-of-range id must never become a wild gather
     other[i] = (int32_t)v;
   }
@@ -129,7 +130,7 @@ extern "C" int pangnn_csr_build(const int64_t* edge_index, int64_t ld, int64_t n
                                 (unsigned)key_bits(num_nodes), s);
   PG_CHECK_ARG(e == hipSuccess, (int)e, "pangnn_csr_build: radix sort failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(other_end_kernel, dim3(grid_for(num_edges)), dim3(kBlock), 0, s, other_row, perm,
-                     other, num_edges, num_nodes);
+                     other, num_edges, num_nodes, bad);
   PG_CHECK_LAUNCH("pangnn_csr_build(other)");
   hipLaunchKernelGGL(rowptr_kernel, dim3(grid_for(num_nodes + 1)), dim3(kBlock), 0, s, keys_out, rowptr,
                      num_edges, num_nodes);

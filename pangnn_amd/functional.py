@@ -16,9 +16,15 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Optional kernel timing for bench.py: when KERNEL_TIMER is a dict, every spmm launch whose `tag` is
+# a key gets a (start, end) torch.cuda.Event pair recorded on the launch stream (= torch's current
+# stream, the one passed to the C ABI) around the launch.
+KERNEL_TIMER = None
+
+
 def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int,
              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-             accumulate: bool = False) -> torch.Tensor:
+             accumulate: bool = False, tag: Optional[str] = None) -> torch.Tensor:
     """out[r] (+)= bias + sum_e val[e] * x[other[e]]  — pangnn_spmm_csr_f32."""
     lib = _lib.load()
     _lib.require_device(x, csr.rowptr, val, bias)
@@ -27,11 +33,18 @@ def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int
     if out is None:
         out = torch.empty(n_rows, f, dtype=torch.float32, device=x.device)
         accumulate = False
+    timed = KERNEL_TIMER is not None and tag in KERNEL_TIMER
     with torch.cuda.device(x.device):
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _lib.check(lib.pangnn_spmm_csr_f32(csr.rowptr.data_ptr(), _lib.ptr(csr.other), _lib.ptr(val),
                                            x.data_ptr(), x.stride(0), x.shape[0], _lib.ptr(bias),
                                            out.data_ptr(), out.stride(0), n_rows, f, int(accumulate),
                                            _lib.stream_ptr()), "pangnn_spmm_csr_f32")
+        if timed:
+            ev1.record()
+            KERNEL_TIMER[tag].append((ev0, ev1))
     return out
 
 
@@ -58,22 +71,24 @@ class _Propagate(torch.autograd.Function):
     leaf without grad in the reference: SURVEY.md §8 a6)."""
 
     @staticmethod
-    def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm):
-        ctx.st, ctx.norm = st, norm
+    def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
+        ctx.st, ctx.norm, ctx.tag = st, norm, tag
         ctx.has_bias = bias is not None
-        return spmm_csr(st.by_dst, norm.by_dst, x, st.num_nodes, bias=None if bias is None else _f32c(bias))
+        return spmm_csr(st.by_dst, norm.by_dst, x, st.num_nodes, bias=None if bias is None else _f32c(bias),
+                        tag=None if tag is None else tag + ".fwd")
 
     @staticmethod
     def backward(ctx, g):
         st, norm = ctx.st, ctx.norm
         g = _f32c(g)
-        gx = spmm_csr(st.by_src, norm.by_src, g, st.num_nodes) if ctx.needs_input_grad[0] else None
+        gx = spmm_csr(st.by_src, norm.by_src, g, st.num_nodes,
+                      tag=None if ctx.tag is None else ctx.tag + ".bwd") if ctx.needs_input_grad[0] else None
         gb = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
-        return gx, gb, None, None
+        return gx, gb, None, None, None
 
 
-def propagate(x, bias, st: EdgeStructure, norm: GcnNorm):
-    return _Propagate.apply(x, bias, st, norm)
+def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
+    return _Propagate.apply(x, bias, st, norm, tag)
 
 
 class _EdgeGatherConcat(torch.autograd.Function):

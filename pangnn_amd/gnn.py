@@ -117,7 +117,8 @@ class AlternateGCN(nn.Module):
         else:
             h = lin0(PF.edge_gather_concat(z, st, extra))
         for layer in list(self.mlp)[1:]:
-            h = layer(h)
+            # [E, D] intermediates are the largest tensors of the step: rectify them in place
+            h = torch.relu_(h) if isinstance(layer, nn.ReLU) else layer(h)
         return h.squeeze(-1)
 
     def forward(self, graph) -> torch.Tensor:

