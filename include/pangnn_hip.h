@@ -124,6 +124,34 @@ int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t
                                float* gm, int64_t ldm, int64_t ldo, int64_t n_rows, int32_t F,
                                pangnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused link decoder, node_dim D = 64 (k7 + the per-edge MLP, src/gnn.py:110-116,171-177):
+ *   h1[e]   = relu(p[src_e] + q[dst_e] (+ extra[e] * cvec))     p = z W1[:, :D]^T, q = z W1[:, D:2D]^T + b1
+ *   h2[e]   = relu(w2 h1[e] + b2)                               w2 [D,D] row-major [out][in]  (mlp.2)
+ *   logits[e] = w3 . h2[e] + b3                                 w3 [D], b3 [1]                (mlp.4)
+ * Edges are taken in the caller's order, e in [0, num_edges) of edge_index[2][ld].  No [E, D]
+ * intermediate touches HBM in the forward pass.  fp32 MFMA (exact fp32 products and sums).
+ *
+ * Backward: given g_logits[E], recomputes the forward and returns
+ *   g_h1[E, D] = dL/d(h1 pre-activation)  (the caller segment-sums it into g_p by source and g_q by
+ *   target with pangnn_segment_sum_rows_f32), and the parameter gradients g_w2[D,D], g_b2[D],
+ *   g_w3[D], g_b3[1], g_cvec[D] (nullable).  Reproducible: per-workgroup partial slabs in
+ *   `workspace`, summed in a fixed order; no float atomics.
+ * ---------------------------------------------------------------------------------------- */
+int pangnn_decoder_mlp_fwd_f32(const float* p, const float* q, int64_t num_nodes,
+                               const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                               const float* extra, const float* cvec, const float* w2, const float* b2,
+                               const float* w3, const float* b3, int32_t D, float* logits,
+                               pangnn_stream_t stream);
+size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges);
+int pangnn_decoder_mlp_bwd_f32(const float* p, const float* q, int64_t num_nodes,
+                               const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                               const float* extra, const float* cvec, const float* w2, const float* b2,
+                               const float* w3, const float* b3, int32_t D, const float* g_logits,
+                               float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
+                               float* g_cvec, void* workspace, size_t workspace_bytes,
+                               pangnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,441 @@
+// Fused link decoder for D = 64 (src/gnn.py:110-116,171-177), fp32, gfx950.
+//
+//   h1[e]   = relu(P[src_e] + Q[dst_e] (+ w_e * c))         P = z W1a^T, Q = z W1b^T + b1  (node level)
+//   h2[e]   = relu(W2 h1[e] + b2)
+//   logit_e = w3 . h2[e] + b3
+//
+// One wavefront owns a tile of 32 consecutive edges (caller's edge order, so logits are written
+// coalesced and no permutation is needed).  The 32 x 64 h1 tile is gathered with row-contiguous
+// 16-byte loads (16 lanes per 256-B node row, 4 rows per wave-instruction) into a padded LDS
+// image and multiplied with W2 (LDS resident, loaded once per workgroup) on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, so results match an fp32 reference to rounding).
+// The product is oriented C[j][e] = sum_k W2[j][k] h1[e][k] (A = W2, B = h1^T): the edge index stays
+// on the lane, so bias + relu + the dot with w3 are in-lane and one xor-32 shuffle finishes a logit.
+//
+// Backward recomputes the forward per tile and chains three more MFMA products without leaving the
+// CU:  G = dL/dh2pre (in the accumulator registers of the first product, used directly as the A
+// operand of the second), gH1 = G^T W2 (written out as dL/dh1pre [E,64]), gW2 += G h1 (operands
+// re-read from LDS).  Parameter gradients are accumulated in registers across all tiles of a wave,
+// reduced over the workgroup's waves in a fixed order and written as one partial slab per workgroup;
+// a second tiny kernel sums the slabs in index order => bitwise reproducible, no float atomics.
+#include "common.h"
+
+namespace pangnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DD = 64;        // decoder width (node_dim)
+constexpr int TE = 32;        // edges per wave tile
+constexpr int GS = 33;        // row stride of the G tile (floats): conflict-free column reads
+constexpr int SLAB = 64 * 64 + 64 + 64 + 64 + 16;   // gW2 | gb2 | gw3 | gcvec | gb3(+pad)
+
+// LDS images of W2 [64][64] and of the h1 tile [32][64] use a padded row stride of 68 floats
+// (272 B): 16-byte aligned, ds_read_b128 down a column of rows is conflict-free (bank = 4*row + 4*k4
+// mod 64 is distinct over each 16-lane service group), row-wise b32/b128 accesses are contiguous, and
+// every address is `lane base + compile-time offset` (an XOR swizzle costs a VGPR per address).
+constexpr int RS = 68;
+__device__ __forceinline__ constexpr int swz(int row, int k) { return row * RS + k; }
+__device__ __forceinline__ constexpr int swz4(int row, int k4) { return row * RS + 4 * k4; }
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave execute in issue order; this only pins the compiler's ordering.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// row of the 32x32 MFMA accumulator held in register r by a lane of half hh
+__device__ __forceinline__ constexpr int jr(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+struct DecParams {
+  const float* p; const float* q;
+  const int64_t* ei; int64_t ld; int64_t E;
+  const float* extra; const float* cvec;
+  const float* w2; const float* b2; const float* w3; const float* b3;
+};
+
+// ---- stage W2 / b2 / w3 (/ cvec) into LDS, once per workgroup
+__device__ __forceinline__ void stage_weights(const DecParams& a, float* Wl, float* b2l, float* w3l,
+                                              float* cvl, int nthreads) {
+  for (int i = threadIdx.x; i < 64 * 16; i += nthreads) {
+    const int j = i >> 4, k4 = i & 15;
+    const float4 v = reinterpret_cast<const float4*>(a.w2)[i];
+    *reinterpret_cast<float4*>(Wl + swz4(j, k4)) = v;
+  }
+  for (int i = threadIdx.x; i < 64; i += nthreads) {
+    b2l[i] = a.b2[i];
+    w3l[i] = a.w3[i];
+    cvl[i] = a.cvec ? a.cvec[i] : 0.f;
+  }
+}
+
+// ---- gather the tile's 32 h1 rows into the wave's LDS image.  Returns w_e / validity per lane e.
+__device__ __forceinline__ void gather_tile(const DecParams& a, int64_t ebase, int lane, float* Ht,
+                                            const float* cvl, float& w_e) {
+  const int64_t e = ebase + (lane & 31);
+  int id = 0;
+  w_e = 0.f;
+  if (e < a.E) {
+    id = (int)a.ei[(int64_t)(lane >> 5) * a.ld + e];     // lanes 0-31: source, 32-63: target
+    if (a.extra && lane < 32) w_e = a.extra[e];
+  }
+  const int c4 = lane & 15, r4 = lane >> 4;
+  const float4* P4 = reinterpret_cast<const float4*>(a.p);
+  const float4* Q4 = reinterpret_cast<const float4*>(a.q);
+  float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.extra) cv = reinterpret_cast<const float4*>(cvl)[c4];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float4 pv[4], qv[4];
+    float wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * (4 * half + i) + r4;
+      const int s = __shfl(id, row);
+      const int d = __shfl(id, 32 + row);
+      wv[i] = __shfl(w_e, row);
+      pv[i] = P4[(uint32_t)s * 16u + c4];
+      qv[i] = Q4[(uint32_t)d * 16u + c4];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * (4 * half + i) + r4;
+      float4 h;
+      h.x = fmaxf(pv[i].x + qv[i].x + wv[i] * cv.x, 0.f);
+      h.y = fmaxf(pv[i].y + qv[i].y + wv[i] * cv.y, 0.f);
+      h.z = fmaxf(pv[i].z + qv[i].z + wv[i] * cv.z, 0.f);
+      h.w = fmaxf(pv[i].w + qv[i].w + wv[i] * cv.w, 0.f);
+      *reinterpret_cast<float4*>(Ht + swz4(row, c4)) = h;
+    }
+  }
+}
+
+// ---- C[j][e] = sum_k W2[j][k] h1[e][k]; lane (e = lane&31, hh = lane>>5) gets rows jr(r,hh)+32b
+__device__ __forceinline__ void gemm1(const float* Wl, const float* Ht, int lane, f32x16 (&acc)[2]) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k4 = 8 * h + i;
+    const float4 bf = *reinterpret_cast<const float4*>(Ht + swz4(r, k4));
+    const float4 a0 = *reinterpret_cast<const float4*>(Wl + swz4(r, k4));
+    const float4 a1 = *reinterpret_cast<const float4*>(Wl + swz4(r + 32, k4));
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf.x, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf.y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf.y, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf.z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf.z, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf.w, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf.w, acc[1], 0, 0, 0);
+  }
+}
+
+constexpr int FWD_WAVES = 16;   // 1024 threads, 1 workgroup / CU, 4 waves / SIMD
+constexpr int BWD_WAVES = 8;    // 512 threads,  1 workgroup / CU, 2 waves / SIMD
+
+__global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a, float* __restrict__ logits,
+                                                                    int64_t n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[64 * RS + 3 * 64 + FWD_WAVES * TE * RS];
+  float* Wl = lds;
+  float* b2l = lds + 64 * RS;
+  float* w3l = b2l + 64;
+  float* cvl = w3l + 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* Ht = cvl + 64 + wave * (TE * RS);
+  stage_weights(a, Wl, b2l, w3l, cvl, FWD_WAVES * 64);
+  __syncthreads();
+  const float b3 = a.b3[0];
+  const int hh = lane >> 5;
+  for (int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave; tile < n_tiles;
+       tile += (int64_t)gridDim.x * FWD_WAVES) {
+    const int64_t ebase = tile * TE;
+    float w_e;
+    gather_tile(a, ebase, lane, Ht, cvl, w_e);
+    wave_lds_sync();
+    f32x16 acc[2];
+    gemm1(Wl, Ht, lane, acc);
+    float part = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int j0 = 32 * b + 8 * qd + 4 * hh;
+        const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
+        const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+        part = fmaf(fmaxf(acc[b][4 * qd + 0] + bb.x, 0.f), ww.x, part);
+        part = fmaf(fmaxf(acc[b][4 * qd + 1] + bb.y, 0.f), ww.y, part);
+        part = fmaf(fmaxf(acc[b][4 * qd + 2] + bb.z, 0.f), ww.z, part);
+        part = fmaf(fmaxf(acc[b][4 * qd + 3] + bb.w, 0.f), ww.w, part);
+      }
+    part += __shfl_xor(part, 32);
+    if (lane < 32 && ebase + lane < a.E) logits[ebase + lane] = part + b3;
+    wave_lds_sync();   // the next gather overwrites Ht
+  }
+}
+
+__global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
+    DecParams a, const float* __restrict__ g_logits, float* __restrict__ g_h1,
+    float* __restrict__ slabs, int64_t n_tiles) {
+  constexpr int PER_WAVE = TE * RS + 64 * GS + 64;   // Ht | H2t | w_e | g_e
+  __shared__ __attribute__((aligned(16))) float lds[64 * RS + 3 * 64 + BWD_WAVES * PER_WAVE];
+  float* Wl = lds;
+  float* b2l = lds + 64 * RS;
+  float* w3l = b2l + 64;
+  float* cvl = w3l + 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* Ht = cvl + 64 + wave * PER_WAVE;
+  float* Gt = Ht + TE * RS;
+  float* wl = Gt + 64 * GS;
+  float* gl = wl + 32;
+  stage_weights(a, Wl, b2l, w3l, cvl, BWD_WAVES * 64);
+  __syncthreads();
+  const int hh = lane >> 5, r = lane & 31;
+
+  f32x16 acc3[2][2];   // gW2[j = jr(i,hh)+32bj][k = r+32bk]
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc3[x][0][i] = 0.f; acc3[x][1][i] = 0.f; }
+  }
+  const float w3j[2] = {w3l[r], w3l[r + 32]};
+  float gw3p[2] = {0.f, 0.f};   // lane (j = r+32bj, h): partial of gw3[j] over edges e = h mod 2
+  float gb2p[2] = {0.f, 0.f};   // same lanes: partial of gb2[j]
+  float gcv[2] = {0.f, 0.f};    // lane (k = r+32bp, hh): partial of gcvec[k]
+  float gb3p = 0.f;
+
+  for (int64_t tile = (int64_t)blockIdx.x * BWD_WAVES + wave; tile < n_tiles;
+       tile += (int64_t)gridDim.x * BWD_WAVES) {
+    const int64_t ebase = tile * TE;
+    float w_e;
+    gather_tile(a, ebase, lane, Ht, cvl, w_e);
+    float g_e = 0.f;
+    if (ebase + r < a.E) g_e = g_logits[ebase + r];
+    if (lane < 32) { wl[lane] = w_e; gl[lane] = g_e; gb3p += g_e; }
+    wave_lds_sync();
+
+    f32x16 acc[2];
+    gemm1(Wl, Ht, lane, acc);
+
+    // G[j][e] = g_e * w3[j] * [h2pre > 0]  (in place in acc; A operand of the next product);
+    // h2[j][e] goes to LDS: the weight-gradient product rebuilds G and g_e * h2 from it
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int j0 = 32 * b + 8 * qd + 4 * hh;
+        const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
+        const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+        const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+        const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = 4 * qd + c;
+          const float pre = acc[b][i] + bbv[c];
+          const bool on = pre > 0.f;
+          acc[b][i] = on ? g_e * wwv[c] : 0.f;
+          Gt[(j0 + c) * GS + r] = on ? pre : 0.f;
+        }
+      }
+    wave_lds_sync();
+
+    // gH1[e][k] = sum_j G[j][e] W2[j][k]  : A = G from the accumulator registers, B = W2 rows
+    f32x16 acc2[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc2[0][i] = 0.f; acc2[1][i] = 0.f; }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = 32 * b + jr(i, hh);
+        const float w0 = Wl[swz(j, r)];
+        const float w1 = Wl[swz(j, r + 32)];
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[b][i], w0, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[b][i], w1, acc2[1], 0, 0, 0);
+      }
+    // mask by h1 > 0, write dL/dh1pre, accumulate gcvec
+#pragma unroll
+    for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = jr(i, hh);
+        const int k = r + 32 * bp;
+        const float hval = Ht[swz(e, k)];
+        const float v = hval > 0.f ? acc2[bp][i] : 0.f;
+        if (ebase + e < a.E) g_h1[(ebase + e) * DD + k] = v;
+        gcv[bp] = fmaf(wl[e], v, gcv[bp]);
+      }
+
+    // gW2[j][k] += sum_e G[j][e] h1[e][k]  : both operands from LDS, reduction over the tile's edges
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int e = 2 * s + hh;
+      const float ge = gl[e];
+      const float x0 = Gt[r * GS + e];           // h2[j][e]
+      const float x1 = Gt[(r + 32) * GS + e];
+      const float a0 = x0 > 0.f ? ge * w3j[0] : 0.f;
+      const float a1 = x1 > 0.f ? ge * w3j[1] : 0.f;
+      gw3p[0] = fmaf(ge, x0, gw3p[0]);
+      gw3p[1] = fmaf(ge, x1, gw3p[1]);
+      gb2p[0] += a0;
+      gb2p[1] += a1;
+      const float h0 = Ht[swz(e, r)];
+      const float h1v = Ht[swz(e, r + 32)];
+      acc3[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, h0, acc3[0][0], 0, 0, 0);
+      acc3[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, h1v, acc3[0][1], 0, 0, 0);
+      acc3[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h0, acc3[1][0], 0, 0, 0);
+      acc3[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h1v, acc3[1][1], 0, 0, 0);
+    }
+    wave_lds_sync();   // next tile overwrites Ht / Gt / wl
+  }
+
+  // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
+  gw3p[0] += __shfl_xor(gw3p[0], 32);
+  gw3p[1] += __shfl_xor(gw3p[1], 32);
+  gb2p[0] += __shfl_xor(gb2p[0], 32);
+  gb2p[1] += __shfl_xor(gb2p[1], 32);
+  gcv[0] += __shfl_xor(gcv[0], 32);
+  gcv[1] += __shfl_xor(gcv[1], 32);
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) gb3p += __shfl_xor(gb3p, off);
+
+  __syncthreads();
+  float* red = cvl + 64;   // reuse the tile area: SLAB floats
+  for (int w = 0; w < BWD_WAVES; ++w) {
+    if (wave == w) {
+      const bool first = (w == 0);
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int idx = (32 * bj + jr(i, hh)) * 64 + r + 32 * bk;
+            red[idx] = (first ? 0.f : red[idx]) + acc3[bj][bk][i];
+          }
+      if (hh == 0) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          red[4096 + r + 32 * x] = (first ? 0.f : red[4096 + r + 32 * x]) + gb2p[x];
+          red[4096 + 64 + r + 32 * x] = (first ? 0.f : red[4096 + 64 + r + 32 * x]) + gw3p[x];
+          red[4096 + 128 + r + 32 * x] = (first ? 0.f : red[4096 + 128 + r + 32 * x]) + gcv[x];
+        }
+      }
+      if (lane == 0) red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * SLAB;
+  for (int i = threadIdx.x; i < 4096 + 193; i += BWD_WAVES * 64) slab[i] = red[i];
+}
+
+// out[i] = sum over workgroup slabs in index order (fixed => reproducible)
+__global__ __launch_bounds__(kBlock) void decoder_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                                float* __restrict__ g_w2,
+                                                                float* __restrict__ g_b2,
+                                                                float* __restrict__ g_w3,
+                                                                float* __restrict__ g_cvec,
+                                                                float* __restrict__ g_b3) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= 4096 + 193) return;
+  float s = 0.f;
+  for (int w = 0; w < n_slabs; ++w) s += slabs[(int64_t)w * SLAB + i];
+  if (i < 4096) g_w2[i] = s;
+  else if (i < 4096 + 64) g_b2[i - 4096] = s;
+  else if (i < 4096 + 128) g_w3[i - 4096 - 64] = s;
+  else if (i < 4096 + 192) { if (g_cvec) g_cvec[i - 4096 - 128] = s; }
+  else g_b3[0] = s;
+}
+
+static int grid_cus() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return cus;
+}
+
+static int check_common(const char* who, const float* p, const float* q, int64_t num_nodes,
+                        const int64_t* ei, int64_t ld, int64_t E, const float* extra,
+                        const float* cvec, const float* w2, const float* b2, const float* w3,
+                        const float* b3, int32_t D) {
+  PG_CHECK_ARG(D == DD, PANGNN_E_BADARG, "%s: fused decoder is built for node_dim 64, got %d", who, (int)D);
+  PG_CHECK_ARG(E >= 0 && ld >= E && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
+  PG_CHECK_ARG(num_nodes < (int64_t)1 << 24, PANGNN_E_TOOLARGE,
+               "%s: node table must stay under 4 GiB (N < 2^24 at 256 B per row)", who);
+  if (E == 0) return 0;
+  PG_CHECK_ARG(p && q && ei && w2 && b2 && w3 && b3 && (!extra || cvec), PANGNN_E_BADARG,
+               "%s: null pointer", who);
+  PG_CHECK_ARG(aligned16(p) && aligned16(q) && aligned16(w2), PANGNN_E_ALIGN,
+               "%s: p / q / w2 must be 16-byte aligned", who);
+  return 0;
+}
+
+}  // namespace pangnn
+
+using namespace pangnn;
+
+extern "C" int pangnn_decoder_mlp_fwd_f32(const float* p, const float* q, int64_t num_nodes,
+                                          const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                                          const float* extra, const float* cvec, const float* w2,
+                                          const float* b2, const float* w3, const float* b3,
+                                          int32_t D, float* logits, pangnn_stream_t stream) {
+  int rc = check_common("pangnn_decoder_mlp_fwd_f32", p, q, num_nodes, edge_index, ld, num_edges, extra,
+                        cvec, w2, b2, w3, b3, D);
+  if (rc) return rc;
+  if (num_edges == 0) return 0;
+  PG_CHECK_ARG(logits, PANGNN_E_BADARG, "pangnn_decoder_mlp_fwd_f32: null logits");
+  const int64_t n_tiles = (num_edges + TE - 1) / TE;
+  int64_t grid = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
+  const int cus = grid_cus();
+  if (grid > cus) grid = cus;
+  DecParams a{p, q, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0,
+                     (hipStream_t)stream, a, logits, n_tiles);
+  PG_CHECK_LAUNCH("pangnn_decoder_mlp_fwd_f32");
+  return 0;
+}
+
+extern "C" size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges) {
+  (void)num_edges;
+  return (size_t)grid_cus() * SLAB * sizeof(float);
+}
+
+extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, const float* q, int64_t num_nodes,
+                                          const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                                          const float* extra, const float* cvec, const float* w2,
+                                          const float* b2, const float* w3, const float* b3, int32_t D,
+                                          const float* g_logits, float* g_h1, float* g_w2, float* g_b2,
+                                          float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                          size_t workspace_bytes, pangnn_stream_t stream) {
+  int rc = check_common("pangnn_decoder_mlp_bwd_f32", p, q, num_nodes, edge_index, ld, num_edges, extra,
+                        cvec, w2, b2, w3, b3, D);
+  if (rc) return rc;
+  PG_CHECK_ARG(g_w2 && g_b2 && g_w3 && g_b3, PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null gradient output");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = (num_edges + TE - 1) / TE;
+  int64_t grid = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+  const int cus = grid_cus();
+  if (grid > cus) grid = cus;
+  if (grid < 1) grid = 1;
+  PG_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * SLAB * sizeof(float), PANGNN_E_WORKSPACE,
+               "pangnn_decoder_mlp_bwd_f32: workspace too small");
+  PG_CHECK_ARG(num_edges == 0 || (g_logits && g_h1), PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null pointer");
+  DecParams a{p, q, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  if (num_edges == 0) {
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)grid * SLAB * sizeof(float), s);
+    PG_CHECK_ARG(e == hipSuccess, (int)e, "pangnn_decoder_mlp_bwd_f32: memset failed");
+  } else {
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3((unsigned)grid), dim3(BWD_WAVES * 64), 0, s, a, g_logits,
+                       g_h1, static_cast<float*>(workspace), n_tiles);
+    PG_CHECK_LAUNCH("pangnn_decoder_mlp_bwd_f32");
+  }
+  hipLaunchKernelGGL(decoder_reduce_kernel, dim3((4096 + 193 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                     static_cast<const float*>(workspace), (int)grid, g_w2, g_b2, g_w3, g_cvec, g_b3);
+  PG_CHECK_LAUNCH("pangnn_decoder_mlp_bwd_f32(reduce)");
+  return 0;
+}

@@ -224,3 +224,57 @@ class _SegmentSum(torch.autograd.Function):
 
 def segment_sum(msg, st: EdgeStructure):
     return _SegmentSum.apply(msg, st)
+
+
+class _DecoderMLP(torch.autograd.Function):
+    """Fused link decoder (node_dim 64): logits[e] = w3 . relu(W2 relu(p[src]+q[dst] (+w_e c)) + b2) + b3.
+    Forward keeps every [E, 64] intermediate on chip; backward recomputes per tile, emits
+    dL/dh1pre [E,64] once and segment-sums it by source (-> g_p) and by target (-> g_q)."""
+
+    @staticmethod
+    def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
+        lib = _lib.load()
+        _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3)
+        p, q, w2, b2, w3, b3 = (_f32c(t) for t in (p, q, w2, b2, w3, b3))
+        ex = None if extra is None else _f32c(extra)
+        cv = None if cvec is None else _f32c(cvec)
+        e, d = st.num_edges, p.shape[1]
+        logits = torch.empty(e, dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(lib.pangnn_decoder_mlp_fwd_f32(p.data_ptr(), q.data_ptr(), p.shape[0],
+                                                      st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv),
+                                                      w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
+                                                      d, _lib.ptr(logits), _lib.stream_ptr()),
+                       "pangnn_decoder_mlp_fwd_f32")
+        ctx.st = st
+        ctx.save_for_backward(p, q, ex, cv, w2, b2, w3, b3)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        st = ctx.st
+        p, q, ex, cv, w2, b2, w3, b3 = ctx.saved_tensors
+        g = _f32c(g)
+        e, d, n = st.num_edges, p.shape[1], p.shape[0]
+        dev = p.device
+        g_h1 = torch.empty(e, d, dtype=torch.float32, device=dev)
+        g_w2 = torch.empty_like(w2)
+        g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
+        g_cv = None if cv is None else torch.empty_like(cv)
+        with torch.cuda.device(dev):
+            ws_bytes = lib.pangnn_decoder_mlp_bwd_workspace_bytes(e)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.pangnn_decoder_mlp_bwd_f32(p.data_ptr(), q.data_ptr(), n, st.edge_index.data_ptr(), e, e,
+                                                      _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
+                                                      w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(g), _lib.ptr(g_h1),
+                                                      g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(),
+                                                      g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(), ws_bytes,
+                                                      _lib.stream_ptr()), "pangnn_decoder_mlp_bwd_f32")
+        gp = segment_sum_rows(st.by_src, g_h1, 0, d, n) if ctx.needs_input_grad[0] else None
+        gq = segment_sum_rows(st.by_dst, g_h1, 0, d, n) if ctx.needs_input_grad[1] else None
+        return gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3
+
+
+def decoder_mlp(p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
+    return _DecoderMLP.apply(p, q, st, extra, cvec, w2, b2, w3, b3)

@@ -113,6 +113,10 @@ class AlternateGCN(nn.Module):
             p = z @ w[:, :d].t()
             q = torch.addmm(lin0.bias, z, w[:, d:2 * d].t())
             cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
+            if d == 64 and self.fused_decoder != "pair_add":
+                # whole per-edge MLP in one HIP kernel (f32 MFMA), no [E, D] tensor in HBM on the way
+                return PF.decoder_mlp(p, q, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
+                                      self.mlp[4].weight.view(-1), self.mlp[4].bias)
             h = PF.edge_pair_add(p, q, st, extra, cvec)
         else:
             h = lin0(PF.edge_gather_concat(z, st, extra))

@@ -197,12 +197,82 @@ def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
         assert close(p.grad, po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), k
 
 
-def test_unfused_decoder_equals_fused_decoder():
-    g, gd, oracle, model = _pair("cfg1_2genomes", (64, 128), dict(skip_connections=True))
-    a = model(gd)
-    model.fused_decoder = False
-    b = model(gd)
-    assert close(a, b, atol=2e-5, rtol=1e-5) and close(b, oracle(g))
+@pytest.mark.parametrize("skip", [False, True])
+def test_three_decoder_forms_agree(skip):
+    """fused MFMA kernel == re-associated pair_add + torch MLP == literal gather-concat-Linear"""
+    g, gd, oracle, model = _pair("cfg1_2genomes", (64, 128), dict(skip_connections=skip))
+    ref = oracle(g)
+    outs = {}
+    for mode in (True, "pair_add", False):
+        model.fused_decoder = mode
+        model.zero_grad()
+        out = model(gd)
+        out.sum().backward()
+        outs[mode] = (out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        assert close(out, ref), mode
+    for mode in ("pair_add", False):
+        assert close(outs[True][0], outs[mode][0], atol=2e-5, rtol=1e-5)
+        for k, gk in outs[True][1].items():
+            scale = float(gk.abs().max()) + 1e-12
+            assert close(gk, outs[mode][1][k], atol=1e-3 * scale + 1e-7, rtol=1e-3), (mode, k)
+
+
+@pytest.mark.parametrize("e", [0, 1, 31, 32, 33, 1000, 70001])
+@pytest.mark.parametrize("skip", [False, True])
+def test_fused_decoder_kernel_vs_torch(e, skip):
+    """pangnn_decoder_mlp_{fwd,bwd}_f32 against the same MLP written with torch ops on the CPU,
+    ragged tile tails included (tile = 32 edges)."""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    torch.manual_seed(e + skip)
+    n, d = 97, 64
+    ei, w = random_graph(n, e, seed=e, isolated=0.0)
+    if e == 0:
+        ei = torch.zeros(2, 0, dtype=torch.long)
+    P, Q = torch.randn(n, d), torch.randn(n, d)
+    W2, b2, w3, b3, cv = torch.randn(d, d) / 8, torch.randn(d), torch.randn(d), torch.randn(1), torch.randn(d)
+    extra = (w / 40) if skip else None
+    leaves = [t.clone().requires_grad_(True) for t in (P, Q, W2, b2, w3, b3, cv)]
+    Pr, Qr, W2r, b2r, w3r, b3r, cvr = leaves
+    h1 = Pr[ei[0]] + Qr[ei[1]]
+    if skip:
+        h1 = h1 + extra.unsqueeze(1) * cvr
+    ref = torch.relu(torch.relu(h1) @ W2r.t() + b2r) @ w3r + b3r
+    gl = [t.clone().to(dev()).requires_grad_(True) for t in (P, Q, W2, b2, w3, b3, cv)]
+    st = EdgeStructure(ei.to(dev()), n)
+    out = PF.decoder_mlp(gl[0], gl[1], st, extra.to(dev()) if skip else None, gl[6] if skip else None,
+                         gl[2], gl[3], gl[4], gl[5])
+    assert out.shape == (e,)
+    assert close(out, ref)
+    go_ = torch.randn(e)
+    ref.backward(go_)
+    out.backward(go_.to(dev()))
+    for i, name in enumerate(["P", "Q", "W2", "b2", "w3", "b3", "cvec"]):
+        if name == "cvec" and not skip:
+            continue
+        rg = leaves[i].grad if leaves[i].grad is not None else torch.zeros_like(leaves[i])
+        scale = float(rg.abs().max()) + 1e-12
+        assert close(gl[i].grad, rg, atol=1e-4 * scale + 1e-6, rtol=1e-3), name
+
+
+def test_fused_decoder_bitwise_reproducible():
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    torch.manual_seed(0)
+    n, e, d = 5000, 400000, 64
+    ei, _ = random_graph(n, e, seed=1)
+    st = EdgeStructure(ei.to(dev()), n)
+    args = [torch.randn(n, d, device=dev()), torch.randn(n, d, device=dev())]
+    par = [torch.randn(d, d, device=dev()) / 8, torch.randn(d, device=dev()), torch.randn(d, device=dev()),
+           torch.randn(1, device=dev())]
+    res = []
+    for _ in range(2):
+        leaves = [t.clone().requires_grad_(True) for t in args + par]
+        out = PF.decoder_mlp(leaves[0], leaves[1], st, None, None, *leaves[2:])
+        out.square().sum().backward()
+        res.append([out.detach()] + [t.grad for t in leaves])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 def test_categorical_nodes_build_defined_semantics():
