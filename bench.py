@@ -106,7 +106,13 @@ def main():
     n, e_sim, e_nb = g.num_nodes, g.edge_index.shape[1], g.neighbour_edge_index.shape[1]
 
     torch.manual_seed(0)
-    if world > 1:
+    force_dist = os.environ.get("PANGNN_FORCE_DIST") == "1"      # exercise the partitioned path at world = 1
+    if force_dist and world == 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    if world > 1 or force_dist:
         from pangnn_amd import dist as pdist
         part = pdist.partition_graph(g, rank, world)
         model = pdist.DistAlternateGCN(dev, dims=[d, h], part=part)
@@ -147,8 +153,8 @@ def main():
     k_bwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["sim.bwd"]]
     if rank == 0:
         t_k = sum(k_fwd) / max(len(k_fwd), 1)
-        rows_local = n if world == 1 else graph.n_local
-        e_local = e_sim if world == 1 else graph.e_sim_local
+        rows_local = getattr(graph, "n_local", n)
+        e_local = getattr(graph, "e_sim_local", e_sim)
         b_alg = spmm_alg_bytes(e_local, rows_local, h)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")

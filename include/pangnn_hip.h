@@ -71,6 +71,16 @@ int pangnn_gcn_norm_f32(const int64_t* rowptr_dst, const int32_t* src_sorted, co
                         float* deg_inv_sqrt, float* norm_sorted, float* norm_orig,
                         pangnn_stream_t stream);
 
+/* The two stages of gcn_norm separately, for a destination-partitioned graph where the source
+ * nodes' deg^-1/2 lives in another table (all-gathered from the other ranks): rows of the CSR are the
+ * n_rows LOCAL targets, src_sorted holds GLOBAL source ids indexing dis_src. */
+int pangnn_gcn_degree_f32(const int64_t* rowptr_dst, const int32_t* perm_dst, const float* edge_weight,
+                          int64_t n_rows, float* deg_inv_sqrt, pangnn_stream_t stream);
+int pangnn_gcn_edge_norm_f32(const int64_t* rowptr_dst, const int32_t* src_sorted, const int32_t* perm_dst,
+                             const float* edge_weight, const float* dis_src, const float* dis_dst,
+                             int64_t n_rows, int64_t num_edges, float* norm_sorted, float* norm_orig,
+                             pangnn_stream_t stream);
+
 /* out[i] = in[perm[i]]  (re-orders per-edge values into another CSR's order) */
 int pangnn_permute_f32(const float* in, const int32_t* perm, float* out, int64_t n,
                        pangnn_stream_t stream);

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(kBlock) void degree_kernel(const int64_t* __restric
 
 __global__ __launch_bounds__(kBlock) void edge_norm_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ src,
-    const int32_t* __restrict__ perm, const float* __restrict__ w, const float* __restrict__ dis,
+    const int32_t* __restrict__ perm, const float* __restrict__ w, const float* __restrict__ dis_src,
+    const float* __restrict__ dis,
     float* __restrict__ norm_sorted, float* __restrict__ norm_orig, int64_t n) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void edge_norm_kernel(
   for (int64_t e = beg + lane; e < end; e += kWave) {
     const int32_t o = perm[e];
     const float we = w ? w[o] : 1.f;
-    const float v = dis[src[e]] * we * dc;  // PyG order: (dis[row] * w) * dis[col]
+    const float v = dis_src[src[e]] * we * dc;  // PyG order: (dis[row] * w) * dis[col]
     norm_sorted[e] = v;
     if (norm_orig) norm_orig[o] = v;
   }
@@ -192,10 +193,42 @@ extern "C" int pangnn_gcn_norm_f32(const int64_t* rowptr_dst, const int32_t* src
   PG_CHECK_LAUNCH("pangnn_gcn_norm_f32(degree)");
   if (num_edges > 0) {
     hipLaunchKernelGGL(edge_norm_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, rowptr_dst,
-                       src_sorted, perm_dst, edge_weight, deg_inv_sqrt, norm_sorted, norm_orig,
+                       src_sorted, perm_dst, edge_weight, deg_inv_sqrt, deg_inv_sqrt, norm_sorted, norm_orig,
                        num_nodes);
     PG_CHECK_LAUNCH("pangnn_gcn_norm_f32(norm)");
   }
+  return 0;
+}
+
+extern "C" int pangnn_gcn_degree_f32(const int64_t* rowptr_dst, const int32_t* perm_dst,
+                                     const float* edge_weight, int64_t n_rows, float* deg_inv_sqrt,
+                                     pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_rows >= 0, PANGNN_E_BADARG, "pangnn_gcn_degree_f32: negative size");
+  if (n_rows == 0) return 0;
+  PG_CHECK_ARG(rowptr_dst && deg_inv_sqrt && (!edge_weight || perm_dst), PANGNN_E_BADARG,
+               "pangnn_gcn_degree_f32: null pointer");
+  const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  PG_CHECK_ARG(blocks < 2147483647LL, PANGNN_E_TOOLARGE, "pangnn_gcn_degree_f32: too many rows");
+  hipLaunchKernelGGL(degree_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, rowptr_dst,
+                     perm_dst, edge_weight, deg_inv_sqrt, n_rows);
+  PG_CHECK_LAUNCH("pangnn_gcn_degree_f32");
+  return 0;
+}
+
+extern "C" int pangnn_gcn_edge_norm_f32(const int64_t* rowptr_dst, const int32_t* src_sorted,
+                                        const int32_t* perm_dst, const float* edge_weight,
+                                        const float* dis_src, const float* dis_dst, int64_t n_rows,
+                                        int64_t num_edges, float* norm_sorted, float* norm_orig,
+                                        pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_rows >= 0 && num_edges >= 0, PANGNN_E_BADARG, "pangnn_gcn_edge_norm_f32: negative size");
+  if (n_rows == 0 || num_edges == 0) return 0;
+  PG_CHECK_ARG(rowptr_dst && src_sorted && perm_dst && dis_src && dis_dst && norm_sorted, PANGNN_E_BADARG,
+               "pangnn_gcn_edge_norm_f32: null pointer");
+  const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  PG_CHECK_ARG(blocks < 2147483647LL, PANGNN_E_TOOLARGE, "pangnn_gcn_edge_norm_f32: too many rows");
+  hipLaunchKernelGGL(edge_norm_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, rowptr_dst,
+                     src_sorted, perm_dst, edge_weight, dis_src, dis_dst, norm_sorted, norm_orig, n_rows);
+  PG_CHECK_LAUNCH("pangnn_gcn_edge_norm_f32");
   return 0;
 }
 

@@ -81,7 +81,7 @@ class _Propagate(torch.autograd.Function):
     def backward(ctx, g):
         st, norm = ctx.st, ctx.norm
         g = _f32c(g)
-        gx = spmm_csr(st.by_src, norm.by_src, g, st.num_nodes,
+        gx = spmm_csr(st.by_src, norm.by_src, g, st.num_src,
                       tag=None if ctx.tag is None else ctx.tag + ".bwd") if ctx.needs_input_grad[0] else None
         gb = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         return gx, gb, None, None, None
@@ -115,6 +115,7 @@ class _EdgeGatherConcat(torch.autograd.Function):
     def backward(ctx, g):
         st, d = ctx.st, ctx.d
         g = _f32c(g)
+        assert st.num_src == st.num_nodes, "edge_gather_concat is defined on a whole (square) graph"
         gz = segment_sum_rows(st.by_src, g, 0, d, st.num_nodes)
         segment_sum_rows(st.by_dst, g, d, d, st.num_nodes, out=gz, accumulate=True)
         return gz, None, None
@@ -133,7 +134,7 @@ class _EdgePairAdd(torch.autograd.Function):
         lib = _lib.load()
         _lib.require_device(p, q, extra, cvec)
         p, q = _f32c(p), _f32c(q)
-        assert p.shape == q.shape and p.stride(0) == q.stride(0)
+        assert p.shape[1] == q.shape[1] and p.stride(0) == q.stride(0)
         e, d = st.num_edges, p.shape[1]
         out = torch.empty(e, d, dtype=torch.float32, device=p.device)
         ex = None if extra is None else _f32c(extra)
@@ -152,7 +153,7 @@ class _EdgePairAdd(torch.autograd.Function):
         st, d = ctx.st, ctx.d
         (ex,) = ctx.saved_tensors
         g = _f32c(g)
-        gp = segment_sum_rows(st.by_src, g, 0, d, st.num_nodes) if ctx.needs_input_grad[0] else None
+        gp = segment_sum_rows(st.by_src, g, 0, d, st.num_src) if ctx.needs_input_grad[0] else None
         gq = segment_sum_rows(st.by_dst, g, 0, d, st.num_nodes) if ctx.needs_input_grad[1] else None
         gc = (ex[: g.shape[0]].unsqueeze(0) @ g).squeeze(0) if (ex is not None and ctx.needs_input_grad[4]) else None
         return gp, gq, None, None, gc
@@ -241,7 +242,7 @@ class _DecoderMLP(torch.autograd.Function):
         e, d = st.num_edges, p.shape[1]
         logits = torch.empty(e, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
-            _lib.check(lib.pangnn_decoder_mlp_fwd_f32(p.data_ptr(), q.data_ptr(), p.shape[0],
+            _lib.check(lib.pangnn_decoder_mlp_fwd_f32(p.data_ptr(), q.data_ptr(), max(p.shape[0], q.shape[0]),
                                                       st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv),
                                                       w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
                                                       d, _lib.ptr(logits), _lib.stream_ptr()),
@@ -256,7 +257,7 @@ class _DecoderMLP(torch.autograd.Function):
         st = ctx.st
         p, q, ex, cv, w2, b2, w3, b3 = ctx.saved_tensors
         g = _f32c(g)
-        e, d, n = st.num_edges, p.shape[1], p.shape[0]
+        e, d, n = st.num_edges, p.shape[1], max(p.shape[0], q.shape[0])
         dev = p.device
         g_h1 = torch.empty(e, d, dtype=torch.float32, device=dev)
         g_w2 = torch.empty_like(w2)
@@ -271,8 +272,8 @@ class _DecoderMLP(torch.autograd.Function):
                                                       g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(),
                                                       g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(), ws_bytes,
                                                       _lib.stream_ptr()), "pangnn_decoder_mlp_bwd_f32")
-        gp = segment_sum_rows(st.by_src, g_h1, 0, d, n) if ctx.needs_input_grad[0] else None
-        gq = segment_sum_rows(st.by_dst, g_h1, 0, d, n) if ctx.needs_input_grad[1] else None
+        gp = segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0]) if ctx.needs_input_grad[0] else None
+        gq = segment_sum_rows(st.by_dst, g_h1, 0, d, q.shape[0]) if ctx.needs_input_grad[1] else None
         return gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3
 
 

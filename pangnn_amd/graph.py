@@ -26,8 +26,11 @@ class CSR:
     perm: torch.Tensor     # int32 [E]  original edge id of each sorted edge
 
 
-def build_csr(edge_index: torch.Tensor, num_nodes: int, group_by: int, validate: bool = True) -> CSR:
-    """pangnn_csr_build: group_by=1 rows are targets (edge_index[1]), 0 rows are sources."""
+def build_csr(edge_index: torch.Tensor, num_nodes: int, group_by: int, validate: bool = True,
+              num_rows: Optional[int] = None) -> CSR:
+    """pangnn_csr_build: group_by=1 rows are targets (edge_index[1]), 0 rows are sources.
+    `num_nodes` bounds both endpoints; `num_rows` (<= num_nodes) trims rowptr for a rectangular
+    (partitioned) graph whose grouped endpoint only takes ids < num_rows."""
     _lib.require_device(edge_index)
     if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError(f"edge_index must be int64 [2,E], got {edge_index.dtype} {tuple(edge_index.shape)}")
@@ -51,15 +54,21 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, group_by: int, validate:
             off = lib.pangnn_csr_build_flag_ptr(ws.data_ptr(), e) - ws.data_ptr()
             if int(ws[off:off + 4].view(torch.int32).item()) != 0:
                 raise ValueError(f"edge_index contains node ids outside [0, {num_nodes})")
+    if num_rows is not None and num_rows < num_nodes:
+        rowptr = rowptr[: num_rows + 1]
     return CSR(rowptr, other, perm)
 
 
 class EdgeStructure:
     """Both groupings of one edge_index plus memoised GCN normalisations."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, num_src: Optional[int] = None):
+        """`num_nodes` = number of TARGET rows (= all nodes for a whole graph).  `num_src` (default
+        the same) = number of SOURCE rows: a destination-partitioned shard keeps local target ids
+        and global source ids (pangnn_amd/dist.py)."""
         self.edge_index = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
         self.num_nodes = int(num_nodes)
+        self.num_src = int(num_nodes if num_src is None else num_src)
         self.num_edges = int(edge_index.shape[1])
         self._by_dst: Optional[CSR] = None
         self._by_src: Optional[CSR] = None
@@ -68,22 +77,28 @@ class EdgeStructure:
     @property
     def by_dst(self) -> CSR:
         if self._by_dst is None:
-            self._by_dst = build_csr(self.edge_index, self.num_nodes, 1)
+            nmax = max(self.num_nodes, self.num_src)
+            self._by_dst = build_csr(self.edge_index, nmax, 1, num_rows=self.num_nodes)
+            if self.num_nodes < nmax and self.num_edges and int(self.edge_index[1].max()) >= self.num_nodes:
+                raise ValueError("target id outside the local row range")
         return self._by_dst
 
     @property
     def by_src(self) -> CSR:
         if self._by_src is None:
-            self._by_src = build_csr(self.edge_index, self.num_nodes, 0, validate=False)
+            nmax = max(self.num_nodes, self.num_src)
+            self._by_src = build_csr(self.edge_index, nmax, 0, validate=False, num_rows=self.num_src)
         return self._by_src
 
-    def gcn_norm(self, edge_weight: Optional[torch.Tensor]) -> "GcnNorm":
-        """norm for this edge_weight tensor (None = unit weights); cached on tensor identity."""
+    def gcn_norm(self, edge_weight: Optional[torch.Tensor], gather_dis=None) -> "GcnNorm":
+        """norm for this edge_weight tensor (None = unit weights); cached on tensor identity.
+        `gather_dis(dis_local [n_dst]) -> dis_src [n_src]` supplies the source nodes' deg^-1/2 for a
+        partitioned shard (an all-gather); omitted for a whole graph."""
         key = None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version,
                                                 tuple(edge_weight.shape))
         hit = self._norm.get(key)
         if hit is None:
-            hit = GcnNorm(self, edge_weight)
+            hit = GcnNorm(self, edge_weight, gather_dis)
             if len(self._norm) >= 4:
                 self._norm.pop(next(iter(self._norm)))
             self._norm[key] = hit
@@ -93,7 +108,7 @@ class EdgeStructure:
 class GcnNorm:
     """k1-k3 of SURVEY.md §2.2: deg^-1/2[src] * w * deg^-1/2[dst], in both CSR orders."""
 
-    def __init__(self, st: EdgeStructure, edge_weight: Optional[torch.Tensor]):
+    def __init__(self, st: EdgeStructure, edge_weight: Optional[torch.Tensor], gather_dis=None):
         lib = _lib.load()
         dev = st.edge_index.device
         e, n = st.num_edges, st.num_nodes
@@ -107,10 +122,24 @@ class GcnNorm:
         self.by_dst = torch.empty(e, dtype=torch.float32, device=dev)    # CSR(dst) order
         self.orig = torch.empty(e, dtype=torch.float32, device=dev)      # caller's edge order
         with torch.cuda.device(dev):
-            _lib.check(lib.pangnn_gcn_norm_f32(d.rowptr.data_ptr(), _lib.ptr(d.other), _lib.ptr(d.perm),
-                                               _lib.ptr(edge_weight), n, e, self.deg_inv_sqrt.data_ptr(),
-                                               _lib.ptr(self.by_dst), _lib.ptr(self.orig),
-                                               _lib.stream_ptr()), "pangnn_gcn_norm_f32")
+            if gather_dis is None:
+                if st.num_src != st.num_nodes:
+                    raise ValueError("a rectangular structure needs gather_dis= for gcn_norm")
+                _lib.check(lib.pangnn_gcn_norm_f32(d.rowptr.data_ptr(), _lib.ptr(d.other), _lib.ptr(d.perm),
+                                                   _lib.ptr(edge_weight), n, e, self.deg_inv_sqrt.data_ptr(),
+                                                   _lib.ptr(self.by_dst), _lib.ptr(self.orig),
+                                                   _lib.stream_ptr()), "pangnn_gcn_norm_f32")
+            else:
+                _lib.check(lib.pangnn_gcn_degree_f32(d.rowptr.data_ptr(), _lib.ptr(d.perm), _lib.ptr(edge_weight),
+                                                     n, self.deg_inv_sqrt.data_ptr(), _lib.stream_ptr()),
+                           "pangnn_gcn_degree_f32")
+                dis_src = gather_dis(self.deg_inv_sqrt).contiguous()
+                assert dis_src.shape[0] >= st.num_src and dis_src.dtype == torch.float32
+                _lib.check(lib.pangnn_gcn_edge_norm_f32(d.rowptr.data_ptr(), _lib.ptr(d.other), _lib.ptr(d.perm),
+                                                        _lib.ptr(edge_weight), dis_src.data_ptr(),
+                                                        self.deg_inv_sqrt.data_ptr(), n, e, _lib.ptr(self.by_dst),
+                                                        _lib.ptr(self.orig), _lib.stream_ptr()),
+                           "pangnn_gcn_edge_norm_f32")
         self._st = st
         self._by_src: Optional[torch.Tensor] = None
 

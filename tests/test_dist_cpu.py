@@ -1,0 +1,125 @@
+"""world_size-2 (and 3) gloo runs of the partition + exchange logic of pangnn_amd/dist.py on CPU.
+
+The HIP kernels cannot run here, so the per-rank arithmetic is a torch restatement plugged in through
+the `ops=` hook (TEST-ONLY; the product only ever builds `HipOps`).  What is under test is everything
+around the kernels: ownership of edges, local/global id remapping, padding, the all-gather /
+reduce-scatter autograd pair, the global-mean loss scaling and the flat gradient all-reduce — checked
+against the single-process oracle on the reference-built golden graph."""
+import os
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, whole_graph_from_golden
+from oracle import gcn_oracle as go
+
+
+class TorchOps:
+    """torch restatement of the four kernel entry points DistAlternateGCN uses"""
+
+    def structure(self, edge_index, n_dst, n_src):
+        return SimpleNamespace(ei=edge_index, n_dst=n_dst, n_src=n_src)
+
+    def norm(self, st, w, gather_dis):
+        src, dst = st.ei
+        w = torch.ones(src.shape[0]) if w is None else w
+        deg = torch.zeros(st.n_dst).scatter_add_(0, dst, w)
+        dis = deg.pow(-0.5)
+        dis[dis == float("inf")] = 0
+        dis_src = gather_dis(dis)
+        assert dis_src.shape[0] == st.n_src
+        return dis_src[src] * w * dis[dst]
+
+    def propagate(self, x_full, bias, st, norm, tag=None):
+        src, dst = st.ei
+        out = torch.zeros(st.n_dst, x_full.shape[1]).index_add(0, dst, norm.view(-1, 1) * x_full[src])
+        return out + bias
+
+    def decoder(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3):
+        src, dst = st.ei
+        h = p_full[src] + q_local[dst]
+        if extra is not None:
+            h = h + extra.view(-1, 1) * cvec
+        return torch.relu(torch.relu(h) @ w2.t() + b2) @ w3 + b3
+
+
+def _worker(rank, world, init_file, flags, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from pangnn_amd import dist as pdist
+    g = whole_graph_from_golden("sim_200x4")
+    if flags.get("union_edge_weights"):
+        g.edge_attr = g.union_edge_attr
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 128), flags=go.default_flags(**flags))
+    with torch.no_grad():
+        for k, p in oracle.named_parameters():
+            if k.endswith("bias"):
+                p.uniform_(-0.5, 0.5)
+    model = pdist.DistAlternateGCN(None, dims=[64, 128], ops=TorchOps(), **flags)
+    model.load_state_dict(oracle.state_dict())
+    shard = pdist.partition_graph(g, rank, world)
+    assert shard.n_pad == shard.n_local * world and shard.e_sim_total == g.edge_index.shape[1]
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt_o = torch.optim.Adam(oracle.parameters(), lr=1e-3)
+
+    # forward parity in the whole graph's edge order
+    out = model(shard)
+    full = pdist.gather_logits(out.detach(), shard)
+    ref = oracle(g)
+    assert torch.allclose(full, ref.detach(), atol=1e-4, rtol=1e-4), (full - ref).abs().max()
+
+    # one train step: loss and every parameter after Adam must match the single-process oracle
+    lo, _ = go.train_step(oracle, opt_o, g, g.y, pw)
+    ll, _ = pdist.train_step(model, opt, shard, shard.y, pw)
+    tot = ll.clone()
+    dist.all_reduce(tot)
+    assert abs(float(tot) - float(lo)) < 1e-5
+    for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        assert torch.allclose(p, q, atol=2e-6, rtol=1e-4), (k, (p - q).abs().max())
+    # owned-edge bookkeeping: every similarity edge has exactly one owner
+    cnt = shard.owned_mask.to(torch.int32).clone()
+    dist.all_reduce(cnt)
+    assert int(cnt.min()) == 1 and int(cnt.max()) == 1
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True), dict(base_model=True),
+                                   dict(union_edge_weights=True)],
+                         ids=["default", "skip", "base", "union"])
+def test_partitioned_model_matches_single_process_oracle(world, flags):
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "rdzv")
+        mp.spawn(_worker, args=(world, init_file, flags, d), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(world))
+
+
+def _ag_worker(rank, world, init_file, out_dir):
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from pangnn_amd.dist import AllGatherRows
+    x = torch.full((3, 2), float(rank + 1), requires_grad=True)
+    full = AllGatherRows.apply(x, None)
+    assert full.shape == (3 * world, 2) and float(full[3 * (world - 1), 0]) == world
+    coeff = torch.arange(3 * world, dtype=torch.float32).view(-1, 1) * (rank + 1)
+    (full * coeff).sum().backward()
+    # d/dx_local = sum over ranks r' of coeff_{r'}[my rows] = my rows' index * sum(r'+1)
+    expect = torch.arange(3 * rank, 3 * rank + 3, dtype=torch.float32).view(-1, 1) * sum(range(1, world + 1))
+    assert torch.equal(x.grad, expect.expand(3, 2))
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_all_gather_rows_backward_is_reduce_scatter():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_ag_worker, args=(2, os.path.join(d, "rdzv"), d), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(d, "ok0")) and os.path.exists(os.path.join(d, "ok1"))
