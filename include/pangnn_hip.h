@@ -139,7 +139,8 @@ int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t
  *   h1[e]   = relu(p[src_e] + q[dst_e] (+ extra[e] * cvec))     p = z W1[:, :D]^T, q = z W1[:, D:2D]^T + b1
  *   h2[e]   = relu(w2 h1[e] + b2)                               w2 [D,D] row-major [out][in]  (mlp.2)
  *   logits[e] = w3 . h2[e] + b3                                 w3 [D], b3 [1]                (mlp.4)
- * Edges are taken in the caller's order, e in [0, num_edges) of edge_index[2][ld].  No [E, D]
+ * p and q are row-major with leading dimensions ldp / ldq (so both may be column windows of one
+ * [N, 2D] product).  Edges are taken in the caller's order, e in [0, num_edges) of edge_index[2][ld].  No [E, D]
  * intermediate touches HBM in the forward pass.  fp32 MFMA (exact fp32 products and sums).
  *
  * Backward: given g_logits[E], recomputes the forward and returns
@@ -148,19 +149,35 @@ int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t
  *   g_w3[D], g_b3[1], g_cvec[D] (nullable).  Reproducible: per-workgroup partial slabs in
  *   `workspace`, summed in a fixed order; no float atomics.
  * ---------------------------------------------------------------------------------------- */
-int pangnn_decoder_mlp_fwd_f32(const float* p, const float* q, int64_t num_nodes,
+int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                const float* extra, const float* cvec, const float* w2, const float* b2,
                                const float* w3, const float* b3, int32_t D, float* logits,
                                pangnn_stream_t stream);
 size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges);
-int pangnn_decoder_mlp_bwd_f32(const float* p, const float* q, int64_t num_nodes,
+int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                const float* extra, const float* cvec, const float* w2, const float* b2,
                                const float* w3, const float* b3, int32_t D, const float* g_logits,
                                float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
                                float* g_cvec, void* workspace, size_t workspace_bytes,
                                pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Node-level dense layers with a short inner dimension, K (in) and M (out) in {64, 128}
+ * (GCNConv.lin = k4 of SURVEY.md §2.2, the decoder's node-level P|Q product, and their backward):
+ *   fwd  : y[n, 0:M]  = x[n, 0:K] . w[M,K]^T (+ bias[M])          (dL/dx = g . w is fwd with w^T)
+ *   wgrad: gw[M,K]    = g[N,M]^T . x[N,K],  gb[M] = sum_n g[n,:]  (gb nullable)
+ * fp32 MFMA, HBM-bound streaming kernels; wgrad is slab-reduced (reproducible).
+ * pangnn_linear_supported(K, M, wgrad) tells the caller whether a shape is covered.
+ * ---------------------------------------------------------------------------------------- */
+int    pangnn_linear_supported(int32_t K, int32_t M, int wgrad);
+int    pangnn_linear_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                             int64_t ldy, int64_t n, int32_t K, int32_t M, pangnn_stream_t stream);
+size_t pangnn_linear_wgrad_workspace_bytes(int32_t K, int32_t M);
+int    pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
+                               int32_t K, int32_t M, float* gw, float* gb, void* workspace,
+                               size_t workspace_bytes, pangnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -33,10 +33,15 @@ SIGNATURES = {
     "pangnn_segment_sum_rows_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32, C.c_int, _p]),
     "pangnn_segment_max_rows_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _p]),
     "pangnn_segment_max_bwd_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
-    "pangnn_decoder_mlp_fwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32, _p, _p]),
+    "pangnn_linear_supported": (C.c_int, [_i32, _i32, C.c_int]),
+    "pangnn_linear_fwd_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
+    "pangnn_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32]),
+    "pangnn_linear_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
+    "pangnn_decoder_mlp_fwd_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
+                                             _p, _p]),
     "pangnn_decoder_mlp_bwd_workspace_bytes": (_sz, [_i64]),
-    "pangnn_decoder_mlp_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32, _p,
-                                             _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pangnn_decoder_mlp_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
+                                             _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

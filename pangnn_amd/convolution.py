@@ -92,7 +92,7 @@ class _GlorotLinear(nn.Module):
         nn.init.uniform_(self.weight, -a, a)
 
     def forward(self, x):
-        return torch.nn.functional.linear(x, self.weight)
+        return PF.linear(x, self.weight)
 
 
 class GCNConv(MessagePassing):

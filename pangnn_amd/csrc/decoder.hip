@@ -48,7 +48,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ constexpr int jr(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 struct DecParams {
-  const float* p; const float* q;
+  const float* p; const float* q; uint32_t ldp4; uint32_t ldq4;   // row strides in float4 units
   const int64_t* ei; int64_t ld; int64_t E;
   const float* extra; const float* cvec;
   const float* w2; const float* b2; const float* w3; const float* b3;
@@ -94,8 +94,8 @@ __device__ __forceinline__ void gather_tile(const DecParams& a, int64_t ebase, i
       const int s = __shfl(id, row);
       const int d = __shfl(id, 32 + row);
       wv[i] = __shfl(w_e, row);
-      pv[i] = P4[(uint32_t)s * 16u + c4];
-      qv[i] = Q4[(uint32_t)d * 16u + c4];
+      pv[i] = P4[(uint32_t)s * a.ldp4 + c4];
+      qv[i] = Q4[(uint32_t)d * a.ldq4 + c4];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -359,14 +359,17 @@ static int grid_cus() {
   return cus;
 }
 
-static int check_common(const char* who, const float* p, const float* q, int64_t num_nodes,
+static int check_common(const char* who, const float* p, const float* q, int64_t ldp, int64_t ldq,
+                        int64_t num_nodes,
                         const int64_t* ei, int64_t ld, int64_t E, const float* extra,
                         const float* cvec, const float* w2, const float* b2, const float* w3,
                         const float* b3, int32_t D) {
   PG_CHECK_ARG(D == DD, PANGNN_E_BADARG, "%s: fused decoder is built for node_dim 64, got %d", who, (int)D);
   PG_CHECK_ARG(E >= 0 && ld >= E && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
-  PG_CHECK_ARG(num_nodes < (int64_t)1 << 24, PANGNN_E_TOOLARGE,
-               "%s: node table must stay under 4 GiB (N < 2^24 at 256 B per row)", who);
+  PG_CHECK_ARG(ldp >= DD && ldq >= DD && ldp % 4 == 0 && ldq % 4 == 0, PANGNN_E_BADARG,
+               "%s: ldp / ldq must be multiples of 4 and >= 64", who);
+  PG_CHECK_ARG((double)num_nodes * (double)(ldp > ldq ? ldp : ldq) * 4.0 < 4294967296.0, PANGNN_E_TOOLARGE,
+               "%s: node tables must stay under 4 GiB (32-bit gather offsets)", who);
   if (E == 0) return 0;
   PG_CHECK_ARG(p && q && ei && w2 && b2 && w3 && b3 && (!extra || cvec), PANGNN_E_BADARG,
                "%s: null pointer", who);
@@ -379,12 +382,12 @@ static int check_common(const char* who, const float* p, const float* q, int64_t
 
 using namespace pangnn;
 
-extern "C" int pangnn_decoder_mlp_fwd_f32(const float* p, const float* q, int64_t num_nodes,
-                                          const int64_t* edge_index, int64_t ld, int64_t num_edges,
+extern "C" int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq,
+                                          int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                           const float* extra, const float* cvec, const float* w2,
                                           const float* b2, const float* w3, const float* b3,
                                           int32_t D, float* logits, pangnn_stream_t stream) {
-  int rc = check_common("pangnn_decoder_mlp_fwd_f32", p, q, num_nodes, edge_index, ld, num_edges, extra,
+  int rc = check_common("pangnn_decoder_mlp_fwd_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
                         cvec, w2, b2, w3, b3, D);
   if (rc) return rc;
   if (num_edges == 0) return 0;
@@ -393,7 +396,7 @@ extern "C" int pangnn_decoder_mlp_fwd_f32(const float* p, const float* q, int64_
   int64_t grid = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
   const int cus = grid_cus();
   if (grid > cus) grid = cus;
-  DecParams a{p, q, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
   hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0,
                      (hipStream_t)stream, a, logits, n_tiles);
   PG_CHECK_LAUNCH("pangnn_decoder_mlp_fwd_f32");
@@ -405,14 +408,14 @@ extern "C" size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges) {
   return (size_t)grid_cus() * SLAB * sizeof(float);
 }
 
-extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, const float* q, int64_t num_nodes,
-                                          const int64_t* edge_index, int64_t ld, int64_t num_edges,
+extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq,
+                                          int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                           const float* extra, const float* cvec, const float* w2,
                                           const float* b2, const float* w3, const float* b3, int32_t D,
                                           const float* g_logits, float* g_h1, float* g_w2, float* g_b2,
                                           float* g_w3, float* g_b3, float* g_cvec, void* workspace,
                                           size_t workspace_bytes, pangnn_stream_t stream) {
-  int rc = check_common("pangnn_decoder_mlp_bwd_f32", p, q, num_nodes, edge_index, ld, num_edges, extra,
+  int rc = check_common("pangnn_decoder_mlp_bwd_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
                         cvec, w2, b2, w3, b3, D);
   if (rc) return rc;
   PG_CHECK_ARG(g_w2 && g_b2 && g_w3 && g_b3, PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null gradient output");
@@ -425,7 +428,7 @@ extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, const float* q, int64_
   PG_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * SLAB * sizeof(float), PANGNN_E_WORKSPACE,
                "pangnn_decoder_mlp_bwd_f32: workspace too small");
   PG_CHECK_ARG(num_edges == 0 || (g_logits && g_h1), PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null pointer");
-  DecParams a{p, q, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
   if (num_edges == 0) {
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)grid * SLAB * sizeof(float), s);
     PG_CHECK_ARG(e == hipSuccess, (int)e, "pangnn_decoder_mlp_bwd_f32: memset failed");

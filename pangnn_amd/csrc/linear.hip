@@ -1,0 +1,268 @@
+// Node-level dense layers with a short inner dimension (K, M in {64, 128}) over N ~ 1e6 rows:
+//   y[N,M]  = x[N,K] w[M,K]^T (+ bias)                      GCNConv.lin, decoder P|Q, dL/dx = g w
+//   gw[M,K] = g[N,M]^T x[N,K],  gb[M] = sum_n g[n,:]        weight / bias gradients
+// These are HBM-bound (0.25 flop/B at K = 64): a library GEMM tuned for square problems leaves an
+// order of magnitude on the table (hipBLASLt: 1.7 - 3.3 ms for 0.77 GB at N = 1e6).  Here one wave
+// owns 32 consecutive rows: row-contiguous 16-byte loads into a padded LDS tile, w resident in LDS,
+// f32 MFMA 32x32x2 (exact fp32 FMA chains), output rows stored as 128-byte segments.
+// The weight gradient keeps its [M,K] accumulator in registers across all of a wave's tiles and is
+// reduced over waves and workgroups in a fixed order (slabs), so it is bitwise reproducible.
+#include "common.h"
+
+namespace pangnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ constexpr int jrow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// rows [base, base+32) of a [n, C] matrix (leading dim ld) -> LDS tile [32][C+4]; rows >= n are zero
+template <int C>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_t ld, int64_t n,
+                                           int64_t base, int lane, float* tile) {
+  constexpr int LPR = C / 4;            // lanes per row
+  constexpr int RPI = 64 / LPR;         // rows per wave-instruction
+  constexpr int RS = C + 4;
+  const int c4 = lane % LPR, r0 = lane / LPR;
+#pragma unroll
+  for (int i = 0; i < 32 / RPI; ++i) {
+    const int row = i * RPI + r0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (base + row < n) v = *reinterpret_cast<const float4*>(src + (base + row) * ld + 4 * c4);
+    *reinterpret_cast<float4*>(tile + row * RS + 4 * c4) = v;
+  }
+}
+
+template <int K, int M>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ y, int64_t ldy, int64_t n,
+                                                         int64_t n_tiles) {
+  constexpr int KS = K + 4;
+  __shared__ __attribute__((aligned(16))) float lds[M * KS + 4 * 32 * KS];
+  float* Wl = lds;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* Xt = lds + M * KS + wave * (32 * KS);
+  for (int i = threadIdx.x; i < M * (K / 4); i += 256) {
+    const int m = i / (K / 4), k4 = i % (K / 4);
+    *reinterpret_cast<float4*>(Wl + m * KS + 4 * k4) = reinterpret_cast<const float4*>(w)[i];
+  }
+  __syncthreads();
+  const int r = lane & 31, hh = lane >> 5;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t base = tile * 32;
+    stage_rows<K>(x, ldx, n, base, lane, Xt);
+    wave_sync_lds();
+    f32x16 acc[M / 32];
+#pragma unroll
+    for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < K / 8; ++i) {
+      const int k4 = (K / 8) * hh + i;
+      const float4 a = *reinterpret_cast<const float4*>(Xt + r * KS + 4 * k4);     // A: x[row r][k]
+#pragma unroll
+      for (int b = 0; b < M / 32; ++b) {
+        const float4 bw = *reinterpret_cast<const float4*>(Wl + (r + 32 * b) * KS + 4 * k4);  // B: w[m][k]
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw.x, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw.y, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw.z, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw.w, acc[b], 0, 0, 0);
+      }
+    }
+    // C[row = jrow(i,hh)][m = r + 32b]
+#pragma unroll
+    for (int b = 0; b < M / 32; ++b) {
+      const float bv = bias ? bias[r + 32 * b] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = base + jrow(i, hh);
+        if (row < n) y[row * ldy + r + 32 * b] = acc[b][i] + bv;
+      }
+    }
+    wave_sync_lds();
+  }
+}
+
+template <int K, int M>
+struct WgradGeo {
+  static constexpr int SLAB = M * K + M;     // gw | gb
+};
+
+template <int K, int M>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ g, int64_t ldg,
+                                                           const float* __restrict__ x, int64_t ldx,
+                                                           int64_t n, int64_t n_tiles,
+                                                           float* __restrict__ slabs) {
+  constexpr int KS = K + 4, MS = M + 4;
+  constexpr int PER_WAVE = 32 * KS + 32 * MS;
+  constexpr int SLAB = WgradGeo<K, M>::SLAB;
+  constexpr int LDS_F = (4 * PER_WAVE > SLAB) ? 4 * PER_WAVE : SLAB;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_F];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* Xt = lds + wave * PER_WAVE;
+  float* Gt = Xt + 32 * KS;
+  const int r = lane & 31, hh = lane >> 5;
+  f32x16 acc[M / 32][K / 32];
+  float gbp[M / 32];
+#pragma unroll
+  for (int a = 0; a < M / 32; ++a) {
+    gbp[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < K / 32; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t base = tile * 32;
+    stage_rows<K>(x, ldx, n, base, lane, Xt);
+    stage_rows<M>(g, ldg, n, base, lane, Gt);
+    wave_sync_lds();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = 2 * s + hh;
+      float av[M / 32], bv[K / 32];
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a) { av[a] = Gt[row * MS + r + 32 * a]; gbp[a] += av[a]; }
+#pragma unroll
+      for (int b = 0; b < K / 32; ++b) bv[b] = Xt[row * KS + r + 32 * b];
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a)
+#pragma unroll
+        for (int b = 0; b < K / 32; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    wave_sync_lds();
+  }
+#pragma unroll
+  for (int a = 0; a < M / 32; ++a) gbp[a] += __shfl_xor(gbp[a], 32);
+  __syncthreads();
+  float* red = lds;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+      const bool first = (wv == 0);
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a) {
+#pragma unroll
+        for (int b = 0; b < K / 32; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int idx = (32 * a + jrow(i, hh)) * K + r + 32 * b;      // gw[m][k]
+            red[idx] = (first ? 0.f : red[idx]) + acc[a][b][i];
+          }
+        if (hh == 0) red[M * K + r + 32 * a] = (first ? 0.f : red[M * K + r + 32 * a]) + gbp[a];
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * SLAB;
+  for (int i = threadIdx.x; i < SLAB; i += 256) slab[i] = red[i];
+}
+
+__global__ __launch_bounds__(kBlock) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                             int slab_len, int split,
+                                                             float* __restrict__ out0,
+                                                             float* __restrict__ out1) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= slab_len) return;
+  float s = 0.f;
+  for (int wv = 0; wv < n_slabs; ++wv) s += slabs[(int64_t)wv * slab_len + i];
+  if (i < split) out0[i] = s;
+  else if (out1) out1[i - split] = s;
+}
+
+static int num_cus() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+    return v;
+  return 256;
+}
+
+template <int K, int M>
+static int launch_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                      int64_t n, hipStream_t s) {
+  const int64_t n_tiles = (n + 31) / 32;
+  int64_t grid = (n_tiles + 3) / 4;
+  const int64_t cap = (int64_t)num_cus() * 2;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((linear_fwd_kernel<K, M>), dim3((unsigned)grid), dim3(256), 0, s, x, ldx, w, bias, y, ldy,
+                     n, n_tiles);
+  PG_CHECK_LAUNCH("pangnn_linear_fwd_f32");
+  return 0;
+}
+
+template <int K, int M>
+static int launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n, float* gw,
+                        float* gb, float* ws, size_t ws_bytes, hipStream_t s) {
+  constexpr int SLAB = WgradGeo<K, M>::SLAB;
+  const int64_t n_tiles = (n + 31) / 32;
+  int64_t grid = (n_tiles + 3) / 4;
+  const int64_t cap = (int64_t)num_cus();
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  PG_CHECK_ARG(ws && ws_bytes >= (size_t)grid * SLAB * sizeof(float), PANGNN_E_WORKSPACE,
+               "pangnn_linear_wgrad_f32: workspace too small");
+  hipLaunchKernelGGL((linear_wgrad_kernel<K, M>), dim3((unsigned)grid), dim3(256), 0, s, g, ldg, x, ldx, n,
+                     n_tiles, ws);
+  PG_CHECK_LAUNCH("pangnn_linear_wgrad_f32");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ws, (int)grid,
+                     SLAB, M * K, gw, gb);
+  PG_CHECK_LAUNCH("pangnn_linear_wgrad_f32(reduce)");
+  return 0;
+}
+
+}  // namespace pangnn
+
+using namespace pangnn;
+
+extern "C" int pangnn_linear_supported(int32_t K, int32_t M, int wgrad) {
+  const bool km = (K == 64 || K == 128) && (M == 64 || M == 128);
+  if (!km) return 0;
+  if (wgrad && K == 128 && M == 128) return 0;   // 256 accumulator registers: left to the library
+  return 1;
+}
+
+extern "C" int pangnn_linear_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                                     int64_t ldy, int64_t n, int32_t K, int32_t M, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_fwd_f32: negative size");
+  PG_CHECK_ARG(pangnn_linear_supported(K, M, 0), PANGNN_E_BADARG,
+               "pangnn_linear_fwd_f32: K and M must be 64 or 128 (got %d, %d)", (int)K, (int)M);
+  if (n == 0) return 0;
+  PG_CHECK_ARG(x && w && y && ldx >= K && ldy >= M, PANGNN_E_BADARG, "pangnn_linear_fwd_f32: bad pointer / ld");
+  PG_CHECK_ARG(aligned16(x) && aligned16(w) && ldx % 4 == 0, PANGNN_E_ALIGN,
+               "pangnn_linear_fwd_f32: x / w must be 16-byte aligned, ldx a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, ldx, w, bias, y, ldy, n, s);
+  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, ldx, w, bias, y, ldy, n, s);
+  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, ldx, w, bias, y, ldy, n, s);
+  return launch_fwd<128, 128>(x, ldx, w, bias, y, ldy, n, s);
+}
+
+extern "C" size_t pangnn_linear_wgrad_workspace_bytes(int32_t K, int32_t M) {
+  return (size_t)num_cus() * ((size_t)M * K + M) * sizeof(float);
+}
+
+extern "C" int pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
+                                       int32_t K, int32_t M, float* gw, float* gb, void* workspace,
+                                       size_t workspace_bytes, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_wgrad_f32: negative size");
+  PG_CHECK_ARG(pangnn_linear_supported(K, M, 1), PANGNN_E_BADARG,
+               "pangnn_linear_wgrad_f32: unsupported (K, M) = (%d, %d)", (int)K, (int)M);
+  PG_CHECK_ARG(gw && (n == 0 || (g && x)) && ldg >= M && ldx >= K, PANGNN_E_BADARG,
+               "pangnn_linear_wgrad_f32: bad pointer / ld");
+  PG_CHECK_ARG(aligned16(g) && aligned16(x) && ldg % 4 == 0 && ldx % 4 == 0, PANGNN_E_ALIGN,
+               "pangnn_linear_wgrad_f32: g / x must be 16-byte aligned, ld multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = static_cast<float*>(workspace);
+  if (K == 64 && M == 64) return launch_wgrad<64, 64>(g, ldg, x, ldx, n, gw, gb, ws, workspace_bytes, s);
+  if (K == 64 && M == 128) return launch_wgrad<64, 128>(g, ldg, x, ldx, n, gw, gb, ws, workspace_bytes, s);
+  return launch_wgrad<128, 64>(g, ldg, x, ldx, n, gw, gb, ws, workspace_bytes, s);
+}

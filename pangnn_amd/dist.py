@@ -162,8 +162,11 @@ class DistAlternateGCN(AlternateGCN):
             cache[key] = self.ops.norm(self._st(shard, name), weight, gather)
         return cache[key]
 
+    def _linear(self, x, w, b):
+        return PF.linear(x, w, b) if x.is_cuda else F.linear(x, w, b)      # CPU only in the gloo tests
+
     def _conv(self, conv, h_local, shard, name, weight, wkey, tag):
-        xw = conv.lin(h_local)
+        xw = self._linear(h_local, conv.lin.weight, None)
         xw_full = AllGatherRows.apply(xw, self.group)
         return self.ops.propagate(xw_full, conv.bias, self._st(shard, name), self._norm(shard, name, weight, wkey), tag)
 
@@ -178,7 +181,7 @@ class DistAlternateGCN(AlternateGCN):
             h = act(self._conv(self.conv_out, h, shard, "union", None, "1", "union"))
         elif fl.base_model:
             h = act(self._conv(self.conv_in, h, shard, "sim", shard.edge_attr, "w", "sim"))
-            h = act(self.linear_out(h))
+            h = act(self._linear(h, self.linear_out.weight, self.linear_out.bias))
         else:
             h = act(self._conv(self.conv_in, h, shard, "sim", shard.edge_attr, "w", "sim"))
             h = act(self._conv(self.conv_out, h, shard, "nb", None, "1", "nb"))
@@ -189,8 +192,8 @@ class DistAlternateGCN(AlternateGCN):
         d = z.shape[1]
         lin0 = self.mlp[0]
         w = lin0.weight
-        p = z @ w[:, :d].t()
-        q = torch.addmm(lin0.bias, z, w[:, d:2 * d].t())
+        p = self._linear(z, w[:, :d].contiguous(), None)
+        q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias)
         p_full = AllGatherRows.apply(p, self.group)
         extra = shard.edge_attr if fl.skip_connections else None
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None

@@ -227,27 +227,46 @@ def segment_sum(msg, st: EdgeStructure):
     return _SegmentSum.apply(msg, st)
 
 
+def _rows_f32(t: torch.Tensor) -> torch.Tensor:
+    """fp32 with unit column stride and a 16-byte friendly row stride; column windows of a wider
+    row-major matrix pass through without a copy"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] \
+            and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
 class _DecoderMLP(torch.autograd.Function):
     """Fused link decoder (node_dim 64): logits[e] = w3 . relu(W2 relu(p[src]+q[dst] (+w_e c)) + b2) + b3.
     Forward keeps every [E, 64] intermediate on chip; backward recomputes per tile, emits
-    dL/dh1pre [E,64] once and segment-sums it by source (-> g_p) and by target (-> g_q)."""
+    dL/dh1pre [E,64] once and segment-sums it by source (-> g_p) and by target (-> g_q).
+    `pq_joint=True`: p and q are the two column halves of one [N, 128] matrix and the gradient comes
+    back as one [N, 128] matrix (no padding / adding of two partial gradients)."""
 
     @staticmethod
-    def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
+    def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3, pq_joint=False):
         lib = _lib.load()
         _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3)
-        p, q, w2, b2, w3, b3 = (_f32c(t) for t in (p, q, w2, b2, w3, b3))
+        if pq_joint:
+            pq = _rows_f32(p)
+            d = pq.shape[1] // 2
+            p, q = pq[:, :d], pq[:, d:]
+        else:
+            p, q = _rows_f32(p), _rows_f32(q)
+        w2, b2, w3, b3 = (_f32c(t) for t in (w2, b2, w3, b3))
         ex = None if extra is None else _f32c(extra)
         cv = None if cvec is None else _f32c(cvec)
         e, d = st.num_edges, p.shape[1]
         logits = torch.empty(e, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
-            _lib.check(lib.pangnn_decoder_mlp_fwd_f32(p.data_ptr(), q.data_ptr(), max(p.shape[0], q.shape[0]),
-                                                      st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv),
-                                                      w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
-                                                      d, _lib.ptr(logits), _lib.stream_ptr()),
-                       "pangnn_decoder_mlp_fwd_f32")
-        ctx.st = st
+            _lib.check(lib.pangnn_decoder_mlp_fwd_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
+                                                      max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
+                                                      _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
+                                                      w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(logits),
+                                                      _lib.stream_ptr()), "pangnn_decoder_mlp_fwd_f32")
+        ctx.st, ctx.joint = st, pq_joint
         ctx.save_for_backward(p, q, ex, cv, w2, b2, w3, b3)
         return logits
 
@@ -257,7 +276,7 @@ class _DecoderMLP(torch.autograd.Function):
         st = ctx.st
         p, q, ex, cv, w2, b2, w3, b3 = ctx.saved_tensors
         g = _f32c(g)
-        e, d, n = st.num_edges, p.shape[1], max(p.shape[0], q.shape[0])
+        e, d = st.num_edges, p.shape[1]
         dev = p.device
         g_h1 = torch.empty(e, d, dtype=torch.float32, device=dev)
         g_w2 = torch.empty_like(w2)
@@ -266,16 +285,84 @@ class _DecoderMLP(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws_bytes = lib.pangnn_decoder_mlp_bwd_workspace_bytes(e)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.check(lib.pangnn_decoder_mlp_bwd_f32(p.data_ptr(), q.data_ptr(), n, st.edge_index.data_ptr(), e, e,
+            _lib.check(lib.pangnn_decoder_mlp_bwd_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
+                                                      max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
                                                       _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
                                                       w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(g), _lib.ptr(g_h1),
                                                       g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(),
                                                       g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(), ws_bytes,
                                                       _lib.stream_ptr()), "pangnn_decoder_mlp_bwd_f32")
+        if ctx.joint:
+            g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
+            segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0], out=g_pq[:, :d])
+            segment_sum_rows(st.by_dst, g_h1, 0, d, p.shape[0], out=g_pq[:, d:])
+            return g_pq, None, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None
         gp = segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0]) if ctx.needs_input_grad[0] else None
         gq = segment_sum_rows(st.by_dst, g_h1, 0, d, q.shape[0]) if ctx.needs_input_grad[1] else None
-        return gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3
+        return gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None
 
 
 def decoder_mlp(p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
-    return _DecoderMLP.apply(p, q, st, extra, cvec, w2, b2, w3, b3)
+    return _DecoderMLP.apply(p, q, st, extra, cvec, w2, b2, w3, b3, False)
+
+
+def decoder_mlp_pq(pq, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
+    """p = pq[:, :D], q = pq[:, D:] (one [N, 2D] node-level product)"""
+    return _DecoderMLP.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, True)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x w^T (+ b) over ~1e6 node rows with K, M in {64, 128}: streaming f32-MFMA kernels
+    (pangnn_linear_fwd_f32 / pangnn_linear_wgrad_f32); dL/dx is the forward kernel with w^T."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        lib = _lib.load()
+        _lib.require_device(x, w, bias)
+        x, w = _rows_f32(x), _f32c(w)
+        b = None if bias is None else _f32c(bias)
+        n, k = x.shape
+        m = w.shape[0]
+        y = torch.empty(n, m, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pangnn_linear_fwd_f32(x.data_ptr(), x.stride(0), w.data_ptr(), _lib.ptr(b), y.data_ptr(),
+                                                 y.stride(0), n, k, m, _lib.stream_ptr()), "pangnn_linear_fwd_f32")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        g = _rows_f32(g)
+        n, k = x.shape
+        m = w.shape[0]
+        dev = x.device
+        gx = gw = gb = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                wt = w.t().contiguous()                       # [K, M]: gx = g . w = linear(g, w^T)
+                gx = torch.empty(n, k, dtype=torch.float32, device=dev)
+                _lib.check(lib.pangnn_linear_fwd_f32(g.data_ptr(), g.stride(0), wt.data_ptr(), None, gx.data_ptr(),
+                                                     gx.stride(0), n, m, k, _lib.stream_ptr()),
+                           "pangnn_linear_fwd_f32(dx)")
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                gw = torch.empty_like(w)
+                gb = torch.empty(m, dtype=torch.float32, device=dev) if ctx.has_bias else None
+                ws_bytes = lib.pangnn_linear_wgrad_workspace_bytes(k, m)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                _lib.check(lib.pangnn_linear_wgrad_f32(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), n, k, m,
+                                                       gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(), ws_bytes,
+                                                       _lib.stream_ptr()), "pangnn_linear_wgrad_f32")
+        return gx, gw, gb
+
+
+def linear(x, w, bias=None):
+    """torch.nn.functional.linear for node-level layers; shapes the HIP kernels do not cover
+    (K or M outside {64,128}, or the 128x128 weight gradient) go to hipBLASLt via torch."""
+    lib = _lib.load()
+    k, m = w.shape[1], w.shape[0]
+    if x.dim() == 2 and x.is_cuda and lib.pangnn_linear_supported(k, m, 1):
+        return _Linear.apply(x, w, bias)
+    return torch.nn.functional.linear(x, w, bias)

@@ -95,7 +95,7 @@ class AlternateGCN(nn.Module):
             h = act(self.conv_out(h, ei, graph=graph, name="union"))
         elif fl.base_model:                                                    # gnn.py:143-150
             h = act(self.conv_in(h, graph.edge_index, graph.edge_attr, graph=graph, name="sim"))
-            h = act(self.linear_out(h))
+            h = act(PF.linear(h, self.linear_out.weight, self.linear_out.bias))
         else:                                                                  # gnn.py:153-166
             h = act(self.conv_in(h, graph.edge_index, graph.edge_attr, graph=graph, name="sim"))
             h = act(self.conv_out(h, graph.neighbour_edge_index, graph=graph, name="nb"))
@@ -110,14 +110,16 @@ class AlternateGCN(nn.Module):
         lin0 = self.mlp[0]
         if self.fused_decoder and d % 4 == 0:
             w = lin0.weight
-            p = z @ w[:, :d].t()
-            q = torch.addmm(lin0.bias, z, w[:, d:2 * d].t())
             cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
+            # one node-level product gives P | Q = z [W_a ; W_b]^T + [0 ; b1]
+            w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
+            b_pq = torch.cat([torch.zeros_like(lin0.bias), lin0.bias])
+            pq = PF.linear(z, w_pq, b_pq)
             if d == 64 and self.fused_decoder != "pair_add":
                 # whole per-edge MLP in one HIP kernel (f32 MFMA), no [E, D] tensor in HBM on the way
-                return PF.decoder_mlp(p, q, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
-                                      self.mlp[4].weight.view(-1), self.mlp[4].bias)
-            h = PF.edge_pair_add(p, q, st, extra, cvec)
+                return PF.decoder_mlp_pq(pq, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
+                                         self.mlp[4].weight.view(-1), self.mlp[4].bias)
+            h = PF.edge_pair_add(pq[:, :d].contiguous(), pq[:, d:].contiguous(), st, extra, cvec)
         else:
             h = lin0(PF.edge_gather_concat(z, st, extra))
         for layer in list(self.mlp)[1:]:

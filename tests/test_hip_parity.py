@@ -423,3 +423,32 @@ def test_hip_ops_on_destination_shards_reassemble_the_whole_graph(world):
     for s, st in zip(shards, sts):
         full[s.owned_mask] = ops.decoder(P, Q[s.lo:s.lo + s.n_local].contiguous(), st, None, None, W2, b2, w3, b3)
     assert torch.equal(full, whole_logits)          # same per-edge arithmetic, only ids remapped
+
+
+# ---------------------------------------------------------------- node-level linear kernels
+@pytest.mark.parametrize("k,m", [(64, 64), (64, 128), (128, 64), (128, 128)])
+@pytest.mark.parametrize("n", [0, 1, 33, 1000, 40007])
+def test_linear_kernels_match_torch(k, m, n):
+    from pangnn_amd import functional as PF
+    torch.manual_seed(n + k + m)
+    x, w, b = torch.randn(n, k), torch.randn(m, k) / 8, torch.randn(m)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    xg, wg, bg = (t.clone().to(dev()).requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.linear(xr.double(), wr.double(), br.double())
+    out = PF.linear(xg, wg, bg)
+    assert out.shape == (n, m)
+    assert close(out, ref, atol=1e-5, rtol=1e-5)
+    g = torch.randn(n, m)
+    ref.backward(g.double())
+    out.backward(g.to(dev()))
+    for a, r in ((xg, xr), (wg, wr), (bg, br)):
+        scale = float(r.grad.abs().max()) + 1e-12 if n else 1.0
+        assert close(a.grad, r.grad, atol=2e-5 * scale + 1e-7, rtol=1e-4)
+
+
+def test_linear_strided_input_window():
+    from pangnn_amd import functional as PF
+    big = torch.randn(500, 192, device=dev())
+    w = torch.randn(128, 64, device=dev())
+    out = PF.linear(big[:, 64:128], w)                  # column window: ld = 192, no copy
+    assert close(out, big[:, 64:128].cpu().double() @ w.cpu().double().t(), atol=1e-4, rtol=1e-5)
