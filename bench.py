@@ -155,7 +155,8 @@ def main():
         t_k = sum(k_fwd) / max(len(k_fwd), 1)
         rows_local = getattr(graph, "n_local", n)
         e_local = getattr(graph, "e_sim_local", e_sim)
-        b_alg = spmm_alg_bytes(e_local, rows_local, h)
+        f_spmm = min(d, h)        # GCNConv propagates on the narrower side of its dense layer
+        b_alg = spmm_alg_bytes(e_local, rows_local, f_spmm)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
@@ -174,7 +175,7 @@ def main():
                        "partition": "none" if world == 1 else f"destination-partitioned x{world}, all-gather/reduce-scatter",
                        "graph_build_s": round(t_gen, 3), "warmup_incl_structure_s": round(t_struct, 3),
                        "final_loss": float(loss.item())},
-            "roofline": {"bound": "hbm", "kernel": f"spmm_row_kernel<{h}> (conv_in propagate fwd)",
+            "roofline": {"bound": "hbm", "kernel": f"spmm_row_kernel<{f_spmm}> (conv_in propagate fwd)",
                          "achieved": b_alg / t_k / 1e9 if t_k > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": (b_alg / t_k) / HBM_PEAK if t_k > 0 else None, "traffic": traffic,
                          "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_k * 1e3,

@@ -128,7 +128,13 @@ class GCNConv(MessagePassing):
             # raise on the length mismatch, so do we
             raise ValueError(f"edge_weight has {edge_weight.shape[0]} entries for {st.num_edges} edges")
         norm = st.gcn_norm(edge_weight)
-        xw = self.lin(x.float())
+        x = x.float()
+        if self.in_channels < self.out_channels:
+            # A_hat (x W^T) == (A_hat x) W^T: propagate on the narrower side (half the gather bytes for
+            # 64 -> 128), then the dense layer with the bias fused
+            agg = PF.propagate(x, None, st, norm, tag=name or None)
+            return PF.linear(agg, self.lin.weight, self.bias)
+        xw = self.lin(x)
         return PF.propagate(xw, self.bias, st, norm, tag=name or None)
 
     def message(self, x_j, edge_weight):            # kept for API parity; forward() is fused

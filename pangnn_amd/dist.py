@@ -166,13 +166,19 @@ class DistAlternateGCN(AlternateGCN):
         return PF.linear(x, w, b) if x.is_cuda else F.linear(x, w, b)      # CPU only in the gloo tests
 
     def _conv(self, conv, h_local, shard, name, weight, wkey, tag):
+        st, norm = self._st(shard, name), self._norm(shard, name, weight, wkey)
+        if conv.in_channels < conv.out_channels:
+            # propagate (and exchange) on the narrower side: half the all-gather bytes for 64 -> 128
+            h_full = AllGatherRows.apply(h_local, self.group)
+            agg = self.ops.propagate(h_full, None, st, norm, tag)
+            return self._linear(agg, conv.lin.weight, conv.bias)
         xw = self._linear(h_local, conv.lin.weight, None)
         xw_full = AllGatherRows.apply(xw, self.group)
-        return self.ops.propagate(xw_full, conv.bias, self._st(shard, name), self._norm(shard, name, weight, wkey), tag)
+        return self.ops.propagate(xw_full, conv.bias, st, norm, tag)
 
     def encode(self, shard):
         fl, act = self.flags, self.activation_fct
-        h = self.embedding(shard.x)
+        h = shard.x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
         if fl.union_edge_weights:
             w = shard.union_edge_attr
             h = act(self._conv(self.conv_in, h, shard, "union", w, "w", "union"))

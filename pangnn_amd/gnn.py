@@ -84,8 +84,11 @@ class AlternateGCN(nn.Module):
         x = graph.x
         _lib.require_device(x)
         if self.categorical_nodes:
-            x = x.long().view(-1)
-        h = self.embedding(x)
+            h = self.embedding(x.long().view(-1))
+        else:
+            # Linear(1, D) on a [N,1] column is an outer product; as a GEMM its weight gradient is a
+            # 64 x 1 x N problem that the BLAS library runs at < 0.1 TB/s
+            h = x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
         act = self.activation_fct
         if fl.union_edge_weights:                                              # gnn.py:128-139
             ei = graph.union_edge_index

@@ -38,7 +38,7 @@ class TorchOps:
     def propagate(self, x_full, bias, st, norm, tag=None):
         src, dst = st.ei
         out = torch.zeros(st.n_dst, x_full.shape[1]).index_add(0, dst, norm.view(-1, 1) * x_full[src])
-        return out + bias
+        return out if bias is None else out + bias
 
     def decoder(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3):
         src, dst = st.ei
@@ -76,14 +76,19 @@ def _worker(rank, world, init_file, flags, out_dir):
     ref = oracle(g)
     assert torch.allclose(full, ref.detach(), atol=1e-4, rtol=1e-4), (full - ref).abs().max()
 
-    # one train step: loss and every parameter after Adam must match the single-process oracle
+    # one train step: the loss and every all-reduced gradient must match the single-process oracle
+    # (gradients, not post-Adam parameters: Adam's g/(|g|+eps) amplifies rounding noise on ~0 entries)
     lo, _ = go.train_step(oracle, opt_o, g, g.y, pw)
     ll, _ = pdist.train_step(model, opt, shard, shard.y, pw)
     tot = ll.clone()
     dist.all_reduce(tot)
     assert abs(float(tot) - float(lo)) < 1e-5
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
-        assert torch.allclose(p, q, atol=2e-6, rtol=1e-4), (k, (p - q).abs().max())
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = float(q.grad.abs().max()) + 1e-12
+        assert torch.allclose(p.grad, q.grad, atol=1e-4 * scale + 1e-8, rtol=1e-3), (k, (p.grad - q.grad).abs().max())
     # owned-edge bookkeeping: every similarity edge has exactly one owner
     cnt = shard.owned_mask.to(torch.int32).clone()
     dist.all_reduce(cnt)
