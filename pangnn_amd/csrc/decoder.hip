@@ -136,6 +136,10 @@ __device__ __forceinline__ void gemm1(const float* Wl, const float* Ht, int lane
 
 constexpr int FWD_WAVES = 16;   // 1024 threads, 1 workgroup / CU, 4 waves / SIMD
 constexpr int BWD_WAVES = 8;    // 512 threads,  1 workgroup / CU, 2 waves / SIMD
+#ifndef PANGNN_DECODER_STAGGER
+#define PANGNN_DECODER_STAGGER 1
+#endif
+constexpr bool STAGGER = PANGNN_DECODER_STAGGER != 0;
 
 __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a, float* __restrict__ logits,
                                                                     int64_t n_tiles) {
@@ -148,6 +152,18 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a
   float* Ht = cvl + 64 + wave * (TE * RS);
   stage_weights(a, Wl, b2l, w3l, cvl, FWD_WAVES * 64);
   __syncthreads();
+  // Waves w, w+4, w+8, w+12 share a SIMD and run identical phases (gather | MFMA | epilogue); with
+  // equal priority they share the matrix pipe instruction by instruction and stay in lockstep, so all
+  // of them wait on their gathers at the same time.  Distinct static priorities let one wave finish
+  // its MFMA phase first: the phases stagger and one wave's gather hides under another's MFMAs.
+  if (STAGGER) {
+    switch (wave >> 2) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
+  }
   const float b3 = a.b3[0];
   const int hh = lane >> 5;
   for (int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave; tile < n_tiles;
@@ -193,6 +209,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   float* gl = wl + 32;
   stage_weights(a, Wl, b2l, w3l, cvl, BWD_WAVES * 64);
   __syncthreads();
+  if (STAGGER && (wave >> 2)) __builtin_amdgcn_s_setprio(2);    // see decoder_fwd_kernel
   const int hh = lane >> 5, r = lane & 31;
 
   f32x16 acc3[2][2];   // gW2[j = jr(i,hh)+32bj][k = r+32bk]
