@@ -179,6 +179,18 @@ int    pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int6
                                int32_t K, int32_t M, float* gw, float* gb, void* workspace,
                                size_t workspace_bytes, pangnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * BCEWithLogitsLoss(pos_weight), mean reduction (pangnn.py:98,203), loss and dL/dlogits in one pass:
+ *   loss[0]     = 1/denom * sum_i (1-y_i) x_i + (1 + (pw-1) y_i) softplus(-x_i)
+ *   g_logits[i] = 1/denom * ((1-y_i) - (1 + (pw-1) y_i) sigmoid(-x_i))
+ * pos_weight is a DEVICE scalar (nullable = 1).  denom = number of edges of the whole job (differs from
+ * n on a partitioned shard).  Reproducible two-stage sum.
+ * ---------------------------------------------------------------------------------------- */
+size_t pangnn_bce_logits_workspace_bytes(void);
+int    pangnn_bce_logits_f32(const float* logits, const float* y, const float* pos_weight, int64_t n,
+                             int64_t denom, float* loss, float* g_logits, void* workspace,
+                             size_t workspace_bytes, pangnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

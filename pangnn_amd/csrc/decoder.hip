@@ -134,12 +134,61 @@ __device__ __forceinline__ void gemm1(const float* Wl, const float* Ht, int lane
   }
 }
 
-constexpr int FWD_WAVES = 16;   // 1024 threads, 1 workgroup / CU, 4 waves / SIMD
-constexpr int BWD_WAVES = 8;    // 512 threads,  1 workgroup / CU, 2 waves / SIMD
+constexpr int FWD_WAVES = 8;    // 512 threads, 1 workgroup / CU, 2 waves / SIMD (prefetch registers)
+constexpr int BWD_WAVES = 8;    // 512 threads, 1 workgroup / CU, 2 waves / SIMD
 #ifndef PANGNN_DECODER_STAGGER
 #define PANGNN_DECODER_STAGGER 1
 #endif
 constexpr bool STAGGER = PANGNN_DECODER_STAGGER != 0;
+
+// ---- software-pipelined gather: edge ids two tiles ahead, node rows one tile ahead, so a wave never
+// waits on HBM between two MFMA phases (the rows of tile t+1 land while tile t is in the matrix pipe).
+struct TileIds { int id; float w_e; };
+struct TileRows { float4 pv[8]; float4 qv[8]; float wv[8]; };
+
+__device__ __forceinline__ TileIds load_ids(const DecParams& a, int64_t tile, int64_t n_tiles, int lane) {
+  TileIds t;
+  t.id = 0;
+  t.w_e = 0.f;
+  const int64_t e = tile * TE + (lane & 31);
+  if (tile < n_tiles && e < a.E) {
+    t.id = (int)a.ei[(int64_t)(lane >> 5) * a.ld + e];   // lanes 0-31: source, 32-63: target
+    if (a.extra && lane < 32) t.w_e = a.extra[e];
+  }
+  return t;
+}
+
+__device__ __forceinline__ void issue_rows(const DecParams& a, const TileIds& t, int lane, TileRows& rw) {
+  const int c4 = lane & 15, r4 = lane >> 4;
+  const float4* P4 = reinterpret_cast<const float4*>(a.p);
+  const float4* Q4 = reinterpret_cast<const float4*>(a.q);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 4 * i + r4;
+    const int s = __shfl(t.id, row);
+    const int d = __shfl(t.id, 32 + row);
+    rw.wv[i] = __shfl(t.w_e, row);
+    rw.pv[i] = P4[(uint32_t)s * a.ldp4 + c4];
+    rw.qv[i] = Q4[(uint32_t)d * a.ldq4 + c4];
+  }
+}
+
+__device__ __forceinline__ void commit_rows(const DecParams& a, const TileRows& rw, int lane, const float* cvl,
+                                            float* Ht) {
+  const int c4 = lane & 15, r4 = lane >> 4;
+  float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.extra) cv = reinterpret_cast<const float4*>(cvl)[c4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 4 * i + r4;
+    float4 h;
+    h.x = fmaxf(rw.pv[i].x + rw.qv[i].x + rw.wv[i] * cv.x, 0.f);
+    h.y = fmaxf(rw.pv[i].y + rw.qv[i].y + rw.wv[i] * cv.y, 0.f);
+    h.z = fmaxf(rw.pv[i].z + rw.qv[i].z + rw.wv[i] * cv.z, 0.f);
+    h.w = fmaxf(rw.pv[i].w + rw.qv[i].w + rw.wv[i] * cv.w, 0.f);
+    *reinterpret_cast<float4*>(Ht + swz4(row, c4)) = h;
+  }
+}
 
 __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a, float* __restrict__ logits,
                                                                     int64_t n_tiles) {
@@ -152,25 +201,21 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a
   float* Ht = cvl + 64 + wave * (TE * RS);
   stage_weights(a, Wl, b2l, w3l, cvl, FWD_WAVES * 64);
   __syncthreads();
-  // Waves w, w+4, w+8, w+12 share a SIMD and run identical phases (gather | MFMA | epilogue); with
-  // equal priority they share the matrix pipe instruction by instruction and stay in lockstep, so all
-  // of them wait on their gathers at the same time.  Distinct static priorities let one wave finish
-  // its MFMA phase first: the phases stagger and one wave's gather hides under another's MFMAs.
-  if (STAGGER) {
-    switch (wave >> 2) {
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      case 3: __builtin_amdgcn_s_setprio(3); break;
-      default: break;
-    }
-  }
+  if (STAGGER && (wave >> 2)) __builtin_amdgcn_s_setprio(2);   // the two waves of a SIMD: distinct priority
   const float b3 = a.b3[0];
   const int hh = lane >> 5;
-  for (int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave; tile < n_tiles;
-       tile += (int64_t)gridDim.x * FWD_WAVES) {
+  const int64_t stride = (int64_t)gridDim.x * FWD_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * FWD_WAVES + wave;
+  TileIds cur = load_ids(a, tile, n_tiles, lane);
+  TileIds nxt = load_ids(a, tile + stride, n_tiles, lane);
+  TileRows rw;
+  issue_rows(a, cur, lane, rw);
+  for (; tile < n_tiles; tile += stride) {
     const int64_t ebase = tile * TE;
-    float w_e;
-    gather_tile(a, ebase, lane, Ht, cvl, w_e);
+    commit_rows(a, rw, lane, cvl, Ht);                       // waits for this tile's rows only
+    const TileIds nn = load_ids(a, tile + 2 * stride, n_tiles, lane);
+    issue_rows(a, nxt, lane, rw);                            // next tile's rows fly during the MFMAs
+    nxt = nn;
     wave_lds_sync();
     f32x16 acc[2];
     gemm1(Wl, Ht, lane, acc);
@@ -189,7 +234,7 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a
       }
     part += __shfl_xor(part, 32);
     if (lane < 32 && ebase + lane < a.E) logits[ebase + lane] = part + b3;
-    wave_lds_sync();   // the next gather overwrites Ht
+    wave_lds_sync();   // the next commit overwrites Ht
   }
 }
 

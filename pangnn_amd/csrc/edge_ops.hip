@@ -162,6 +162,46 @@ __global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
   }
 }
 
+// BCEWithLogits(pos_weight), mean over `denom` edges (pangnn.py:98,203), forward AND gradient in one
+// pass:  l = (1-y) x + (1 + (pw-1) y) softplus(-x),   dl/dx = (1-y) - (1 + (pw-1) y) sigmoid(-x).
+// Each block sums a fixed slice in a fixed order; a second single-block pass adds the block partials in
+// index order (reproducible).
+constexpr int kBceBlocks = 1024;
+__global__ __launch_bounds__(kBlock) void bce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ pos_weight, int64_t n,
+                                                     float inv_denom, float* __restrict__ g,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[kBlock / kWave];
+  const float pw = pos_weight ? pos_weight[0] : 1.f;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float xv = x[i], yv = y[i];
+    const float lw = 1.f + (pw - 1.f) * yv;
+    const float ax = fabsf(xv);
+    const float t = expf(-ax);
+    const float sp = log1pf(t) + fmaxf(-xv, 0.f);            // softplus(-x)
+    acc += (1.f - yv) * xv + lw * sp;
+    const float sig_neg = xv >= 0.f ? t / (1.f + t) : 1.f / (1.f + t);   // sigmoid(-x)
+    g[i] = ((1.f - yv) - lw * sig_neg) * inv_denom;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) s += red[w];
+    partial[blockIdx.x] = s * inv_denom;
+  }
+}
+
+__global__ void bce_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    loss[0] = s;
+  }
+}
+
 static inline unsigned grid_for(int64_t total) {
   int64_t b = (total + kBlock - 1) / kBlock;
   const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
@@ -315,5 +355,27 @@ extern "C" int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, co
   hipLaunchKernelGGL(segment_max_bwd_kernel, dim3(grid_for(n_rows * F)), dim3(kBlock), 0,
                      (hipStream_t)stream, g, arg, gm, ldm, ldo, n_rows, (int)F);
   PG_CHECK_LAUNCH("pangnn_segment_max_bwd_f32");
+  return 0;
+}
+
+extern "C" size_t pangnn_bce_logits_workspace_bytes(void) { return kBceBlocks * sizeof(float); }
+
+extern "C" int pangnn_bce_logits_f32(const float* logits, const float* y, const float* pos_weight, int64_t n,
+                                     int64_t denom, float* loss, float* g_logits, void* workspace,
+                                     size_t workspace_bytes, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0 && denom > 0, PANGNN_E_BADARG, "pangnn_bce_logits_f32: bad size");
+  PG_CHECK_ARG(loss && workspace && workspace_bytes >= kBceBlocks * sizeof(float) &&
+                   (n == 0 || (logits && y && g_logits)),
+               PANGNN_E_BADARG, "pangnn_bce_logits_f32: null pointer / workspace");
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = (int)((n + kBlock - 1) / kBlock);
+  if (blocks > kBceBlocks) blocks = kBceBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bce_kernel, dim3(blocks), dim3(kBlock), 0, s, logits, y, pos_weight, n,
+                     1.0f / (float)denom, g_logits, static_cast<float*>(workspace));
+  PG_CHECK_LAUNCH("pangnn_bce_logits_f32");
+  hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, s, static_cast<const float*>(workspace), blocks,
+                     loss);
+  PG_CHECK_LAUNCH("pangnn_bce_logits_f32(finish)");
   return 0;
 }

@@ -228,7 +228,11 @@ def train_step(model: DistAlternateGCN, optimizer, shard, labels, pos_weight):
     by the global edge count and the gradient all-reduce is a plain sum."""
     optimizer.zero_grad(set_to_none=True)
     out = model(shard)
-    loss = F.binary_cross_entropy_with_logits(out, labels, pos_weight=pos_weight, reduction="sum") / shard.e_sim_total
+    if out.is_cuda:
+        loss = PF.bce_with_logits(out, labels, pos_weight, denom=shard.e_sim_total)
+    else:                                               # gloo CPU tests
+        loss = F.binary_cross_entropy_with_logits(out, labels, pos_weight=pos_weight,
+                                                  reduction="sum") / shard.e_sim_total
     loss.backward()
     model.sync_gradients()
     optimizer.step()

@@ -366,3 +366,35 @@ def linear(x, w, bias=None):
     if x.dim() == 2 and x.is_cuda and lib.pangnn_linear_supported(k, m, 1):
         return _Linear.apply(x, w, bias)
     return torch.nn.functional.linear(x, w, bias)
+
+
+class _BCEWithLogits(torch.autograd.Function):
+    """mean BCEWithLogitsLoss(pos_weight) with its gradient produced in the same pass
+    (pangnn_bce_logits_f32); `denom` = edge count of the whole job."""
+
+    @staticmethod
+    def forward(ctx, logits, y, pos_weight, denom):
+        lib = _lib.load()
+        _lib.require_device(logits, y, pos_weight)
+        x, yy = _f32c(logits), _f32c(y)
+        pw = None if pos_weight is None else _f32c(pos_weight).reshape(-1)
+        n = x.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        g = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            ws_bytes = lib.pangnn_bce_logits_workspace_bytes()
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.pangnn_bce_logits_f32(_lib.ptr(x), _lib.ptr(yy), _lib.ptr(pw), n, int(denom),
+                                                 loss.data_ptr(), _lib.ptr(g), ws.data_ptr(), ws_bytes,
+                                                 _lib.stream_ptr()), "pangnn_bce_logits_f32")
+        ctx.save_for_backward(g)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go, None, None, None
+
+
+def bce_with_logits(logits, y, pos_weight=None, denom=None):
+    return _BCEWithLogits.apply(logits, y, pos_weight, logits.shape[0] if denom is None else denom)

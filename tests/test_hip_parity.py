@@ -452,3 +452,26 @@ def test_linear_strided_input_window():
     w = torch.randn(128, 64, device=dev())
     out = PF.linear(big[:, 64:128], w)                  # column window: ld = 192, no copy
     assert close(out, big[:, 64:128].cpu().double() @ w.cpu().double().t(), atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n", [0, 1, 257, 100003])
+@pytest.mark.parametrize("pw", [None, 4.7])
+def test_fused_bce_with_logits(n, pw):
+    from pangnn_amd import functional as PF
+    torch.manual_seed(n)
+    x = torch.randn(n) * 6
+    y = (torch.rand(n) < 0.2).float()
+    pwt = None if pw is None else torch.tensor(pw)
+    xr = x.clone().double().requires_grad_(True)
+    if n:
+        ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, y.double(),
+                                                                   pos_weight=None if pw is None else pwt.double())
+        ref.backward()
+    xg = x.clone().to(dev()).requires_grad_(True)
+    out = PF.bce_with_logits(xg, y.to(dev()), None if pw is None else pwt.to(dev()), denom=max(n, 1))
+    (out * 2.0).backward()
+    if n:
+        assert close(out, ref, atol=1e-6, rtol=1e-5)
+        assert close(xg.grad, 2.0 * xr.grad, atol=1e-9, rtol=1e-4)
+    else:
+        assert float(out) == 0.0
