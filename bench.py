@@ -132,7 +132,7 @@ def main():
     torch.cuda.synchronize()
     t_struct = time.perf_counter() - t_struct
 
-    PF.KERNEL_TIMER = {"sim.fwd": [], "sim.bwd": []}
+    PF.KERNEL_TIMER = {"sim.fwd": [], "sim.bwd": [], "dec.fwd": [], "dec.bwd": []}
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -151,6 +151,8 @@ def main():
 
     k_fwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["sim.fwd"]]
     k_bwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["sim.bwd"]]
+    d_fwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["dec.fwd"]]
+    d_bwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["dec.bwd"]]
     if rank == 0:
         t_k = sum(k_fwd) / max(len(k_fwd), 1)
         rows_local = getattr(graph, "n_local", n)
@@ -181,6 +183,17 @@ def main():
                          "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_k * 1e3,
                          "bwd_avg_launch_ms": (sum(k_bwd) / max(len(k_bwd), 1)) * 1e3},
         }
+        if d_bwd:
+            # the decoder kernels are bound by the f32 matrix pipe, not by HBM: report them against the
+            # dense f32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s).  2*64*64 flop per edge per product;
+            # forward = 1 product, backward = 3 (recompute, dL/dh1, dL/dW2).
+            e_loc = getattr(graph, "e_sim_local", e_sim)
+            tb, tfw = sum(d_bwd) / len(d_bwd), sum(d_fwd) / max(len(d_fwd), 1)
+            line["roofline_decoder"] = {
+                "bound": "mfma", "kernel": "decoder_bwd_kernel (largest single kernel of the step)",
+                "achieved": 3 * 8192 * e_loc / tb / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": 3 * 8192 * e_loc / tb / 157.3e12, "avg_launch_ms": tb * 1e3,
+                "fwd_achieved": 8192 * e_loc / tfw / 1e12 if tfw > 0 else None, "fwd_avg_launch_ms": tfw * 1e3}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, d, h)
         print(json.dumps(line), flush=True)

@@ -22,6 +22,21 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 KERNEL_TIMER = None
 
 
+def _timer_start(tag):
+    if KERNEL_TIMER is None or tag not in KERNEL_TIMER:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _timer_stop(tag, ev0):
+    if ev0 is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        KERNEL_TIMER[tag].append((ev0, ev1))
+
+
 def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int,
              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
              accumulate: bool = False, tag: Optional[str] = None) -> torch.Tensor:
@@ -261,11 +276,13 @@ class _DecoderMLP(torch.autograd.Function):
         e, d = st.num_edges, p.shape[1]
         logits = torch.empty(e, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
+            ev = _timer_start("dec.fwd")
             _lib.check(lib.pangnn_decoder_mlp_fwd_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
                                                       max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
                                                       _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
                                                       w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(logits),
                                                       _lib.stream_ptr()), "pangnn_decoder_mlp_fwd_f32")
+            _timer_stop("dec.fwd", ev)
         ctx.st, ctx.joint = st, pq_joint
         ctx.save_for_backward(p, q, ex, cv, w2, b2, w3, b3)
         return logits
@@ -285,6 +302,7 @@ class _DecoderMLP(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws_bytes = lib.pangnn_decoder_mlp_bwd_workspace_bytes(e)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            ev = _timer_start("dec.bwd")
             _lib.check(lib.pangnn_decoder_mlp_bwd_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
                                                       max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
                                                       _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
@@ -292,6 +310,7 @@ class _DecoderMLP(torch.autograd.Function):
                                                       g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(),
                                                       g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(), ws_bytes,
                                                       _lib.stream_ptr()), "pangnn_decoder_mlp_bwd_f32")
+            _timer_stop("dec.bwd", ev)
         if ctx.joint:
             g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
             segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0], out=g_pq[:, :d])
