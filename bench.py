@@ -79,6 +79,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything native libraries print there (RCCL's version
+    # banner at communicator creation) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,6 +120,14 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1 or force_dist:
         from pangnn_amd import dist as pdist
+        # every rank generated the graph itself from the same seed: verify they agree before slicing it
+        chk = torch.stack([g.edge_index.sum(), g.edge_index[0].max(), torch.tensor(e_sim, device=dev),
+                           (g.edge_attr.double().sum() * 1e3).long()]).long()
+        lo_, hi_ = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo_, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi_, op=torch.distributed.ReduceOp.MAX)
+        if not torch.equal(lo_, hi_):
+            raise RuntimeError("ranks generated different graphs from the same seed")
         part = pdist.partition_graph(g, rank, world)
         model = pdist.DistAlternateGCN(dev, dims=[d, h], part=part)
         graph, labels = part, part.y
@@ -196,8 +210,8 @@ def main():
                 "fwd_achieved": 8192 * e_loc / tfw / 1e12 if tfw > 0 else None, "fwd_avg_launch_ms": tfw * 1e3}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, d, h)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -11,15 +11,20 @@ isolated rows so that every collective is a fixed-size all-gather / reduce-scatt
     rows with GLOBAL source ids, so the propagate kernel reads an all-gathered source table and
     writes only local rows,
   * the supervised edges (= similarity edges) it owns, hence its slice of logits and labels.
-Exchanges per step (fp32, F = feature width of the exchanged tensor):
-  * forward, per GCN layer: all-gather of the local X W^T rows  -> [N_pad, F]
-  * backward, per GCN layer: reduce-scatter(sum) of dL/d(X W^T) [N_pad, F] -> local rows
-  * decoder: all-gather of P = z W1a^T rows (sources may be remote; Q = z W1b^T + b is indexed by
-    the local target only), reduce-scatter of dL/dP in backward
+Exchanges per step (fp32, F = width of the exchanged rows; conv layers exchange on their narrower
+side, so F = 64 everywhere at default dims):
+  * default `exchange="halo"`: per graph a one-time plan lists, for every peer, exactly the owned rows
+    that peer's edges reference (boundary-node embeddings).  Forward per GCN layer / decoder:
+    ONE all-to-all-v of those rows; backward: the reverse all-to-all-v of their gradients, summed into
+    the owner's rows through a fixed CSR (no atomics, reproducible).  For the simulated pan-genome
+    graphs the halo is one genome on each side of a rank's range (negatives only link adjacent genomes,
+    node ids are genome-major) and 1 row per side for the neighbour graph, i.e. ~10 % of an all-gather.
+  * `exchange="allgather"`: all-gather of the local rows -> [N_pad, F], reduce-scatter of the gradient
+    (the right primitive when the halo is dense).
   * parameters: ONE flat all-reduce of all gradients (54 k floats = 216 KB) per step
-  * gcn_norm (once per graph): all-gather of deg^-1/2 [N_pad]
-xGMI is a full mesh of point-to-point links, so fixed-size all-gather / reduce-scatter (each shard
-crosses one link once) are the right primitives; nothing here is a ring of small messages.
+  * gcn_norm (once per graph): the same exchange applied to deg^-1/2.
+xGMI is a full mesh of point-to-point links: an all-to-all-v sends each peer's rows over the direct link
+to that peer, once; nothing here is a ring of small messages.
 
 The arithmetic on each rank is the same HIP kernels as the single-GPU path (`HipOps`).  The
 `ops=` hook exists so the partition / exchange logic can be exercised on CPU with gloo, where the
@@ -77,6 +82,94 @@ class AllGatherRows(torch.autograd.Function):
         return _reduce_scatter_rows(g, ctx.group), None
 
 
+def _all_to_all_v(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group):
+    """rows of `send` (split by destination rank) -> rows of `recv` (split by source rank)"""
+    if dist.get_backend(group) != "gloo":
+        dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group)
+        return
+    # gloo (CPU tests): point-to-point
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    so = [0]
+    ro = [0]
+    for c in send_splits:
+        so.append(so[-1] + c)
+    for c in recv_splits:
+        ro.append(ro[-1] + c)
+    ops = []
+    for r in range(world):
+        if r == rank:
+            recv[ro[r]:ro[r + 1]] = send[so[r]:so[r + 1]]
+            continue
+        if send_splits[r]:
+            ops.append(dist.P2POp(dist.isend, send[so[r]:so[r + 1]].contiguous(), r, group))
+        if recv_splits[r]:
+            ops.append(dist.P2POp(dist.irecv, recv[ro[r]:ro[r + 1]], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+class HaloPlan:
+    """Which owned rows every peer needs from this rank, and the local edge list re-indexed into the
+    compact table [owned rows | received halo rows].  Built once per (graph, partition)."""
+
+    def __init__(self, ei_local: torch.Tensor, lo: int, n_local: int, group=None, make_csr=None):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = ei_local.device
+        src = ei_local[0]
+        hi = lo + n_local
+        remote = (src < lo) | (src >= hi)
+        need = torch.unique(src[remote])                                   # sorted global ids
+        owner = torch.div(need, n_local, rounding_mode="floor")
+        need_counts = torch.bincount(owner, minlength=world)
+        all_counts = _all_gather_rows(need_counts.view(1, world), group)       # [world(asker), world(owner)]
+        mx = max(int(all_counts.max()), 1)
+        padded = torch.full((world, mx), -1, dtype=torch.int64, device=dev)
+        off = 0
+        for r in range(world):
+            c = int(need_counts[r])
+            padded[r, :c] = need[off:off + c]
+            off += c
+        everyone = _all_gather_rows(padded.view(1, world, mx), group)          # [asker, owner, mx]
+        send_idx = [everyone[r, rank, : int(all_counts[r, rank])] - lo for r in range(world)]
+        self.send_splits = [int(all_counts[r, rank]) for r in range(world)]    # rows I send to rank r
+        self.recv_splits = [int(c) for c in need_counts.tolist()]              # rows I receive from rank r
+        self.send_idx = torch.cat(send_idx) if send_idx else torch.zeros(0, dtype=torch.int64, device=dev)
+        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < n_local)
+        self.n_local, self.n_halo = n_local, int(need.numel())
+        self.n_table = n_local + self.n_halo
+        new_src = torch.where(remote, n_local + torch.searchsorted(need, src), src - lo)
+        self.edge_index = torch.stack([new_src, ei_local[1]]).contiguous()
+        self.group = group
+        # fixed-order accumulation of returned halo gradients into the owner's rows
+        self.back_csr = make_csr(self.send_idx, n_local) if (make_csr is not None and self.send_idx.numel()) else None
+
+
+class HaloGather(torch.autograd.Function):
+    """[n_local, F] -> table [n_local + n_halo, F] (own rows, then the referenced rows of the peers)."""
+
+    @staticmethod
+    def forward(ctx, x, plan: HaloPlan, accumulate_back):
+        ctx.plan, ctx.acc = plan, accumulate_back
+        x = x.contiguous()
+        send = x.index_select(0, plan.send_idx)
+        recv = torch.empty((plan.n_halo,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        _all_to_all_v(recv, send, plan.recv_splits, plan.send_splits, plan.group)
+        return torch.cat([x, recv], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        g = g.contiguous()
+        g_halo = g[plan.n_local:].contiguous()
+        back = torch.empty((plan.send_idx.numel(),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        _all_to_all_v(back, g_halo, plan.send_splits, plan.recv_splits, plan.group)
+        g_local = g[: plan.n_local].clone()
+        if back.shape[0]:
+            ctx.acc(g_local, back, plan)
+        return g_local, None, None
+
+
 # --------------------------------------------------------------------------------------
 # partition
 # --------------------------------------------------------------------------------------
@@ -127,6 +220,19 @@ class HipOps:
     def decoder(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3):
         return PF.decoder_mlp(p_full, q_local, st, extra, cvec, w2, b2, w3, b3)
 
+    def make_back_csr(self, send_idx, n_local):
+        """CSR over owned rows of the positions in the returned-gradient buffer (stable => fixed order)"""
+        m = send_idx.numel()
+        ei = torch.stack([torch.arange(m, device=send_idx.device), send_idx]).contiguous()
+        return EdgeStructure(ei, n_local, max(m, 1)).by_dst
+
+    def accumulate_back(self, g_local, back, plan):
+        """g_local[send_idx[k]] += back[k], summed per row in buffer order (segment sum, no atomics)"""
+        if back.dim() == 1:
+            g_local.index_add_(0, plan.send_idx, back)        # only deg^-1/2 (no grad path): never hit in training
+            return
+        PF.segment_sum_rows(plan.back_csr, back, 0, back.shape[1], plan.n_local, out=g_local, accumulate=True)
+
     def pair_rows(self, z_full, z_local, st):
         """(z[src], z[dst]) per owned edge for the cosine / dot decoders"""
         raise NotImplementedError("cosine / dot decoders are single-GPU only")
@@ -135,10 +241,13 @@ class HipOps:
 class DistAlternateGCN(AlternateGCN):
     """AlternateGCN (same parameters / state_dict) evaluated on a destination-partitioned shard."""
 
-    def __init__(self, device=None, dims=(64, 128), part=None, group=None, ops=None, **kw):
+    def __init__(self, device=None, dims=(64, 128), part=None, group=None, ops=None, exchange="halo", **kw):
         super().__init__(device, None, False, dims=dims, **kw)
         self.group = group
         self.ops = ops or HipOps()
+        if exchange not in ("halo", "allgather"):
+            raise ValueError("exchange must be 'halo' or 'allgather'")
+        self.exchange = exchange
         self._structs = {}
         if self.flags.decoder != "mlp":
             raise NotImplementedError("partitioned mode implements the mlp decoder")
@@ -146,19 +255,39 @@ class DistAlternateGCN(AlternateGCN):
             raise NotImplementedError("partitioned HIP decoder is built for node_dim 64")
 
     # structures / norms are per shard tensor and cached on the shard object
-    def _st(self, shard, name):
-        cache = shard.__dict__.setdefault("_dist_structs", {})
+    def _plan(self, shard, name):
+        cache = shard.__dict__.setdefault("_dist_plans", {})
         if name not in cache:
             ei = {"sim": shard.edge_index, "nb": getattr(shard, "neighbour_edge_index", None),
                   "union": getattr(shard, "union_edge_index", None)}[name]
-            cache[name] = self.ops.structure(ei, shard.n_local, shard.n_pad)
+            cache[name] = HaloPlan(ei, shard.lo, shard.n_local, self.group,
+                                   getattr(self.ops, "make_back_csr", None))
         return cache[name]
+
+    def _st(self, shard, name):
+        cache = shard.__dict__.setdefault("_dist_structs", {})
+        key = (name, self.exchange)
+        if key not in cache:
+            if self.exchange == "halo":
+                plan = self._plan(shard, name)
+                cache[key] = self.ops.structure(plan.edge_index, shard.n_local, plan.n_table)
+            else:
+                ei = {"sim": shard.edge_index, "nb": getattr(shard, "neighbour_edge_index", None),
+                      "union": getattr(shard, "union_edge_index", None)}[name]
+                cache[key] = self.ops.structure(ei, shard.n_local, shard.n_pad)
+        return cache[key]
+
+    def _table(self, x_local, shard, name):
+        """rows of every node this rank's `name` edges read: [own | halo] or the all-gathered [N_pad]"""
+        if self.exchange == "halo":
+            return HaloGather.apply(x_local, self._plan(shard, name), self.ops.accumulate_back)
+        return AllGatherRows.apply(x_local, self.group)
 
     def _norm(self, shard, name, weight, wkey):
         cache = shard.__dict__.setdefault("_dist_norms", {})
-        key = (name, wkey)
+        key = (name, wkey, self.exchange)
         if key not in cache:
-            gather = lambda d: _all_gather_rows(d, self.group)       # noqa: E731
+            gather = lambda d: self._table(d.view(-1, 1), shard, name).view(-1).contiguous()   # noqa: E731
             cache[key] = self.ops.norm(self._st(shard, name), weight, gather)
         return cache[key]
 
@@ -169,11 +298,11 @@ class DistAlternateGCN(AlternateGCN):
         st, norm = self._st(shard, name), self._norm(shard, name, weight, wkey)
         if conv.in_channels < conv.out_channels:
             # propagate (and exchange) on the narrower side: half the all-gather bytes for 64 -> 128
-            h_full = AllGatherRows.apply(h_local, self.group)
+            h_full = self._table(h_local, shard, name)
             agg = self.ops.propagate(h_full, None, st, norm, tag)
             return self._linear(agg, conv.lin.weight, conv.bias)
         xw = self._linear(h_local, conv.lin.weight, None)
-        xw_full = AllGatherRows.apply(xw, self.group)
+        xw_full = self._table(xw, shard, name)
         return self.ops.propagate(xw_full, conv.bias, st, norm, tag)
 
     def encode(self, shard):
@@ -200,7 +329,7 @@ class DistAlternateGCN(AlternateGCN):
         w = lin0.weight
         p = self._linear(z, w[:, :d].contiguous(), None)
         q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias)
-        p_full = AllGatherRows.apply(p, self.group)
+        p_full = self._table(p, shard, "sim")
         extra = shard.edge_attr if fl.skip_connections else None
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
         return self.ops.decoder(p_full, q, self._st(shard, "sim"), extra, cvec, self.mlp[2].weight,

@@ -40,6 +40,9 @@ class TorchOps:
         out = torch.zeros(st.n_dst, x_full.shape[1]).index_add(0, dst, norm.view(-1, 1) * x_full[src])
         return out if bias is None else out + bias
 
+    def accumulate_back(self, g_local, back, plan):
+        g_local.index_add_(0, plan.send_idx, back)
+
     def decoder(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3):
         src, dst = st.ei
         h = p_full[src] + q_local[dst]
@@ -48,7 +51,7 @@ class TorchOps:
         return torch.relu(torch.relu(h) @ w2.t() + b2) @ w3 + b3
 
 
-def _worker(rank, world, init_file, flags, out_dir):
+def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
@@ -62,7 +65,7 @@ def _worker(rank, world, init_file, flags, out_dir):
         for k, p in oracle.named_parameters():
             if k.endswith("bias"):
                 p.uniform_(-0.5, 0.5)
-    model = pdist.DistAlternateGCN(None, dims=[64, 128], ops=TorchOps(), **flags)
+    model = pdist.DistAlternateGCN(None, dims=[64, 128], ops=TorchOps(), exchange=exchange, **flags)
     model.load_state_dict(oracle.state_dict())
     shard = pdist.partition_graph(g, rank, world)
     assert shard.n_pad == shard.n_local * world and shard.e_sim_total == g.edge_index.shape[1]
@@ -89,11 +92,20 @@ def _worker(rank, world, init_file, flags, out_dir):
             continue
         scale = float(q.grad.abs().max()) + 1e-12
         assert torch.allclose(p.grad, q.grad, atol=1e-4 * scale + 1e-8, rtol=1e-3), (k, (p.grad - q.grad).abs().max())
+    if exchange == "halo":
+        plan = model._plan(shard, "sim")
+        # the halo is exactly the set of remote sources this rank's edges reference
+        src = shard.edge_index[0]
+        rem = (src < shard.lo) | (src >= shard.lo + shard.n_local)
+        assert plan.n_halo == int(torch.unique(src[rem]).numel())
+        assert plan.n_halo < shard.n_pad - shard.n_local or world == 2
+        assert sum(plan.recv_splits) == plan.n_halo and int(plan.edge_index[0].max()) < plan.n_table
     # owned-edge bookkeeping: every similarity edge has exactly one owner
     cnt = shard.owned_mask.to(torch.int32).clone()
     dist.all_reduce(cnt)
     assert int(cnt.min()) == 1 and int(cnt.max()) == 1
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -104,8 +116,16 @@ def _worker(rank, world, init_file, flags, out_dir):
 def test_partitioned_model_matches_single_process_oracle(world, flags):
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "rdzv")
-        mp.spawn(_worker, args=(world, init_file, flags, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, init_file, flags, d, "halo"), nprocs=world, join=True)
         assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(world))
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(union_edge_weights=True)], ids=["default", "union"])
+def test_partitioned_model_allgather_exchange(flags):
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "rdzv")
+        mp.spawn(_worker, args=(2, init_file, flags, d, "allgather"), nprocs=2, join=True)
+        assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(2))
 
 
 def _ag_worker(rank, world, init_file, out_dir):
@@ -121,6 +141,7 @@ def _ag_worker(rank, world, init_file, out_dir):
     expect = torch.arange(3 * rank, 3 * rank + 3, dtype=torch.float32).view(-1, 1) * sum(range(1, world + 1))
     assert torch.equal(x.grad, expect.expand(3, 2))
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
     dist.destroy_process_group()
 
 

@@ -475,3 +475,24 @@ def test_fused_bce_with_logits(n, pw):
         assert close(xg.grad, 2.0 * xr.grad, atol=1e-9, rtol=1e-4)
     else:
         assert float(out) == 0.0
+
+
+def test_halo_gradient_accumulation_is_a_fixed_order_segment_sum():
+    """HipOps.make_back_csr / accumulate_back: g_local[send_idx[k]] += back[k] without atomics"""
+    from types import SimpleNamespace
+    from pangnn_amd import dist as pdist
+    ops = pdist.HipOps()
+    torch.manual_seed(0)
+    n_local, m, f = 1000, 7000, 64
+    send_idx = torch.randint(0, n_local, (m,))
+    back = torch.randn(m, f)
+    g0 = torch.randn(n_local, f)
+    ref = g0.clone().index_add_(0, send_idx, back)
+    outs = []
+    for _ in range(2):
+        g = g0.clone().to(dev())
+        plan = SimpleNamespace(send_idx=send_idx.to(dev()), n_local=n_local,
+                               back_csr=ops.make_back_csr(send_idx.to(dev()), n_local))
+        ops.accumulate_back(g, back.to(dev()), plan)
+        outs.append(g)
+    assert close(outs[0], ref, atol=1e-5, rtol=1e-5) and torch.equal(outs[0], outs[1])
