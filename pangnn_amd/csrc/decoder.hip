@@ -24,6 +24,11 @@ namespace pangnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef PANGNN_ABLATE_MFMA   // diagnostic builds only (tools/ablate_decoder.sh): one VALU op per MFMA
+__device__ __forceinline__ f32x16 fake_mfma(float a, float b, f32x16 c) { c[0] = fmaf(a, b, c[0]); return c; }
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) fake_mfma(a, b, c)
+#endif
+
 constexpr int DD = 64;        // decoder width (node_dim)
 constexpr int TE = 32;        // edges per wave tile
 constexpr int GS = 33;        // row stride of the G tile (floats): conflict-free column reads
@@ -318,18 +323,23 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
         acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[b][i], w0, acc2[0], 0, 0, 0);
         acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[b][i], w1, acc2[1], 0, 0, 0);
       }
-    // mask by h1 > 0, write dL/dh1pre, accumulate gcvec
+    // mask by h1 > 0, write dL/dh1pre, accumulate gcvec.  Full tiles (all but the last) store through
+    // one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
+    {
+      float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
+      const bool full = ebase + TE <= a.E;
 #pragma unroll
-    for (int bp = 0; bp < 2; ++bp)
+      for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int e = jr(i, hh);
-        const int k = r + 32 * bp;
-        const float hval = Ht[swz(e, k)];
-        const float v = hval > 0.f ? acc2[bp][i] : 0.f;
-        if (ebase + e < a.E) g_h1[(ebase + e) * DD + k] = v;
-        gcv[bp] = fmaf(wl[e], v, gcv[bp]);
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int e = jr(i, hh);
+          const int k = r + 32 * bp;
+          const float hval = Ht[swz(e, k)];
+          const float v = hval > 0.f ? acc2[bp][i] : 0.f;
+          if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
+          if (a.extra) gcv[bp] = fmaf(wl[e], v, gcv[bp]);
+        }
+    }
 
     // gW2[j][k] += sum_e G[j][e] h1[e][k]  : both operands from LDS, reduction over the tile's edges
 #pragma unroll
