@@ -21,21 +21,35 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// rows [base, base+32) of a [n, C] matrix (leading dim ld) -> LDS tile [32][C+4]; rows >= n are zero
+// rows [base, base+32) of a [n, C] matrix (leading dim ld): issued into registers one tile ahead
+// (`load_rows`), written to the LDS tile [32][C+4] when the previous tile's MFMAs are done
+// (`store_rows`); rows >= n are zero.
 template <int C>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_t ld, int64_t n,
-                                           int64_t base, int lane, float* tile) {
+struct RowRegs { float4 v[32 / (64 / (C / 4))]; };
+
+template <int C>
+__device__ __forceinline__ void load_rows(const float* __restrict__ src, int64_t ld, int64_t n, int64_t base,
+                                          int lane, RowRegs<C>& rg) {
   constexpr int LPR = C / 4;            // lanes per row
   constexpr int RPI = 64 / LPR;         // rows per wave-instruction
-  constexpr int RS = C + 4;
   const int c4 = lane % LPR, r0 = lane / LPR;
 #pragma unroll
   for (int i = 0; i < 32 / RPI; ++i) {
     const int row = i * RPI + r0;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (base + row < n) v = *reinterpret_cast<const float4*>(src + (base + row) * ld + 4 * c4);
-    *reinterpret_cast<float4*>(tile + row * RS + 4 * c4) = v;
+    rg.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (base + row < n) rg.v[i] = *reinterpret_cast<const float4*>(src + (base + row) * ld + 4 * c4);
   }
+}
+
+template <int C>
+__device__ __forceinline__ void store_rows(const RowRegs<C>& rg, int lane, float* tile) {
+  constexpr int LPR = C / 4;
+  constexpr int RPI = 64 / LPR;
+  constexpr int RS = C + 4;
+  const int c4 = lane % LPR, r0 = lane / LPR;
+#pragma unroll
+  for (int i = 0; i < 32 / RPI; ++i)
+    *reinterpret_cast<float4*>(tile + (i * RPI + r0) * RS + 4 * c4) = rg.v[i];
 }
 
 template <int K, int M>
@@ -55,9 +69,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   }
   __syncthreads();
   const int r = lane & 31, hh = lane >> 5;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  RowRegs<K> rg;
+  load_rows<K>(x, ldx, n, tile * 32, lane, rg);
+  for (; tile < n_tiles; tile += stride) {
     const int64_t base = tile * 32;
-    stage_rows<K>(x, ldx, n, base, lane, Xt);
+    store_rows<K>(rg, lane, Xt);
+    load_rows<K>(x, ldx, n, (tile + stride) * 32, lane, rg);     // next tile flies during the MFMAs
     wave_sync_lds();
     f32x16 acc[M / 32];
 #pragma unroll
@@ -120,10 +139,17 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
   }
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t base = tile * 32;
-    stage_rows<K>(x, ldx, n, base, lane, Xt);
-    stage_rows<M>(g, ldg, n, base, lane, Gt);
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  RowRegs<K> rx;
+  RowRegs<M> rgm;
+  load_rows<K>(x, ldx, n, tile * 32, lane, rx);
+  load_rows<M>(g, ldg, n, tile * 32, lane, rgm);
+  for (; tile < n_tiles; tile += stride) {
+    store_rows<K>(rx, lane, Xt);
+    store_rows<M>(rgm, lane, Gt);
+    load_rows<K>(x, ldx, n, (tile + stride) * 32, lane, rx);
+    load_rows<M>(g, ldg, n, (tile + stride) * 32, lane, rgm);
     wave_sync_lds();
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
