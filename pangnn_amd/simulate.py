@@ -157,3 +157,16 @@ def simulate_graph(n: int, genomes: int, frac_pos: float, num_fragments: float =
     g.class_balance = ((g.y == 0).sum() / pos.clamp_min(1)).to(torch.float32)      # dataset.py:346
     g.genome_of = raw.genome_of
     return g
+
+
+def simulate_subgraph_dataset(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
+                              neighbours: int = 1, seed: int = 0, device="cpu", temperature: float = 0.8):
+    """the reference's `--train` regime on a simulated pan-genome (dataset.py:137-147): one sub-graph per
+    ortholog group, stored flat (pangnn_amd/subgraphs.py) so that 32-graph mini-batches are slices"""
+    from . import subgraphs
+    raw = simulate_raw(n, genomes, frac_pos, num_fragments, n_shuffle, seed=seed, device=device)
+    s, d, sc = construct.remove_trivial_cases(raw.src, raw.dst, raw.score, raw.genome_of)
+    s, d, w = construct.normalize_sim_scores(s, d, sc, raw.genome_of, t=temperature)
+    nodes = torch.arange(raw.num_nodes, device=raw.src.device)
+    return subgraphs.build_subgraphs(raw.num_nodes, s, d, w, raw.group_of, nodes, neighbours=neighbours,
+                                     labels_group_of=raw.group_of)

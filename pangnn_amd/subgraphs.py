@@ -1,0 +1,208 @@
+"""Per-ortholog-group sub-graphs — the reference's actual training regime — built for all groups at
+once as sort / unique / searchsorted tensor programs (runs on the device the relation lives on).
+
+Restates /root/reference/src/dataset.py:222-322 with src/helper.py:327-433 and
+src/preprocessing.py:73-156,264-325:
+
+  for every ortholog group (>= 2 genes):
+    1. BFS over the normalised similarity relation, `neighbours` hops from the group's genes
+       (get_connected_nodes)                                                       -> "core" nodes
+    2. positional neighbours v +- k (k <= neighbours, inside [0, N), ignoring genome ends) of every
+       core node are added as extra nodes; neighbour edges (core v, v +- k) in both directions,
+       de-duplicated (get_neighbour_graph + remove_duplicate_edges_tuple)
+    3. similarity edges = every normalised edge whose two endpoints are in the sub-graph
+       (build_edge_index over the sub dict); weights and labels as for the whole graph
+    4. the group is dropped if it has no similarity rows, or (real data on a genome subset) fewer
+       similarity edges than group members (dataset.py:248,252)
+
+The reference numbers a sub-graph's nodes in CPython string-set iteration order (helper.py:344), which
+no other implementation can reproduce; here local ids are: core nodes by ascending gene position, then
+the extra neighbour nodes by ascending position.  Parity with the reference-built fixtures is therefore
+checked on GLOBAL ids: same node set, same similarity edge set with the same weights and labels, same
+neighbour edge set (tests/test_construct.py).
+
+The result is one flat "dataset" whose index tensors already carry dataset-wide node numbering, so a
+mini-batch of consecutive sub-graphs (PyG `Batch.from_data_list`, pangnn.py:152-153) is a pair of
+slices and one subtraction — no per-step collation on the host.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+
+
+def _unique_sorted(keys: torch.Tensor) -> torch.Tensor:
+    return torch.unique(keys)          # sorted ascending, duplicates dropped
+
+
+def _isin_sorted(sorted_keys: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    if sorted_keys.numel() == 0:
+        return torch.zeros_like(q, dtype=torch.bool)
+    pos = torch.searchsorted(sorted_keys, q).clamp_(max=sorted_keys.numel() - 1)
+    return sorted_keys[pos] == q
+
+
+def _expand_by_src(rowptr: torch.Tensor, dst_sorted: torch.Tensor, gid: torch.Tensor, node: torch.Tensor):
+    """all (gid, t, edge position) for edges node -> t of the src-grouped relation"""
+    beg, end = rowptr[node], rowptr[node + 1]
+    cnt = end - beg
+    total = int(cnt.sum())
+    rep = torch.repeat_interleave(torch.arange(node.numel(), device=node.device), cnt)
+    off = torch.arange(total, device=node.device) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+    epos = beg[rep] + off
+    return gid[rep], dst_sorted[epos], epos, rep
+
+
+def build_subgraphs(num_nodes: int, src, dst, weight, group_id: torch.Tensor, group_member: torch.Tensor,
+                    neighbours: int = 1, labels_group_of: Optional[torch.Tensor] = None, pair_src=None,
+                    pair_dst=None, require_edges_ge_members: bool = False):
+    """(src, dst, weight): normalised similarity relation (self hits already removed).
+    (group_id, group_member): the ortholog groups as parallel arrays (group ids 0..G-1, gene node ids).
+    Labels as in construct.whole_graph: `labels_group_of[node]` or explicit (pair_src, pair_dst)."""
+    dev = src.device
+    n = int(num_nodes)
+    ok = (src != dst) & (src >= 0) & (dst >= 0) & (src < n) & (dst < n)
+    src, dst, weight = src[ok], dst[ok], weight[ok]
+    order = torch.argsort(src * n + dst, stable=True)                 # canonical (src, dst) order
+    src, dst, weight = src[order], dst[order], weight[order]
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+    has_rows = (rowptr[1:] - rowptr[:-1]) > 0
+
+    ngroups = int(group_id.max().item()) + 1 if group_id.numel() else 0
+    gsize = torch.bincount(group_id, minlength=ngroups)
+    keep_m = gsize[group_id] > 1                                       # dataset.py:230
+    gid, mem = group_id[keep_m], group_member[keep_m]
+
+    # 1. BFS (get_connected_nodes): keys = gid * n + node
+    core = _unique_sorted(gid * n + mem)
+    frontier = core
+    for _ in range(int(neighbours)):
+        fg, fn = torch.div(frontier, n, rounding_mode="floor"), frontier % n
+        eg, et, _, _ = _expand_by_src(rowptr, dst, fg, fn)
+        cand = _unique_sorted(eg * n + et)
+        new = cand[~_isin_sorted(core, cand)]
+        if new.numel() == 0:
+            break
+        core = _unique_sorted(torch.cat([core, new]))
+        frontier = new
+    cg, cn = torch.div(core, n, rounding_mode="floor"), core % n
+
+    # 2. positional neighbours of core nodes (get_neighbour_graph)
+    ks = torch.tensor([k for k in range(-neighbours, neighbours + 1) if k != 0], dtype=torch.int64, device=dev)
+    nb_g = cg.repeat_interleave(ks.numel())
+    nb_a = cn.repeat_interleave(ks.numel())
+    nb_b = nb_a + ks.repeat(cn.numel())
+    inr = (nb_b >= 0) & (nb_b < n)
+    nb_g, nb_a, nb_b = nb_g[inr], nb_a[inr], nb_b[inr]
+    extra = _unique_sorted(nb_g * n + nb_b)
+    extra = extra[~_isin_sorted(core, extra)]
+    xg, xn = torch.div(extra, n, rounding_mode="floor"), extra % n
+
+    # node list per group: core (ascending) then extra (ascending)
+    all_g = torch.cat([cg, xg])
+    all_n = torch.cat([cn, xn])
+    flag = torch.cat([torch.zeros_like(cg), torch.ones_like(xg)])
+    o = torch.argsort((all_g * 2 + flag) * n + all_n)
+    all_g, all_n = all_g[o], all_n[o]
+    nodes_per_group = torch.bincount(all_g, minlength=ngroups)
+    node_off_g = torch.zeros(ngroups + 1, dtype=torch.int64, device=dev)
+    node_off_g[1:] = torch.cumsum(nodes_per_group, 0)
+    local = torch.arange(all_g.numel(), device=dev) - node_off_g[all_g]
+    # lookup (gid, node) -> local id
+    lk = all_g * n + all_n
+    lo = torch.argsort(lk)
+    lk_sorted, lk_local = lk[lo], local[lo]
+
+    def lookup(g, v):
+        q = g * n + v
+        if lk_sorted.numel() == 0:
+            return torch.zeros_like(q, dtype=torch.bool), torch.zeros_like(q)
+        pos = torch.searchsorted(lk_sorted, q).clamp_(max=lk_sorted.numel() - 1)
+        return lk_sorted[pos] == q, lk_local[pos]
+
+    # 3. similarity edges with both endpoints inside the sub-graph (build_edge_index on the sub dict)
+    eg, et, epos, rep = _expand_by_src(rowptr, dst, all_g, all_n)
+    inside, t_local = lookup(eg, et)
+    eg, epos, s_local, t_local = eg[inside], epos[inside], local[rep][inside], t_local[inside]
+    e_w = weight[epos].to(torch.float32)
+    s_glob, t_glob = src[epos], dst[epos]
+    if labels_group_of is not None:
+        a, b = labels_group_of[s_glob], labels_group_of[t_glob]
+        y = ((a == b) & (a >= 0)).to(torch.float32)
+    else:
+        k = torch.cat([pair_src * n + pair_dst, pair_dst * n + pair_src]).unique()
+        y = _isin_sorted(k, s_glob * n + t_glob).to(torch.float32)
+    edges_per_group = torch.bincount(eg, minlength=ngroups)
+
+    # neighbour edges (core v, v +- k), both directions, de-duplicated
+    _, a_local = lookup(nb_g, nb_a)
+    _, b_local = lookup(nb_g, nb_b)
+    big = int(nodes_per_group.max().item()) + 1 if ngroups else 1
+    und = _unique_sorted(torch.cat([(nb_g * big + a_local) * big + b_local, (nb_g * big + b_local) * big + a_local]))
+    ng = torch.div(und, big * big, rounding_mode="floor")
+    na = torch.div(und, big, rounding_mode="floor") % big
+    nbb = und % big
+    nb_per_group = torch.bincount(ng, minlength=ngroups)
+
+    # 4. drop groups (dataset.py:230,235,248,252)
+    sim_rows = torch.zeros(ngroups, dtype=torch.int64, device=dev).index_add_(0, all_g, has_rows[all_n].long())
+    keep_g = (gsize > 1) & (nodes_per_group > 0) & (sim_rows > 0)
+    if require_edges_ge_members:
+        keep_g &= edges_per_group >= gsize
+    new_gid = torch.cumsum(keep_g.long(), 0) - 1
+    n_sub = int(keep_g.sum())
+
+    def compact(g, *cols):
+        m = keep_g[g]
+        return (new_gid[g[m]],) + tuple(c[m] for c in cols)
+
+    all_g2, all_n2, local2 = compact(all_g, all_n, local)
+    eg2, s2, t2, w2, y2 = compact(eg, s_local, t_local, e_w, y)
+    ng2, na2, nb2 = compact(ng, na, nbb)
+    node_off = torch.zeros(n_sub + 1, dtype=torch.int64, device=dev)
+    node_off[1:] = torch.cumsum(torch.bincount(all_g2, minlength=n_sub), 0)
+    edge_off = torch.zeros(n_sub + 1, dtype=torch.int64, device=dev)
+    edge_off[1:] = torch.cumsum(torch.bincount(eg2, minlength=n_sub), 0)
+    nb_off = torch.zeros(n_sub + 1, dtype=torch.int64, device=dev)
+    nb_off[1:] = torch.cumsum(torch.bincount(ng2, minlength=n_sub), 0)
+    # dataset-wide node numbering: local id + first node of the sub-graph
+    return SubGraphDataset(
+        num_graphs=n_sub, node_off=node_off, edge_off=edge_off, nb_off=nb_off, node_global=all_n2,
+        edge_index=torch.stack([s2 + node_off[eg2], t2 + node_off[eg2]]), edge_attr=w2, y=y2,
+        neighbour_edge_index=torch.stack([na2 + node_off[ng2], nb2 + node_off[ng2]]),
+        group_of_graph=torch.nonzero(keep_g).view(-1))
+
+
+class SubGraphDataset:
+    """Flat storage of all sub-graphs; `batch(i0, i1)` is the disjoint union of sub-graphs [i0, i1)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __len__(self):
+        return self.num_graphs
+
+    def batch(self, i0: int, i1: int):
+        i1 = min(i1, self.num_graphs)
+        n0, n1 = int(self.node_off[i0]), int(self.node_off[i1])
+        e0, e1 = int(self.edge_off[i0]), int(self.edge_off[i1])
+        b0, b1 = int(self.nb_off[i0]), int(self.nb_off[i1])
+        dev = self.edge_index.device
+        ptr = self.node_off[i0:i1 + 1] - n0
+        return SimpleNamespace(
+            x=torch.ones(n1 - n0, 1, dtype=torch.float32, device=dev),
+            edge_index=(self.edge_index[:, e0:e1] - n0).contiguous(),
+            edge_attr=self.edge_attr[e0:e1].contiguous(), y=self.y[e0:e1].contiguous(),
+            neighbour_edge_index=(self.neighbour_edge_index[:, b0:b1] - n0).contiguous(),
+            ptr=ptr, num_graphs=i1 - i0,
+            batch=torch.repeat_interleave(torch.arange(i1 - i0, device=dev), ptr[1:] - ptr[:-1]))
+
+    def graph(self, i: int):
+        return self.batch(i, i + 1)
+
+    def class_balance(self):
+        pos = self.y.sum().clamp_min(1)
+        return ((self.y == 0).sum() / pos).to(torch.float32)

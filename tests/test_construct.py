@@ -1,0 +1,141 @@
+"""CPU suite: the product's tensor-program graph construction (pangnn_amd/construct.py, subgraphs.py,
+simulate.py) against fixtures built by the reference's own code (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from pangnn_amd import construct, simulate, subgraphs
+
+FIXTURES = ["sim_200x4", "cfg1_2genomes", "cfg2_sim_1000x5", "cfg3_5genomes"]
+
+
+def T(f, k):
+    return torch.from_numpy(f[k])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_whole_graph_construction_is_bit_exact(name):
+    f = load_golden(name)
+    g = construct.build_from_raw(int(f["num_nodes"]), T(f, "raw_src"), T(f, "raw_dst"), T(f, "raw_score"),
+                                 T(f, "genome_of").long(), pair_src=T(f, "grp_src"), pair_dst=T(f, "grp_dst"))
+    o = np.lexsort((f["whole_edge_index"][1], f["whole_edge_index"][0]))
+    assert np.array_equal(g.edge_index.numpy(), f["whole_edge_index"][:, o])          # bit-exact edge_index
+    assert np.array_equal(g.neighbour_edge_index.numpy(), f["whole_neighbour_edge_index"])
+    assert np.array_equal(g.y.numpy(), f["whole_y"][o])
+    assert np.array_equal(g.edge_attr.numpy(), f["whole_edge_attr"][o])               # fp32 weights identical on CPU
+    assert np.array_equal(g.x.numpy(), f["whole_x"])
+
+
+def _groups_from_pairs(f):
+    """ortholog groups as (group id, member) arrays: a key gene and its members form one group"""
+    ks, ms = f["grp_src"], f["grp_dst"]
+    n = int(f["num_nodes"])
+    gmin = np.arange(n)
+    np.minimum.at(gmin, ks, ms)
+    np.minimum.at(gmin, ks, ks)
+    genes = np.unique(ks)
+    rep = gmin[genes]
+    # a group's representative is its smallest member; every member maps to it after one more hop
+    rep = np.minimum(rep, gmin[rep])
+    _, gid = np.unique(rep, return_inverse=True)
+    return torch.from_numpy(gid.astype(np.int64)), torch.from_numpy(genes.astype(np.int64))
+
+
+@pytest.mark.parametrize("name,subset", [("sim_200x4", False), ("cfg1_2genomes", True), ("cfg3_5genomes", True),
+                                         ("cfg2_sim_1000x5", False)])
+def test_subgraphs_equal_the_reference_sets(name, subset):
+    """node set, similarity edges (+ weight, label) and neighbour edges of every reference sub-graph, in
+    GLOBAL ids (the reference's local numbering is CPython set order)"""
+    f = load_golden(name)
+    n = int(f["num_nodes"])
+    gid, mem = _groups_from_pairs(f)
+    ds = subgraphs.build_subgraphs(n, T(f, "nrm_src"), T(f, "nrm_dst"), T(f, "nrm_weight"), gid, mem, neighbours=1,
+                                   pair_src=T(f, "grp_src"), pair_dst=T(f, "grp_dst"),
+                                   require_edges_ge_members=subset)
+    mine = {}          # node set -> candidate sub-graphs (two groups can span the same node set)
+    for i in range(len(ds)):
+        nodes = ds.node_global[int(ds.node_off[i]):int(ds.node_off[i + 1])].numpy()
+        mine.setdefault(tuple(sorted(nodes.tolist())), []).append(i)
+    no, eo, bo = f["sub_node_off"], f["sub_edge_off"], f["sub_nb_off"]
+    total = int(f["n_train"]) + int(f["n_val"])
+    assert len(ds) >= len(no) - 1
+    if len(no) - 1 == total:                       # fixture holds every train+val graph (70 % + 15 %)
+        assert abs(len(ds) * 0.85 - total) <= 2
+    for k in range(len(no) - 1):
+        glob = f["sub_global_node"][no[k]:no[k + 1]]
+        key = tuple(sorted(glob.tolist()))
+        assert key in mine, f"reference sub-graph {k} (|V|={len(key)}) has no counterpart"
+        ref_nb = glob[f["sub_neighbour_edge_index"][:, bo[k]:bo[k + 1]]]
+        ref_nb_set = set(map(tuple, ref_nb.T.tolist()))
+        assert len(ref_nb_set) == ref_nb.shape[1]                       # reference de-duplicates
+        match = None
+        for i in mine[key]:            # same node set: the neighbour edges tell the groups apart
+            b = ds.graph(i)
+            mg = ds.node_global[int(ds.node_off[i]):int(ds.node_off[i + 1])].numpy()
+            my_nb = mg[b.neighbour_edge_index.numpy()]
+            if my_nb.shape == ref_nb.shape and set(map(tuple, my_nb.T.tolist())) == ref_nb_set:
+                match = i
+                break
+        assert match is not None, f"no sub-graph with the neighbour edges of reference sub-graph {k}"
+        mine[key].remove(match)        # one-to-one
+        ref_e = glob[f["sub_edge_index"][:, eo[k]:eo[k + 1]]]
+        my_e = mg[b.edge_index.numpy()]
+        ro, mo = np.lexsort((ref_e[1], ref_e[0])), np.lexsort((my_e[1], my_e[0]))
+        assert np.array_equal(ref_e[:, ro], my_e[:, mo])
+        assert np.array_equal(f["sub_edge_attr"][eo[k]:eo[k + 1]][ro], b.edge_attr.numpy()[mo])
+        assert np.array_equal(f["sub_y"][eo[k]:eo[k + 1]][ro], b.y.numpy()[mo])
+
+
+def test_subgraph_batches_are_disjoint_unions():
+    f = load_golden("cfg1_2genomes")
+    gid, mem = _groups_from_pairs(f)
+    ds = subgraphs.build_subgraphs(int(f["num_nodes"]), T(f, "nrm_src"), T(f, "nrm_dst"), T(f, "nrm_weight"), gid,
+                                   mem, pair_src=T(f, "grp_src"), pair_dst=T(f, "grp_dst"),
+                                   require_edges_ge_members=True)
+    b = ds.batch(3, 35)
+    assert b.num_graphs == 32 and b.x.shape[0] == int(b.ptr[-1])
+    assert int(b.edge_index.min()) >= 0 and int(b.edge_index.max()) < b.x.shape[0]
+    # every edge stays inside its own sub-graph
+    gb = b.batch
+    assert torch.equal(gb[b.edge_index[0]], gb[b.edge_index[1]])
+    assert torch.equal(gb[b.neighbour_edge_index[0]], gb[b.neighbour_edge_index[1]])
+    one = ds.graph(5)
+    e0 = int(ds.edge_off[5] - ds.edge_off[3])
+    off = int(ds.node_off[5] - ds.node_off[3])
+    assert torch.equal(b.edge_index[:, e0:e0 + one.edge_index.shape[1]], one.edge_index + off)
+
+
+# ---------------------------------------------------------------- simulator: distributional parity
+def test_simulator_matches_reference_statistics():
+    """the reference never seeds its RNG, so compare laws, not samples (cfg 2: 1000 x 5, frac 0.3)"""
+    f = load_golden("cfg2_sim_1000x5")
+    g = simulate.simulate_graph(1000, 5, 0.3, 10, 2, seed=3)
+    assert g.num_nodes == 5000 and g.neighbour_edge_index.shape[1] == 14998
+    e_ref = f["whole_edge_index"].shape[1]
+    assert abs(g.edge_index.shape[1] - e_ref) / e_ref < 0.05
+    assert abs(float(g.y.mean()) - float(f["whole_y"].mean())) < 0.01
+    assert abs(float(g.edge_attr.mean()) - float(f["whole_edge_attr"].mean())) / float(f["whole_edge_attr"].mean()) < 0.05
+    assert float(g.edge_attr.min()) >= 1.0 and float(g.edge_attr.max()) <= 81.0001
+    deg = torch.bincount(g.edge_index[1], minlength=5000).float()
+    dref = np.bincount(f["whole_edge_index"][1], minlength=5000)
+    assert abs(float(deg.median()) - np.median(dref)) <= 1
+    assert 0.6 < float(deg.quantile(0.99)) / np.quantile(dref, 0.99) < 1.6
+    # structure: no self loops; after remove_trivial_cases only adjacent genomes stay linked; the RAW
+    # relation is symmetric with one score per pair (simulate.py:166-167,188-189)
+    s, d = g.edge_index
+    assert not bool((s == d).any())
+    assert int(((s // 1000) - (d // 1000)).abs().max()) == 1
+    raw = simulate.simulate_raw(1000, 5, 0.3, 10, 2, seed=3)
+    fwd = torch.stack([raw.src * 5000 + raw.dst, raw.score.long()], 1)
+    bwd = torch.stack([raw.dst * 5000 + raw.src, raw.score.long()], 1)
+    assert torch.equal(fwd[torch.argsort(fwd[:, 0])], bwd[torch.argsort(bwd[:, 0])])
+    assert torch.unique(fwd[:, 0]).numel() == fwd.shape[0]             # a dict: one score per ordered pair
+
+
+def test_simulator_is_seeded():
+    a = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=7)
+    b = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=7)
+    c = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=8)
+    assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.edge_attr, b.edge_attr)
+    assert a.edge_index.shape != c.edge_index.shape or not torch.equal(a.edge_index, c.edge_index)

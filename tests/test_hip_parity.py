@@ -496,3 +496,24 @@ def test_halo_gradient_accumulation_is_a_fixed_order_segment_sum():
         ops.accumulate_back(g, back.to(dev()), plan)
         outs.append(g)
     assert close(outs[0], ref, atol=1e-5, rtol=1e-5) and torch.equal(outs[0], outs[1])
+
+
+def test_model_on_native_subgraph_batches_matches_oracle():
+    """sub-graphs built by pangnn_amd/subgraphs.py on the GPU, batched as slices, through the HIP model;
+    the oracle sees the same batch on the CPU"""
+    import pangnn_amd
+    from pangnn_amd import simulate
+    ds = simulate.simulate_subgraph_dataset(300, 4, 0.3, 10, 2, seed=5, device=dev())
+    assert len(ds) > 200
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 128))
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+    model.load_state_dict(oracle.state_dict())
+    for i0 in (0, 32, len(ds) - 7):
+        b = ds.batch(i0, i0 + 32)
+        ref = oracle(copy_graph(b, "cpu"))
+        assert close(model(b), ref)
+    # structure caches live on each batch object: a second pass over the same batch reuses them
+    b = ds.batch(0, 32)
+    a1 = model(b)
+    assert hasattr(b, "_pangnn_structs") and torch.equal(a1, model(b))
