@@ -79,17 +79,21 @@ def minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd):
     pw = ds.class_balance()
     torch.manual_seed(0)
     model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h])
-    opt = make_optimizer(model)
+    graphed = os.environ.get("PANGNN_HIPGRAPH", "1") != "0"
+    opt = make_optimizer(model, capturable=graphed)
+    if graphed:
+        from pangnn_amd.train import GraphedTrainStep
+        steps_fn = [GraphedTrainStep(model, opt, b, b.y, pw) for b in batches]     # one HIP graph per batch
+    else:
+        steps_fn = [(lambda b=b: train_step(model, opt, b, b.y, pw)) for b in batches]
     for k in range(args.warmup):
-        b = batches[k % len(batches)]
-        train_step(model, opt, b, b.y, pw)
+        steps_fn[k % len(batches)]()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     edges = 0
     for k in range(args.steps):
-        b = batches[k % len(batches)]
-        loss, _ = train_step(model, opt, b, b.y, pw)
-        edges += b.edge_index.shape[1]
+        loss, _ = steps_fn[k % len(batches)]()
+        edges += batches[k % len(batches)].edge_index.shape[1]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     line = {"metric": "edges/sec in GNN forward+backward (link-pred train step)", "value": edges / dt,
@@ -98,7 +102,7 @@ def minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf} --train, mini-batches of 32 "
                                    f"per-group sub-graphs ({len(batches)} batches, {n_train} train sub-graphs), "
-                                   f"node_dim={d} hidden_dim={h}",
+                                   f"node_dim={d} hidden_dim={h}" + (", one captured HIP graph per batch" if graphed else ""),
                        "mean_edges_per_batch": edges / args.steps, "final_loss": float(loss.item())}}
     os.write(json_fd, (json.dumps(line) + "\n").encode())
 

@@ -17,8 +17,8 @@ def criterion(logits, labels, pos_weight):
     return F.binary_cross_entropy_with_logits(logits, labels, pos_weight=pos_weight)
 
 
-def make_optimizer(model, lr: float = 1e-3):
-    return torch.optim.Adam(model.parameters(), lr=lr)      # pangnn.py:88
+def make_optimizer(model, lr: float = 1e-3, capturable: bool = False):
+    return torch.optim.Adam(model.parameters(), lr=lr, capturable=capturable)      # pangnn.py:88
 
 
 def train_step(model, optimizer, graph, labels, pos_weight):
@@ -35,3 +35,43 @@ def train_step(model, optimizer, graph, labels, pos_weight):
 def eval_step(model, graph, labels, pos_weight):
     out = model(graph)
     return criterion(out, labels, pos_weight), out
+
+
+class GraphedTrainStep:
+    """The whole train step (zero_grad -> forward -> loss -> backward -> Adam) of ONE fixed batch captured
+    into a HIP graph and replayed.  For the reference's regime (32 small sub-graphs per batch,
+    pangnn.py:152-216) a step is ~70 launches of a few microseconds of GPU work each, i.e. bound by the
+    host launch path; replaying a captured graph removes it.  One instance per distinct batch (shapes are
+    baked in); parameters and optimizer state are shared, so instances for different batches can be
+    replayed in any order, exactly like iterating a DataLoader.
+
+    The batch's structures / normalisations are built (and cached on the batch) by the warm-up steps
+    that precede capture, so the captured region contains kernel launches only."""
+
+    def __init__(self, model, optimizer, graph, labels, pos_weight, warmup: int = 2):
+        for g in optimizer.param_groups:
+            if not g.get("capturable", False):
+                raise ValueError("GraphedTrainStep needs torch.optim.Adam(..., capturable=True)")
+        self.model, self.optimizer = model, optimizer
+        self.graph, self.labels, self.pos_weight = graph, labels, pos_weight
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        self.cuda_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.cuda_graph):
+            self.loss, self.logits = self._step()
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        out = self.model(self.graph)
+        loss = criterion(out, self.labels, self.pos_weight)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach(), out.detach()
+
+    def __call__(self):
+        self.cuda_graph.replay()
+        return self.loss, self.logits

@@ -517,3 +517,45 @@ def test_model_on_native_subgraph_batches_matches_oracle():
     b = ds.batch(0, 32)
     a1 = model(b)
     assert hasattr(b, "_pangnn_structs") and torch.equal(a1, model(b))
+
+
+def test_hip_graph_replay_equals_eager_steps():
+    """GraphedTrainStep: the captured train step replayed N times == N eager steps (same kernels, same
+    order => bitwise), for two different batches sharing one model / optimizer"""
+    import pangnn_amd
+    from pangnn_amd import simulate
+    from pangnn_amd.train import GraphedTrainStep, make_optimizer, train_step
+    ds = simulate.simulate_subgraph_dataset(300, 4, 0.3, 10, 2, seed=5, device=dev())
+    batches = [ds.batch(0, 32), ds.batch(32, 64)]
+    pw = ds.class_balance()
+
+    def run_graphed():
+        torch.manual_seed(0)
+        model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+        opt = make_optimizer(model, capturable=True)
+        fns = [GraphedTrainStep(model, opt, b, b.y, pw, warmup=1) for b in batches]
+        losses = []
+        for k in range(6):
+            l, _ = fns[k % 2]()
+            losses.append(float(l))
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    # capture itself does not run the kernels, so eager needs exactly `warmup` extra steps per batch
+    def run_eager():
+        torch.manual_seed(0)
+        model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+        opt = make_optimizer(model, capturable=True)
+        for b in batches:
+            train_step(model, opt, b, b.y, pw)
+        losses = []
+        for k in range(6):
+            b = batches[k % 2]
+            l, _ = train_step(model, opt, b, b.y, pw)
+            losses.append(float(l))
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    lg, pg = run_graphed()
+    le, pe = run_eager()
+    assert lg == le
+    for a, b in zip(pg, pe):
+        assert torch.equal(a, b)
