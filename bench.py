@@ -241,16 +241,18 @@ def main():
                          "bwd_avg_launch_ms": (sum(k_bwd) / max(len(k_bwd), 1)) * 1e3},
         }
         if d_bwd:
-            # the decoder kernels are bound by the f32 matrix pipe, not by HBM: report them against the
-            # dense f32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s).  2*64*64 flop per edge per product;
-            # forward = 1 product, backward = 3 (recompute, dL/dh1, dL/dW2).
+            # the decoder kernel is bound by the f32 matrix pipe, not by HBM: report it against the dense
+            # f32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s).  2*64*64 flop per edge per product; the
+            # training pass (logits + BCE + all gradients in one kernel) runs 3 products per edge:
+            # W2 h1, dL/dh1 = G^T W2, dL/dW2 += G h1.  (`fwd_*` is null when no separate forward ran.)
             e_loc = getattr(graph, "e_sim_local", e_sim)
             tb, tfw = sum(d_bwd) / len(d_bwd), sum(d_fwd) / max(len(d_fwd), 1)
             line["roofline_decoder"] = {
-                "bound": "mfma", "kernel": "decoder_bwd_kernel (largest single kernel of the step)",
+                "bound": "mfma", "kernel": "decoder_bwd_kernel<fused loss> (largest single kernel of the step)",
                 "achieved": 3 * 8192 * e_loc / tb / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                 "frac": 3 * 8192 * e_loc / tb / 157.3e12, "avg_launch_ms": tb * 1e3,
-                "fwd_achieved": 8192 * e_loc / tfw / 1e12 if tfw > 0 else None, "fwd_avg_launch_ms": tfw * 1e3}
+                "fwd_achieved": 8192 * e_loc / tfw / 1e12 if tfw > 0 else None,
+                "fwd_avg_launch_ms": tfw * 1e3 if tfw > 0 else None}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, d, h)
         os.write(json_fd, (json.dumps(line) + "\n").encode())

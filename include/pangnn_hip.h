@@ -163,6 +163,19 @@ int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const float* q, int6
                                float* g_cvec, void* workspace, size_t workspace_bytes,
                                pangnn_stream_t stream);
 
+/* Training form of the decoder: logits, BCEWithLogits(pos_weight) mean loss (denominator `denom`) AND every
+ * gradient in ONE pass over the edges — the logits of a tile come out of the backward's recomputed first
+ * product, so forward + criterion + backward (pangnn.py:200-207) do not need three kernels and the
+ * forward's product is not computed twice.  Outputs as pangnn_decoder_mlp_bwd_f32 plus logits[E], loss[1];
+ * all gradients are those of `loss` (upstream gradient 1). */
+int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
+                                const int64_t* edge_index, int64_t ld, int64_t num_edges, const float* extra,
+                                const float* cvec, const float* w2, const float* b2, const float* w3,
+                                const float* b3, int32_t D, const float* y, const float* pos_weight,
+                                int64_t denom, float* logits, float* loss, float* g_h1, float* g_w2,
+                                float* g_b2, float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                size_t workspace_bytes, pangnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Node-level dense layers with a short inner dimension, K (in) and M (out) in {64, 128}
  * (GCNConv.lin = k4 of SURVEY.md §2.2, the decoder's node-level P|Q product, and their backward):

@@ -243,8 +243,17 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a
   }
 }
 
+// FUSED_LOSS: the upstream gradient is not read but produced in place — the tile's logits come out of the
+// first product anyway, so BCEWithLogits(pos_weight) and its derivative are evaluated right there
+// (pangnn.py:200-207 in one pass): a training step then runs this kernel only, not forward + loss +
+// backward, and the forward's 64 MFMAs per tile are not spent twice.
+struct LossParams {
+  const float* y; const float* pos_weight; float inv_denom; float* logits; 
+};
+
+template <bool FUSED_LOSS>
 __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
-    DecParams a, const float* __restrict__ g_logits, float* __restrict__ g_h1,
+    DecParams a, const float* __restrict__ g_logits, LossParams lp, float* __restrict__ g_h1,
     float* __restrict__ slabs, int64_t n_tiles) {
   constexpr int PER_WAVE = TE * RS + 64 * GS + 64;   // Ht | H2t | w_e | g_e
   __shared__ __attribute__((aligned(16))) float lds[64 * RS + 3 * 64 + BWD_WAVES * PER_WAVE];
@@ -273,6 +282,9 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   float gb2p[2] = {0.f, 0.f};   // same lanes: partial of gb2[j]
   float gcv[2] = {0.f, 0.f};    // lane (k = r+32bp, hh): partial of gcvec[k]
   float gb3p = 0.f;
+  float lossp = 0.f;            // FUSED_LOSS: lanes < 32, partial of the (already 1/denom-scaled) loss
+  const float b3v = a.b3[0];
+  const float pw = (FUSED_LOSS && lp.pos_weight) ? lp.pos_weight[0] : 1.f;
 
   for (int64_t tile = (int64_t)blockIdx.x * BWD_WAVES + wave; tile < n_tiles;
        tile += (int64_t)gridDim.x * BWD_WAVES) {
@@ -280,33 +292,91 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
     float w_e;
     gather_tile(a, ebase, lane, Ht, cvl, w_e);
     float g_e = 0.f;
-    if (ebase + r < a.E) g_e = g_logits[ebase + r];
-    if (lane < 32) { wl[lane] = w_e; gl[lane] = g_e; gb3p += g_e; }
+    float y_e = 0.f;
+    const bool live = ebase + r < a.E;
+    if (FUSED_LOSS) {
+      if (live) y_e = lp.y[ebase + r];
+      if (lane < 32) wl[lane] = w_e;
+    } else {
+      if (live) g_e = g_logits[ebase + r];
+      if (lane < 32) { wl[lane] = w_e; gl[lane] = g_e; gb3p += g_e; }
+    }
     wave_lds_sync();
 
     f32x16 acc[2];
     gemm1(Wl, Ht, lane, acc);
 
-    // G[j][e] = g_e * w3[j] * [h2pre > 0]  (in place in acc; A operand of the next product);
-    // h2[j][e] goes to LDS: the weight-gradient product rebuilds G and g_e * h2 from it
+    if (FUSED_LOSS) {
+      // h2 = relu(C + b2) in place; the tile's logits; then loss and dL/dlogit per edge
+      float part = 0.f;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int j0 = 32 * b + 8 * qd + 4 * hh;
-        const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
-        const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
-        const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
-        const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+        for (int qd = 0; qd < 4; ++qd) {
+          const int j0 = 32 * b + 8 * qd + 4 * hh;
+          const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
+          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+          const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int i = 4 * qd + c;
-          const float pre = acc[b][i] + bbv[c];
-          const bool on = pre > 0.f;
-          acc[b][i] = on ? g_e * wwv[c] : 0.f;
-          Gt[(j0 + c) * GS + r] = on ? pre : 0.f;
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * qd + c;
+            const float h2 = fmaxf(acc[b][i] + bbv[c], 0.f);
+            acc[b][i] = h2;
+            part = fmaf(h2, wwv[c], part);
+            Gt[(j0 + c) * GS + r] = h2;
+          }
+        }
+      part += __shfl_xor(part, 32);
+      const float xv = part + b3v;
+      const float lw = 1.f + (pw - 1.f) * y_e;
+      const float t = expf(-fabsf(xv));
+      const float sig_neg = xv >= 0.f ? t / (1.f + t) : 1.f / (1.f + t);          // sigmoid(-x)
+      g_e = live ? ((1.f - y_e) - lw * sig_neg) * lp.inv_denom : 0.f;
+      if (lane < 32) {
+        gl[lane] = g_e;
+        gb3p += g_e;
+        if (live) {
+          lp.logits[ebase + r] = xv;
+          lossp += ((1.f - y_e) * xv + lw * (log1pf(t) + fmaxf(-xv, 0.f))) * lp.inv_denom;
         }
       }
+      // G[j][e] = g_e * w3[j] * [h2 > 0]  (A operand of the next product)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int j0 = 32 * b + 8 * qd + 4 * hh;
+          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * qd + c;
+            acc[b][i] = acc[b][i] > 0.f ? g_e * wwv[c] : 0.f;
+          }
+        }
+    } else {
+      // G[j][e] = g_e * w3[j] * [h2pre > 0]  (in place in acc; A operand of the next product);
+      // h2[j][e] goes to LDS: the weight-gradient product rebuilds G and g_e * h2 from it
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int j0 = 32 * b + 8 * qd + 4 * hh;
+          const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
+          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+          const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * qd + c;
+            const float pre = acc[b][i] + bbv[c];
+            const bool on = pre > 0.f;
+            acc[b][i] = on ? g_e * wwv[c] : 0.f;
+            Gt[(j0 + c) * GS + r] = on ? pre : 0.f;
+          }
+        }
+    }
     wave_lds_sync();
 
     // gH1[e][k] = sum_j G[j][e] W2[j][k]  : A = G from the accumulator registers, B = W2 rows
@@ -372,7 +442,10 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   gcv[0] += __shfl_xor(gcv[0], 32);
   gcv[1] += __shfl_xor(gcv[1], 32);
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) gb3p += __shfl_xor(gb3p, off);
+  for (int off = 16; off >= 1; off >>= 1) {
+    gb3p += __shfl_xor(gb3p, off);
+    lossp += __shfl_xor(lossp, off);
+  }
 
   __syncthreads();
   float* red = cvl + 64;   // reuse the tile area: SLAB floats
@@ -396,12 +469,15 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
           red[4096 + 128 + r + 32 * x] = (first ? 0.f : red[4096 + 128 + r + 32 * x]) + gcv[x];
         }
       }
-      if (lane == 0) red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
+      if (lane == 0) {
+        red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
+        red[4096 + 193] = (first ? 0.f : red[4096 + 193]) + lossp;
+      }
     }
     __syncthreads();
   }
   float* slab = slabs + (int64_t)blockIdx.x * SLAB;
-  for (int i = threadIdx.x; i < 4096 + 193; i += BWD_WAVES * 64) slab[i] = red[i];
+  for (int i = threadIdx.x; i < 4096 + 194; i += BWD_WAVES * 64) slab[i] = red[i];
 }
 
 // out[i] = sum over workgroup slabs in index order (fixed => reproducible)
@@ -410,16 +486,18 @@ __global__ __launch_bounds__(kBlock) void decoder_reduce_kernel(const float* __r
                                                                 float* __restrict__ g_b2,
                                                                 float* __restrict__ g_w3,
                                                                 float* __restrict__ g_cvec,
-                                                                float* __restrict__ g_b3) {
+                                                                float* __restrict__ g_b3,
+                                                                float* __restrict__ loss) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= 4096 + 193) return;
+  if (i >= 4096 + 194) return;
   float s = 0.f;
   for (int w = 0; w < n_slabs; ++w) s += slabs[(int64_t)w * SLAB + i];
   if (i < 4096) g_w2[i] = s;
   else if (i < 4096 + 64) g_b2[i - 4096] = s;
   else if (i < 4096 + 128) g_w3[i - 4096 - 64] = s;
   else if (i < 4096 + 192) { if (g_cvec) g_cvec[i - 4096 - 128] = s; }
-  else g_b3[0] = s;
+  else if (i == 4096 + 192) g_b3[0] = s;
+  else if (loss) loss[0] = s;
 }
 
 static int grid_cus() {
@@ -480,6 +558,38 @@ extern "C" size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges) {
   return (size_t)grid_cus() * SLAB * sizeof(float);
 }
 
+static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, int32_t D, const float* g_logits,
+                      const LossParams* lp, float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
+                      float* g_cvec, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  PG_CHECK_ARG(g_w2 && g_b2 && g_w3 && g_b3, PANGNN_E_BADARG, "%s: null gradient output", who);
+  const int64_t num_edges = a.E;
+  const int64_t n_tiles = (num_edges + TE - 1) / TE;
+  int64_t grid = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+  const int cus = grid_cus();
+  if (grid > cus) grid = cus;
+  if (grid < 1) grid = 1;
+  PG_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * SLAB * sizeof(float), PANGNN_E_WORKSPACE,
+               "%s: workspace too small", who);
+  PG_CHECK_ARG(num_edges == 0 || g_h1, PANGNN_E_BADARG, "%s: null g_h1", who);
+  if (num_edges == 0) {
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)grid * SLAB * sizeof(float), s);
+    PG_CHECK_ARG(e == hipSuccess, (int)e, "%s: memset failed", who);
+  } else if (lp) {
+    hipLaunchKernelGGL((decoder_bwd_kernel<true>), dim3((unsigned)grid), dim3(BWD_WAVES * 64), 0, s, a, g_logits,
+                       *lp, g_h1, static_cast<float*>(workspace), n_tiles);
+    PG_CHECK_LAUNCH(who);
+  } else {
+    LossParams none{nullptr, nullptr, 0.f, nullptr};
+    hipLaunchKernelGGL((decoder_bwd_kernel<false>), dim3((unsigned)grid), dim3(BWD_WAVES * 64), 0, s, a, g_logits,
+                       none, g_h1, static_cast<float*>(workspace), n_tiles);
+    PG_CHECK_LAUNCH(who);
+  }
+  hipLaunchKernelGGL(decoder_reduce_kernel, dim3((4096 + 194 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                     static_cast<const float*>(workspace), (int)grid, g_w2, g_b2, g_w3, g_cvec, g_b3, loss);
+  PG_CHECK_LAUNCH(who);
+  return 0;
+}
+
 extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq,
                                           int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                           const float* extra, const float* cvec, const float* w2,
@@ -490,27 +600,27 @@ extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const flo
   int rc = check_common("pangnn_decoder_mlp_bwd_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
                         cvec, w2, b2, w3, b3, D);
   if (rc) return rc;
-  PG_CHECK_ARG(g_w2 && g_b2 && g_w3 && g_b3, PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null gradient output");
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t n_tiles = (num_edges + TE - 1) / TE;
-  int64_t grid = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
-  const int cus = grid_cus();
-  if (grid > cus) grid = cus;
-  if (grid < 1) grid = 1;
-  PG_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * SLAB * sizeof(float), PANGNN_E_WORKSPACE,
-               "pangnn_decoder_mlp_bwd_f32: workspace too small");
-  PG_CHECK_ARG(num_edges == 0 || (g_logits && g_h1), PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null pointer");
+  PG_CHECK_ARG(num_edges == 0 || g_logits, PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null g_logits");
   DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
-  if (num_edges == 0) {
-    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)grid * SLAB * sizeof(float), s);
-    PG_CHECK_ARG(e == hipSuccess, (int)e, "pangnn_decoder_mlp_bwd_f32: memset failed");
-  } else {
-    hipLaunchKernelGGL(decoder_bwd_kernel, dim3((unsigned)grid), dim3(BWD_WAVES * 64), 0, s, a, g_logits,
-                       g_h1, static_cast<float*>(workspace), n_tiles);
-    PG_CHECK_LAUNCH("pangnn_decoder_mlp_bwd_f32");
-  }
-  hipLaunchKernelGGL(decoder_reduce_kernel, dim3((4096 + 193 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                     static_cast<const float*>(workspace), (int)grid, g_w2, g_b2, g_w3, g_cvec, g_b3);
-  PG_CHECK_LAUNCH("pangnn_decoder_mlp_bwd_f32(reduce)");
-  return 0;
+  return launch_bwd("pangnn_decoder_mlp_bwd_f32", a, num_nodes, D, g_logits, nullptr, g_h1, g_w2, g_b2, g_w3, g_b3,
+                    g_cvec, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int64_t ldq,
+                                           int64_t num_nodes, const int64_t* edge_index, int64_t ld,
+                                           int64_t num_edges, const float* extra, const float* cvec,
+                                           const float* w2, const float* b2, const float* w3, const float* b3,
+                                           int32_t D, const float* y, const float* pos_weight, int64_t denom,
+                                           float* logits, float* loss, float* g_h1, float* g_w2, float* g_b2,
+                                           float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                           size_t workspace_bytes, pangnn_stream_t stream) {
+  int rc = check_common("pangnn_decoder_mlp_loss_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
+                        cvec, w2, b2, w3, b3, D);
+  if (rc) return rc;
+  PG_CHECK_ARG(denom > 0 && loss && (num_edges == 0 || (y && logits)), PANGNN_E_BADARG,
+               "pangnn_decoder_mlp_loss_f32: bad denom / null pointer");
+  DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  LossParams lp{y, pos_weight, 1.0f / (float)denom, logits};
+  return launch_bwd("pangnn_decoder_mlp_loss_f32", a, num_nodes, D, nullptr, &lp, g_h1, g_w2, g_b2, g_w3, g_b3,
+                    g_cvec, loss, workspace, workspace_bytes, (hipStream_t)stream);
 }

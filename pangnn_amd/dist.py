@@ -233,6 +233,9 @@ class HipOps:
             return
         PF.segment_sum_rows(plan.back_csr, back, 0, back.shape[1], plan.n_local, out=g_local, accumulate=True)
 
+    def decoder_loss(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+        return PF.decoder_loss(p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
+
     def pair_rows(self, z_full, z_local, st):
         """(z[src], z[dst]) per owned edge for the cosine / dot decoders"""
         raise NotImplementedError("cosine / dot decoders are single-GPU only")
@@ -322,7 +325,7 @@ class DistAlternateGCN(AlternateGCN):
             h = act(self._conv(self.conv_out, h, shard, "nb", None, "1", "nb"))
         return h
 
-    def decode_mlp(self, z, shard):
+    def _dec_in(self, z, shard):
         fl = self.flags
         d = z.shape[1]
         lin0 = self.mlp[0]
@@ -332,11 +335,29 @@ class DistAlternateGCN(AlternateGCN):
         p_full = self._table(p, shard, "sim")
         extra = shard.edge_attr if fl.skip_connections else None
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
+        return p_full, q, extra, cvec
+
+    def decode_mlp(self, z, shard):
+        p_full, q, extra, cvec = self._dec_in(z, shard)
         return self.ops.decoder(p_full, q, self._st(shard, "sim"), extra, cvec, self.mlp[2].weight,
                                 self.mlp[2].bias, self.mlp[4].weight.view(-1), self.mlp[4].bias)
 
     def forward(self, shard):
         return self.decode_mlp(self.encode(shard), shard)
+
+    def loss_and_logits(self, shard, labels, pos_weight=None):
+        """global-mean BCE loss share of this rank + local logits; one decoder pass on the HIP back end"""
+        z = self.encode(shard)
+        if hasattr(self.ops, "decoder_loss") and torch.is_grad_enabled():
+            p_full, q, extra, cvec = self._dec_in(z, shard)
+            return self.ops.decoder_loss(p_full, q, self._st(shard, "sim"), extra, cvec, self.mlp[2].weight,
+                                         self.mlp[2].bias, self.mlp[4].weight.view(-1), self.mlp[4].bias, labels,
+                                         pos_weight, shard.e_sim_total)
+        out = self.decode_mlp(z, shard)
+        if out.is_cuda:
+            return PF.bce_with_logits(out, labels, pos_weight, denom=shard.e_sim_total), out.detach()
+        return F.binary_cross_entropy_with_logits(out, labels, pos_weight=pos_weight,
+                                                  reduction="sum") / shard.e_sim_total, out.detach()
 
     def sync_gradients(self):
         """one flat all-reduce (sum) of every parameter gradient: 216 KB at default dims"""
@@ -356,12 +377,7 @@ def train_step(model: DistAlternateGCN, optimizer, shard, labels, pos_weight):
     """pangnn.py:194-216 on a shard: the loss is the GLOBAL mean, so every rank divides its local sum
     by the global edge count and the gradient all-reduce is a plain sum."""
     optimizer.zero_grad(set_to_none=True)
-    out = model(shard)
-    if out.is_cuda:
-        loss = PF.bce_with_logits(out, labels, pos_weight, denom=shard.e_sim_total)
-    else:                                               # gloo CPU tests
-        loss = F.binary_cross_entropy_with_logits(out, labels, pos_weight=pos_weight,
-                                                  reduction="sum") / shard.e_sim_total
+    loss, out = model.loss_and_logits(shard, labels, pos_weight)
     loss.backward()
     model.sync_gradients()
     optimizer.step()

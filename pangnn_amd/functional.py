@@ -330,6 +330,74 @@ def decoder_mlp_pq(pq, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
     return _DecoderMLP.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, True)
 
 
+class _DecoderLoss(torch.autograd.Function):
+    """Training form of the fused decoder: mean BCEWithLogits(pos_weight) loss, logits and ALL gradients in
+    one pass over the edges (pangnn_decoder_mlp_loss_f32).  Everything is computed in forward(); backward()
+    only scales the stored gradients by the upstream gradient of the loss."""
+
+    @staticmethod
+    def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, pq_joint):
+        lib = _lib.load()
+        _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3, y, pos_weight)
+        if pq_joint:
+            pq = _rows_f32(p)
+            d = pq.shape[1] // 2
+            p, q = pq[:, :d], pq[:, d:]
+        else:
+            p, q = _rows_f32(p), _rows_f32(q)
+        w2, b2, w3, b3, y = (_f32c(t) for t in (w2, b2, w3, b3, y))
+        ex = None if extra is None else _f32c(extra)
+        cv = None if cvec is None else _f32c(cvec)
+        pw = None if pos_weight is None else _f32c(pos_weight).reshape(-1)
+        e, d = st.num_edges, p.shape[1]
+        dev = p.device
+        logits = torch.empty(e, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        g_h1 = torch.empty(e, d, dtype=torch.float32, device=dev)
+        g_w2 = torch.empty_like(w2)
+        g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
+        g_cv = None if cv is None else torch.empty_like(cv)
+        with torch.cuda.device(dev):
+            ws_bytes = lib.pangnn_decoder_mlp_bwd_workspace_bytes(e)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            ev = _timer_start("dec.bwd")
+            _lib.check(lib.pangnn_decoder_mlp_loss_f32(
+                p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), max(p.shape[0], q.shape[0]),
+                st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
+                w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(y), _lib.ptr(pw), int(denom), _lib.ptr(logits),
+                loss.data_ptr(), _lib.ptr(g_h1), g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(), g_b3.data_ptr(),
+                _lib.ptr(g_cv), ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "pangnn_decoder_mlp_loss_f32")
+            _timer_stop("dec.bwd", ev)
+        if pq_joint:
+            g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
+            segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0], out=g_pq[:, :d])
+            segment_sum_rows(st.by_dst, g_h1, 0, d, p.shape[0], out=g_pq[:, d:])
+            gp, gq = g_pq, None
+        else:
+            gp = segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0])
+            gq = segment_sum_rows(st.by_dst, g_h1, 0, d, q.shape[0])
+        del g_h1
+        ctx.has_cv, ctx.has_q = g_cv is not None, gq is not None
+        ctx.save_for_backward(gp, gq if gq is not None else gp.new_empty(0),
+                              g_cv if g_cv is not None else gp.new_empty(0), g_w2, g_b2, g_w3, g_b3)
+        ctx.mark_non_differentiable(logits)
+        return loss.view(()), logits
+
+    @staticmethod
+    def backward(ctx, go, _go_logits):
+        gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
+        return (gp * go, (gq * go) if ctx.has_q else None, None, None, (g_cv * go) if ctx.has_cv else None,
+                g_w2 * go, g_b2 * go, g_w3 * go, g_b3 * go, None, None, None, None)
+
+
+def decoder_loss(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+    return _DecoderLoss.apply(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, False)
+
+
+def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+    return _DecoderLoss.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, True)
+
+
 class _Linear(torch.autograd.Function):
     """y = x w^T (+ b) over ~1e6 node rows with K, M in {64, 128}: streaming f32-MFMA kernels
     (pangnn_linear_fwd_f32 / pangnn_linear_wgrad_f32); dL/dx is the forward kernel with w^T."""

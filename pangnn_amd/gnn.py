@@ -104,6 +104,44 @@ class AlternateGCN(nn.Module):
             h = act(self.conv_out(h, graph.neighbour_edge_index, graph=graph, name="nb"))
         return h
 
+    def _decoder_inputs(self, z, graph):
+        """(pq [N,2D], structure, extra, cvec) of the re-associated first decoder layer"""
+        fl = self.flags
+        ei = graph.edge_index
+        st = structure_of(ei, z.shape[0], holder=graph, name="sim")
+        d = z.shape[1]
+        extra = graph.edge_attr[: ei.shape[1]] if fl.skip_connections else None
+        w = self.mlp[0].weight
+        cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
+        w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
+        b_pq = torch.cat([torch.zeros_like(self.mlp[0].bias), self.mlp[0].bias])
+        return PF.linear(z, w_pq, b_pq), st, extra, cvec
+
+    def loss_and_logits(self, graph, labels, pos_weight=None):
+        """`criterion(model(graph), labels)` (pangnn.py:200-203) as ONE decoder pass when the fused kernel
+        applies (mlp decoder, node_dim 64): returns (loss, detached logits).  Falls back to forward +
+        criterion otherwise."""
+        from .train import criterion
+        z = self.encode(graph)
+        if "mlp" in self.flags.decoder and self.fused_decoder is True and z.shape[1] == 64 and torch.is_grad_enabled():
+            pq, st, extra, cvec = self._decoder_inputs(z, graph)
+            return PF.decoder_loss_pq(pq, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
+                                      self.mlp[4].weight.view(-1), self.mlp[4].bias, labels, pos_weight,
+                                      labels.shape[0])
+        out = self._decode(z, graph)
+        return criterion(out, labels, pos_weight), out.detach()
+
+    def _decode(self, nodes, graph):
+        fl = self.flags
+        out = None
+        if "mlp" in fl.decoder:
+            out = self.decode_mlp(nodes, graph)
+        if "cosine" in fl.decoder:
+            out = self.cosine_sim(nodes, graph.edge_index, graph)
+        if "dot" in fl.decoder:
+            out = self.decode(nodes, graph.edge_index, graph)
+        return out
+
     def decode_mlp(self, z, graph) -> torch.Tensor:
         fl = self.flags
         ei = graph.edge_index
@@ -132,15 +170,7 @@ class AlternateGCN(nn.Module):
 
     def forward(self, graph) -> torch.Tensor:
         fl = self.flags
-        nodes = self.encode(graph)
-        link_predictions = None
-        if "mlp" in fl.decoder:
-            link_predictions = self.decode_mlp(nodes, graph)
-        if "cosine" in fl.decoder:
-            link_predictions = self.cosine_sim(nodes, graph.edge_index, graph)
-        if "dot" in fl.decoder:
-            link_predictions = self.decode(nodes, graph.edge_index, graph)
-        return link_predictions
+        return self._decode(self.encode(graph), graph)
 
     def _pairs(self, z, edge_index, graph=None):
         st = structure_of(edge_index, z.shape[0], holder=graph, name="sim")

@@ -24,8 +24,11 @@ def make_optimizer(model, lr: float = 1e-3, capturable: bool = False):
 def train_step(model, optimizer, graph, labels, pos_weight):
     """One step; returns (loss, logits) as device tensors without synchronising."""
     optimizer.zero_grad(set_to_none=True)
-    out = model(graph)
-    loss = criterion(out, labels, pos_weight)                                       # pangnn.py:98,203
+    if hasattr(model, "loss_and_logits"):
+        loss, out = model.loss_and_logits(graph, labels, pos_weight)                # fused forward + criterion
+    else:
+        out = model(graph)
+        loss = criterion(out, labels, pos_weight)                                   # pangnn.py:98,203
     loss.backward()
     optimizer.step()
     return loss.detach(), out.detach()
@@ -66,8 +69,11 @@ class GraphedTrainStep:
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
-        out = self.model(self.graph)
-        loss = criterion(out, self.labels, self.pos_weight)
+        if hasattr(self.model, "loss_and_logits"):
+            loss, out = self.model.loss_and_logits(self.graph, self.labels, self.pos_weight)
+        else:
+            out = self.model(self.graph)
+            loss = criterion(out, self.labels, self.pos_weight)
         loss.backward()
         self.optimizer.step()
         return loss.detach(), out.detach()

@@ -559,3 +559,40 @@ def test_hip_graph_replay_equals_eager_steps():
     assert lg == le
     for a, b in zip(pg, pe):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True)], ids=["default", "skip"])
+def test_fused_loss_pass_equals_forward_criterion_backward(flags):
+    """model.loss_and_logits (one decoder pass: logits + BCE + all gradients) vs model() + criterion +
+    backward (three kernels), and vs the oracle"""
+    from pangnn_amd.train import criterion
+    g, gd, oracle, model = _pair("cfg3_5genomes", (64, 128), flags)
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    # reference: oracle
+    lo = torch.nn.functional.binary_cross_entropy_with_logits(oracle(g), g.y, pos_weight=pw)
+    lo.backward()
+    # unfused HIP path
+    out = model(gd)
+    lu = criterion(out, gd.y, pw.to(dev()))
+    lu.backward()
+    gu = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    # fused
+    lf, logits = model.loss_and_logits(gd, gd.y, pw.to(dev()))
+    (lf * 1.0).backward()
+    assert close(logits, out, atol=1e-6, rtol=1e-6) and close(logits, oracle(g))
+    assert close(lf, lu, atol=1e-6, rtol=1e-6) and close(lf, lo, atol=1e-5, rtol=1e-5)
+    po = dict(oracle.named_parameters())
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        scale = float(gu[k].abs().max()) + 1e-12
+        assert close(p.grad, gu[k], atol=1e-5 * scale + 1e-9, rtol=1e-4), k
+        assert close(p.grad, po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), k
+    # upstream gradient scaling flows through the stored gradients
+    model.zero_grad()
+    lf2, _ = model.loss_and_logits(gd, gd.y, pw.to(dev()))
+    (lf2 * 3.0).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert close(p.grad, 3.0 * gu[k], atol=3e-5 * (float(gu[k].abs().max()) + 1e-12) + 1e-9, rtol=1e-4), k
