@@ -596,3 +596,52 @@ def test_fused_loss_pass_equals_forward_criterion_backward(flags):
     for k, p in model.named_parameters():
         if p.grad is not None:
             assert close(p.grad, 3.0 * gu[k], atol=3e-5 * (float(gu[k].abs().max()) + 1e-12) + 1e-9, rtol=1e-4), k
+
+
+def test_full_size_config4_invariants():
+    """BASELINE config 4 at full size (N = 1e6, E ~ 7.5e7): properties that need no oracle run.
+      * structure: rowptr ends at E, every row's edge ids ascend (stable sort), perm is a permutation
+      * gcn_norm: sum_e norm_e^2 * deg_src * deg_dst / w_e^2 == E over non-isolated endpoints (definition)
+      * one-pass training decoder == forward + criterion + backward (logits, loss, parameter gradients)
+      * propagate: <A x, y> == <x, A^T y>"""
+    import pangnn_amd
+    from pangnn_amd import functional as PF
+    from pangnn_amd import simulate
+    from pangnn_amd.graph import structure_of
+    from pangnn_amd.train import criterion
+    g = simulate.simulate_graph(50000, 20, 0.2, 100, 20, seed=0, device=dev())
+    n, e = g.num_nodes, g.edge_index.shape[1]
+    assert n == 1_000_000 and 7.0e7 < e < 8.0e7 and g.neighbour_edge_index.shape[1] == 3 * n - 2
+    st = structure_of(g.edge_index, n, holder=g, name="sim")
+    for csr in (st.by_dst, st.by_src):
+        assert int(csr.rowptr[0]) == 0 and int(csr.rowptr[-1]) == e
+        assert bool((csr.rowptr[1:] >= csr.rowptr[:-1]).all())
+        inner = torch.ones(e, dtype=torch.bool, device=dev())
+        inner[csr.rowptr[:-1][csr.rowptr[:-1] < e]] = False            # first edge of each row
+        assert bool((csr.perm[1:] > csr.perm[:-1])[inner[1:]].all())    # ascending original id inside a row
+        assert int(torch.bincount(csr.perm.long(), minlength=e).max()) == 1
+    nrm = st.gcn_norm(g.edge_attr)
+    deg = torch.zeros(n, device=dev()).index_add_(0, g.edge_index[1], g.edge_attr)
+    s, d = g.edge_index
+    lhs = (nrm.orig.double() ** 2 * deg[s].double() * deg[d].double() / g.edge_attr.double() ** 2)
+    ok = (deg[s] > 0) & (deg[d] > 0)
+    assert abs(float(lhs[ok].sum()) / float(ok.sum()) - 1.0) < 1e-5
+    x, y = torch.randn(n, 64, device=dev()), torch.randn(n, 64, device=dev())
+    ax = PF.propagate(x, None, st, nrm)
+    aty = PF.spmm_csr(st.by_src, nrm.by_src, y, n)
+    l, r = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
+    assert abs(l - r) <= 1e-6 * max(abs(l), abs(r), 1.0)
+    torch.manual_seed(0)
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+    out = model(g)
+    lu = criterion(out, g.y, g.class_balance)
+    lu.backward()
+    gu = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    lf, logits = model.loss_and_logits(g, g.y, g.class_balance)
+    lf.backward()
+    assert close(logits, out, atol=1e-6, rtol=1e-6) and close(lf, lu, atol=1e-6, rtol=1e-6)
+    assert bool(torch.isfinite(logits).all())
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert close(p.grad, gu[k], atol=1e-4 * (float(gu[k].abs().max()) + 1e-12) + 1e-10, rtol=1e-3), k
