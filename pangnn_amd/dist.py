@@ -48,11 +48,29 @@ from .graph import EdgeStructure
 # --------------------------------------------------------------------------------------
 # collectives with autograd
 # --------------------------------------------------------------------------------------
+def _host_staged(group, *tensors) -> bool:
+    """gloo moves host memory only: device tensors are staged through the CPU (used by the 2-rank
+    one-GPU test; the product runs on RCCL and never takes this path)"""
+    return dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
+
+
 def _all_gather_rows(x: torch.Tensor, group) -> torch.Tensor:
     world = dist.get_world_size(group)
+    if _host_staged(group, x):
+        return _all_gather_rows(x.cpu(), group).to(x.device)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     return out
+
+
+def _all_reduce_sum_(t: torch.Tensor, group) -> torch.Tensor:
+    if _host_staged(group, t):
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
 
 
 def _reduce_scatter_rows(full: torch.Tensor, group) -> torch.Tensor:
@@ -61,7 +79,7 @@ def _reduce_scatter_rows(full: torch.Tensor, group) -> torch.Tensor:
     out = torch.empty((n_local,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
     full = full.contiguous()
     if dist.get_backend(group) == "gloo":          # gloo has no reduce_scatter: all-reduce + slice
-        dist.all_reduce(full, group=group)
+        full = _all_reduce_sum_(full.clone(), group)
         r = dist.get_rank(group)
         out.copy_(full[r * n_local:(r + 1) * n_local])
     else:
@@ -84,6 +102,11 @@ class AllGatherRows(torch.autograd.Function):
 
 def _all_to_all_v(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group):
     """rows of `send` (split by destination rank) -> rows of `recv` (split by source rank)"""
+    if _host_staged(group, recv, send):
+        r_c = torch.empty(recv.shape, dtype=recv.dtype)
+        _all_to_all_v(r_c, send.cpu(), recv_splits, send_splits, group)
+        recv.copy_(r_c)
+        return
     if dist.get_backend(group) != "gloo":
         dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group)
         return
@@ -365,7 +388,7 @@ class DistAlternateGCN(AlternateGCN):
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, group=self.group)
+        _all_reduce_sum_(flat, self.group)
         off = 0
         for g in grads:
             n = g.numel()
@@ -389,7 +412,7 @@ def gather_logits(out_local: torch.Tensor, shard, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     counts = torch.zeros(world, dtype=torch.long, device=out_local.device)
     counts[shard.rank] = out_local.shape[0]
-    dist.all_reduce(counts, group=group)
+    _all_reduce_sum_(counts, group)
     mx = int(counts.max())
     buf = torch.zeros(mx, dtype=out_local.dtype, device=out_local.device)
     buf[: out_local.shape[0]] = out_local

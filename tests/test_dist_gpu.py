@@ -1,0 +1,71 @@
+"""Two ranks on ONE MI355X (the GPU box has a single card): the partitioned path with the real HIP kernels on
+every rank and a real process group.  RCCL refuses two ranks on one device, so the collectives run on gloo
+with device tensors staged through the host (pangnn_amd/dist.py `_host_staged`); everything else — shards,
+halo plans, HipOps on rectangular structures, fused loss pass, gradient all-reduce — is the code the 8-GPU
+run executes."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, init_file, exchange, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import copy_graph, whole_graph_from_golden
+    from oracle import gcn_oracle as go
+    import pangnn_amd
+    from pangnn_amd import dist as pdist
+    from pangnn_amd.train import make_optimizer, train_step
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    g = whole_graph_from_golden("cfg2_sim_1000x5")
+    gd = copy_graph(g, dev)
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 128))
+    single = pangnn_amd.AlternateGCN(dev, None, False, dims=[64, 128])
+    single.load_state_dict(oracle.state_dict())
+    model = pdist.DistAlternateGCN(dev, dims=[64, 128], exchange=exchange)
+    model.load_state_dict(oracle.state_dict())
+    shard = pdist.partition_graph(gd, rank, world)
+
+    full = pdist.gather_logits(model(shard).detach(), shard)
+    ref = oracle(g).detach()
+    assert torch.allclose(full.cpu(), ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(full, single(gd).detach(), atol=1e-5, rtol=1e-5)
+
+    opt_s, opt_d = make_optimizer(single), make_optimizer(model)
+    for step in range(3):
+        ls, _ = train_step(single, opt_s, gd, gd.y, pw.to(dev))
+        ld, _ = pdist.train_step(model, opt_d, shard, shard.y, pw.to(dev))
+        tot = ld.clone().cpu()
+        dist.all_reduce(tot)
+        assert abs(float(tot) - float(ls)) < 2e-5, (step, float(tot), float(ls))
+        for (k, p), (_, q) in zip(model.named_parameters(), single.named_parameters()):
+            if q.grad is None:
+                continue
+            scale = float(q.grad.abs().max()) + 1e-12
+            assert torch.allclose(p.grad, q.grad, atol=2e-4 * scale + 1e-8, rtol=1e-3), (step, k)
+    if exchange == "halo":
+        plan = model._plan(shard, "sim")
+        assert plan.n_halo > 0 and plan.n_table < shard.n_pad        # genuinely smaller than an all-gather
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_two_ranks_on_one_gpu_match_the_single_gpu_model(exchange):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, os.path.join(d, "rdzv"), exchange, d), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(d, "ok0")) and os.path.exists(os.path.join(d, "ok1"))
