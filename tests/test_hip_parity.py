@@ -645,3 +645,44 @@ def test_full_size_config4_invariants():
     for k, p in model.named_parameters():
         if p.grad is not None:
             assert close(p.grad, gu[k], atol=1e-4 * (float(gu[k].abs().max()) + 1e-12) + 1e-10, rtol=1e-3), k
+
+
+# ---------------------------------------------------------------- edge cases of the whole module
+def test_model_on_degenerate_graphs():
+    """no similarity edges at all; a single node; isolated nodes; E not a multiple of the 32-edge tile"""
+    import pangnn_amd
+    from types import SimpleNamespace
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 128))
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+    model.load_state_dict(oracle.state_dict())
+
+    def mk(n, ei, w, nb):
+        return SimpleNamespace(x=torch.ones(n, 1), edge_index=ei, edge_attr=w, neighbour_edge_index=nb)
+
+    empty = torch.zeros(2, 0, dtype=torch.long)
+    cases = [
+        mk(5, empty, torch.zeros(0), torch.tensor([[0, 1, 2], [1, 2, 3]])),                  # E_sim = 0
+        mk(1, empty, torch.zeros(0), torch.tensor([[0], [0]])),                              # one node, self loop
+        mk(7, torch.tensor([[0, 1, 2], [1, 2, 0]]), torch.tensor([3.0, 81.0, 1.0]), empty),  # no neighbour edges
+        mk(40, *random_graph(40, 33, seed=1)[:2], torch.tensor([[i for i in range(39)], [i + 1 for i in range(39)]])),
+    ]
+    for g in cases:
+        ref = oracle(g)
+        out = model(copy_graph(g, dev()))
+        assert out.shape == ref.shape
+        assert close(out, ref)
+
+
+def test_operator_argument_errors_are_loud():
+    import pangnn_amd
+    conv = pangnn_amd.GCNConv(64, 64).to(dev())
+    x = torch.randn(10, 64, device=dev())
+    with pytest.raises(ValueError):
+        conv(x, torch.tensor([[0, 1], [1, 2]], dtype=torch.int32, device=dev()))          # int32 edge_index
+    with pytest.raises(ValueError):
+        conv(x, torch.tensor([[0, 1], [1, 20]], device=dev()))                            # node id out of range
+    with pytest.raises(ValueError):
+        conv(x, torch.tensor([[0, 1], [1, 2]], device=dev()), torch.ones(5, device=dev()))  # weight length
+    with pytest.raises(NotImplementedError):
+        pangnn_amd.GCNConv(4, 4, add_self_loops=True)
