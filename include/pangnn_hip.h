@@ -90,13 +90,14 @@ int pangnn_permute_f32(const float* in, const int32_t* perm, float* out, int64_t
  * aggregation + bias, src/gnn.py:158,165):
  *   out[r, 0:F] (+)= bias[0:F] + sum_{e in [rowptr[r], rowptr[r+1])} val[e] * x[idx[e], 0:F]
  * val == NULL means 1.0; bias == NULL means none; accumulate != 0 adds into `out`.
+ * nnz = rowptr[n_rows] if known (a scheduling hint only: thin rows use a shallower unroll), else -1.
  * F in {16, 32, 64, 128, 256}; x/out/bias 16-byte aligned, ldx/ldo multiples of 4 floats.
  * No atomics: bitwise reproducible for a fixed structure.
  * ---------------------------------------------------------------------------------------- */
 int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, const float* val,
                         const float* x, int64_t ldx, int64_t n_src_rows,
                         const float* bias, float* out, int64_t ldo, int64_t n_rows,
-                        int32_t F, int accumulate, pangnn_stream_t stream);
+                        int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * edge decoder gather (k7; src/gnn.py:171-177):

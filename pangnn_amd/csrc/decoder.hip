@@ -141,10 +141,6 @@ __device__ __forceinline__ void gemm1(const float* Wl, const float* Ht, int lane
 
 constexpr int FWD_WAVES = 8;    // 512 threads, 1 workgroup / CU, 2 waves / SIMD (prefetch registers)
 constexpr int BWD_WAVES = 8;    // 512 threads, 1 workgroup / CU, 2 waves / SIMD
-#ifndef PANGNN_DECODER_STAGGER
-#define PANGNN_DECODER_STAGGER 1
-#endif
-constexpr bool STAGGER = PANGNN_DECODER_STAGGER != 0;
 
 // ---- software-pipelined gather: edge ids two tiles ahead, node rows one tile ahead, so a wave never
 // waits on HBM between two MFMA phases (the rows of tile t+1 land while tile t is in the matrix pipe).
@@ -206,7 +202,6 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a
   float* Ht = cvl + 64 + wave * (TE * RS);
   stage_weights(a, Wl, b2l, w3l, cvl, FWD_WAVES * 64);
   __syncthreads();
-  if (STAGGER && (wave >> 2)) __builtin_amdgcn_s_setprio(2);   // the two waves of a SIMD: distinct priority
   const float b3 = a.b3[0];
   const int hh = lane >> 5;
   const int64_t stride = (int64_t)gridDim.x * FWD_WAVES;
@@ -268,7 +263,6 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   float* gl = wl + 32;
   stage_weights(a, Wl, b2l, w3l, cvl, BWD_WAVES * 64);
   __syncthreads();
-  if (STAGGER && (wave >> 2)) __builtin_amdgcn_s_setprio(2);    // see decoder_fwd_kernel
   const int hh = lane >> 5, r = lane & 31;
 
   f32x16 acc3[2][2];   // gW2[j = jr(i,hh)+32bj][k = r+32bk]

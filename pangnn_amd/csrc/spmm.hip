@@ -151,7 +151,7 @@ using namespace pangnn;
 extern "C" int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, const float* val,
                                    const float* x, int64_t ldx, int64_t n_src_rows,
                                    const float* bias, float* out, int64_t ldo, int64_t n_rows,
-                                   int32_t F, int accumulate, pangnn_stream_t stream) {
+                                   int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream) {
   PG_CHECK_ARG(n_rows >= 0 && n_src_rows >= 0 && F > 0, PANGNN_E_BADARG,
                "pangnn_spmm_csr_f32: negative size (n_rows=%lld n_src_rows=%lld F=%d)",
                (long long)n_rows, (long long)n_src_rows, (int)F);
@@ -165,12 +165,19 @@ extern "C" int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, co
   hipStream_t s = (hipStream_t)stream;
   const bool vec_ok = aligned16(x) && aligned16(out) && (!bias || aligned16(bias)) &&
                       (ldx % 4 == 0) && (ldo % 4 == 0);
+  // Rows that average fewer entries than one unrolled step holds (the positional-neighbour graph has 3
+  // per row) gain nothing from keeping 4 gathers per lane in flight: U = 1 for them, U = 4 otherwise.
+  const bool thin = nnz >= 0 && nnz < 8 * n_rows;
   if (vec_ok) {
     switch (F) {
       case 16:  return launch_spmm<16, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       case 32:  return launch_spmm<32, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
-      case 64:  return launch_spmm<64, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
-      case 128: return launch_spmm<128, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+      case 64:
+        if (thin) return launch_spmm<64, 1>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+        return launch_spmm<64, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+      case 128:
+        if (thin) return launch_spmm<128, 1>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+        return launch_spmm<128, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       case 256: return launch_spmm<256, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       default: break;
     }
@@ -191,5 +198,5 @@ extern "C" int pangnn_segment_sum_rows_f32(const int64_t* rowptr, const int32_t*
                "pangnn_segment_sum_rows_f32: column window [%lld,%lld) outside ldm=%lld",
                (long long)col_off, (long long)(col_off + F), (long long)ldm);
   return pangnn_spmm_csr_f32(rowptr, perm, nullptr, m + col_off, ldm, n_m_rows, nullptr,
-                             out, ldo, n_rows, F, accumulate, stream);
+                             out, ldo, n_rows, n_m_rows, F, accumulate, stream);
 }

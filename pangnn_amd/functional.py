@@ -55,8 +55,8 @@ def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int
             ev0.record()
         _lib.check(lib.pangnn_spmm_csr_f32(csr.rowptr.data_ptr(), _lib.ptr(csr.other), _lib.ptr(val),
                                            x.data_ptr(), x.stride(0), x.shape[0], _lib.ptr(bias),
-                                           out.data_ptr(), out.stride(0), n_rows, f, int(accumulate),
-                                           _lib.stream_ptr()), "pangnn_spmm_csr_f32")
+                                           out.data_ptr(), out.stride(0), n_rows, int(csr.other.shape[0]), f,
+                                           int(accumulate), _lib.stream_ptr()), "pangnn_spmm_csr_f32")
         if timed:
             ev1.record()
             KERNEL_TIMER[tag].append((ev0, ev1))

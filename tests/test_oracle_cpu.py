@@ -178,13 +178,13 @@ def test_c_abi_argument_errors_without_gpu():
     """argument validation happens before any HIP call, so it is checkable on a CPU-only box"""
     from pangnn_amd import _lib
     lib = _lib.load()
-    rc = lib.pangnn_spmm_csr_f32(None, None, None, None, 64, 10, None, None, 64, 5, 64, 0, None)
+    rc = lib.pangnn_spmm_csr_f32(None, None, None, None, 64, 10, None, None, 64, 5, -1, 64, 0, None)
     assert rc == -1 and b"null pointer" in lib.pangnn_last_error()
     rc = lib.pangnn_csr_build(None, 5, 10, 4, 1, None, None, None, None, 0, None)
     assert rc == -1                                          # ld < E
     rc = lib.pangnn_csr_build(None, 2**31 + 5, 2**31 + 5, 4, 1, ctypes.c_void_p(16), None, None, None, 0, None)
     assert rc == -2                                          # E does not fit int32
-    assert lib.pangnn_spmm_csr_f32(None, None, None, None, 64, 10, None, None, 64, 0, 64, 0, None) == 0
+    assert lib.pangnn_spmm_csr_f32(None, None, None, None, 64, 10, None, None, 64, 0, -1, 64, 0, None) == 0
 
 
 def test_c_restatement_agrees_with_torch_restatement():
