@@ -89,7 +89,8 @@ int pangnn_permute_f32(const float* in, const int32_t* perm, float* out, int64_t
  * propagate (k5+k6, and k5^T for backward; MessagePassing.propagate + GCNConv.message + 'add'
  * aggregation + bias, src/gnn.py:158,165):
  *   out[r, 0:F] (+)= bias[0:F] + sum_{e in [rowptr[r], rowptr[r+1])} val[e] * x[idx[e], 0:F]
- * val == NULL means 1.0; bias == NULL means none; accumulate != 0 adds into `out`.
+ * val == NULL means 1.0; idx == NULL means the identity (row r sums x[rowptr[r] .. rowptr[r+1]));
+ * bias == NULL means none; accumulate != 0 adds into `out`.
  * nnz = rowptr[n_rows] if known (a scheduling hint only: thin rows use a shallower unroll), else -1.
  * F in {16, 32, 64, 128, 256}; x/out/bias 16-byte aligned, ldx/ldo multiples of 4 floats.
  * No atomics: bitwise reproducible for a fixed structure.
@@ -149,6 +150,10 @@ int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t
  *   target with pangnn_segment_sum_rows_f32), and the parameter gradients g_w2[D,D], g_b2[D],
  *   g_w3[D], g_b3[1], g_cvec[D] (nullable).  Reproducible: per-workgroup partial slabs in
  *   `workspace`, summed in a fixed order; no float atomics.
+ *   part_buf / part_off (both NULL, or both set when the edge list is sorted by source): the kernel also
+ *   sums the g_h1 rows of every (32-edge tile, source) run into part_buf[part, 0:D]; part_off[tile] is the
+ *   index of the tile's first part, i.e. the number of k < 32*tile with k % 32 == 0 or src_k != src_{k-1}.
+ *   g_p[s] is then the sum of the consecutive parts of source s (pangnn_spmm_csr_f32 with idx == NULL).
  * ---------------------------------------------------------------------------------------- */
 int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                const int64_t* edge_index, int64_t ld, int64_t num_edges,
@@ -161,8 +166,8 @@ int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const float* q, int6
                                const float* extra, const float* cvec, const float* w2, const float* b2,
                                const float* w3, const float* b3, int32_t D, const float* g_logits,
                                float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
-                               float* g_cvec, void* workspace, size_t workspace_bytes,
-                               pangnn_stream_t stream);
+                               float* g_cvec, float* part_buf, const int32_t* part_off, void* workspace,
+                               size_t workspace_bytes, pangnn_stream_t stream);
 
 /* Training form of the decoder: logits, BCEWithLogits(pos_weight) mean loss (denominator `denom`) AND every
  * gradient in ONE pass over the edges — the logits of a tile come out of the backward's recomputed first
@@ -174,8 +179,9 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
                                 const float* cvec, const float* w2, const float* b2, const float* w3,
                                 const float* b3, int32_t D, const float* y, const float* pos_weight,
                                 int64_t denom, float* logits, float* loss, float* g_h1, float* g_w2,
-                                float* g_b2, float* g_w3, float* g_b3, float* g_cvec, void* workspace,
-                                size_t workspace_bytes, pangnn_stream_t stream);
+                                float* g_b2, float* g_w3, float* g_b3, float* g_cvec, float* part_buf,
+                                const int32_t* part_off, void* workspace, size_t workspace_bytes,
+                                pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node-level dense layers with a short inner dimension, K (in) and M (out) in {64, 128}

@@ -43,9 +43,9 @@ SIGNATURES = {
                                              _p, _p]),
     "pangnn_decoder_mlp_bwd_workspace_bytes": (_sz, [_i64]),
     "pangnn_decoder_mlp_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
-                                             _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+                                             _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pangnn_decoder_mlp_loss_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
-                                              _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+                                              _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

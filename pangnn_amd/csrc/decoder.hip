@@ -76,9 +76,9 @@ __device__ __forceinline__ void stage_weights(const DecParams& a, float* Wl, flo
 
 // ---- gather the tile's 32 h1 rows into the wave's LDS image.  Returns w_e / validity per lane e.
 __device__ __forceinline__ void gather_tile(const DecParams& a, int64_t ebase, int lane, float* Ht,
-                                            const float* cvl, float& w_e) {
+                                            const float* cvl, float& w_e, int& id) {
   const int64_t e = ebase + (lane & 31);
-  int id = 0;
+  id = 0;
   w_e = 0.f;
   if (e < a.E) {
     id = (int)a.ei[(int64_t)(lane >> 5) * a.ld + e];     // lanes 0-31: source, 32-63: target
@@ -246,9 +246,19 @@ struct LossParams {
   const float* y; const float* pos_weight; float inv_denom; float* logits; 
 };
 
-template <bool FUSED_LOSS>
+// RUNSUM: when the caller's edge order is sorted by source (every edge list pangnn_amd/construct.py emits
+// is), the rows of dL/dh1 that belong to one source are consecutive, so their sum — dL/dP[source] — is
+// taken right here per (tile, source) run and written as one 256-byte "part" row; a short contiguous
+// segment sum over the parts replaces a 19 GB pass over dL/dh1.  part_off[tile] = index of the tile's first
+// part (precomputed with the structure); the number of parts a tile writes is fixed by the edge list, so
+// the layout is deterministic.
+struct RunSumParams {
+  float* part; const int32_t* part_off;
+};
+
+template <bool FUSED_LOSS, bool RUNSUM>
 __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
-    DecParams a, const float* __restrict__ g_logits, LossParams lp, float* __restrict__ g_h1,
+    DecParams a, const float* __restrict__ g_logits, LossParams lp, RunSumParams rs, float* __restrict__ g_h1,
     float* __restrict__ slabs, int64_t n_tiles) {
   constexpr int PER_WAVE = TE * RS + 64 * GS + 64;   // Ht | H2t | w_e | g_e
   __shared__ __attribute__((aligned(16))) float lds[64 * RS + 3 * 64 + BWD_WAVES * PER_WAVE];
@@ -284,7 +294,8 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
        tile += (int64_t)gridDim.x * BWD_WAVES) {
     const int64_t ebase = tile * TE;
     float w_e;
-    gather_tile(a, ebase, lane, Ht, cvl, w_e);
+    int id;
+    gather_tile(a, ebase, lane, Ht, cvl, w_e, id);
     float g_e = 0.f;
     float y_e = 0.f;
     const bool live = ebase + r < a.E;
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
           const float v = hval > 0.f ? acc2[bp][i] : 0.f;
           if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
           if (a.extra) gcv[bp] = fmaf(wl[e], v, gcv[bp]);
+          if (RUNSUM) acc2[bp][i] = v;
         }
     }
 
@@ -424,6 +436,46 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
       acc3[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, h1v, acc3[0][1], 0, 0, 0);
       acc3[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h0, acc3[1][0], 0, 0, 0);
       acc3[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h1v, acc3[1][1], 0, 0, 0);
+    }
+    if (RUNSUM) {
+      // close a part at the last edge of every source run of the tile
+      const int id_nxt = __shfl(id, (lane + 1) & 63);
+      const bool ok = lane < 32 && ebase + lane < a.E;
+      const bool ok_nxt = lane < 31 && ebase + lane + 1 < a.E;
+      const unsigned long long mask = __ballot(ok && (!ok_nxt || id != id_nxt));
+      const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask & 0xffffffffull));
+      int64_t pidx = rs.part_off[tile];
+      if ((m & (m - 1u)) == 0u) {
+        // one run covers the tile (the common case at degree >> 32): column sums straight from registers
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0 += acc2[0][i]; s1 += acc2[1][i]; }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (hh == 0) {
+          rs.part[pidx * DD + r] = s0;
+          rs.part[pidx * DD + 32 + r] = s1;
+        }
+      } else {
+        // several runs: dL/dh1 tile -> LDS (the h1 image is no longer needed); every lane owns one of the 64
+        // columns and walks the 32 rows
+        wave_lds_sync();
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Ht[swz(jr(i, hh), r + 32 * bp)] = acc2[bp][i];
+        wave_lds_sync();
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+          sum += Ht[swz(e, lane)];
+          if ((m >> e) & 1u) {
+            rs.part[pidx * DD + lane] = sum;
+            sum = 0.f;
+            ++pidx;
+          }
+        }
+      }
     }
     wave_lds_sync();   // next tile overwrites Ht / Gt / wl
   }
@@ -553,7 +605,7 @@ extern "C" size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges) {
 }
 
 static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, int32_t D, const float* g_logits,
-                      const LossParams* lp, float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
+                      const LossParams* lp, float* part_buf, const int32_t* part_off, float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
                       float* g_cvec, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s) {
   PG_CHECK_ARG(g_w2 && g_b2 && g_w3 && g_b3, PANGNN_E_BADARG, "%s: null gradient output", who);
   const int64_t num_edges = a.E;
@@ -568,14 +620,18 @@ static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, in
   if (num_edges == 0) {
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)grid * SLAB * sizeof(float), s);
     PG_CHECK_ARG(e == hipSuccess, (int)e, "%s: memset failed", who);
-  } else if (lp) {
-    hipLaunchKernelGGL((decoder_bwd_kernel<true>), dim3((unsigned)grid), dim3(BWD_WAVES * 64), 0, s, a, g_logits,
-                       *lp, g_h1, static_cast<float*>(workspace), n_tiles);
-    PG_CHECK_LAUNCH(who);
   } else {
-    LossParams none{nullptr, nullptr, 0.f, nullptr};
-    hipLaunchKernelGGL((decoder_bwd_kernel<false>), dim3((unsigned)grid), dim3(BWD_WAVES * 64), 0, s, a, g_logits,
-                       none, g_h1, static_cast<float*>(workspace), n_tiles);
+    PG_CHECK_ARG((part_buf == nullptr) == (part_off == nullptr), PANGNN_E_BADARG,
+                 "%s: part_buf and part_off go together", who);
+    const LossParams none{nullptr, nullptr, 0.f, nullptr};
+    const LossParams l = lp ? *lp : none;
+    const RunSumParams rs{part_buf, part_off};
+    const dim3 g((unsigned)grid), b(BWD_WAVES * 64);
+    float* ws = static_cast<float*>(workspace);
+    if (lp && part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<true, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+    else if (lp) hipLaunchKernelGGL((decoder_bwd_kernel<true, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+    else if (part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<false, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+    else hipLaunchKernelGGL((decoder_bwd_kernel<false, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     PG_CHECK_LAUNCH(who);
   }
   hipLaunchKernelGGL(decoder_reduce_kernel, dim3((4096 + 194 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
@@ -589,14 +645,15 @@ extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const flo
                                           const float* extra, const float* cvec, const float* w2,
                                           const float* b2, const float* w3, const float* b3, int32_t D,
                                           const float* g_logits, float* g_h1, float* g_w2, float* g_b2,
-                                          float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                          float* g_w3, float* g_b3, float* g_cvec, float* part_buf,
+                                          const int32_t* part_off, void* workspace,
                                           size_t workspace_bytes, pangnn_stream_t stream) {
   int rc = check_common("pangnn_decoder_mlp_bwd_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
                         cvec, w2, b2, w3, b3, D);
   if (rc) return rc;
   PG_CHECK_ARG(num_edges == 0 || g_logits, PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null g_logits");
   DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
-  return launch_bwd("pangnn_decoder_mlp_bwd_f32", a, num_nodes, D, g_logits, nullptr, g_h1, g_w2, g_b2, g_w3, g_b3,
+  return launch_bwd("pangnn_decoder_mlp_bwd_f32", a, num_nodes, D, g_logits, nullptr, part_buf, part_off, g_h1, g_w2, g_b2, g_w3, g_b3,
                     g_cvec, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -606,7 +663,8 @@ extern "C" int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const fl
                                            const float* w2, const float* b2, const float* w3, const float* b3,
                                            int32_t D, const float* y, const float* pos_weight, int64_t denom,
                                            float* logits, float* loss, float* g_h1, float* g_w2, float* g_b2,
-                                           float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                           float* g_w3, float* g_b3, float* g_cvec, float* part_buf,
+                                           const int32_t* part_off, void* workspace,
                                            size_t workspace_bytes, pangnn_stream_t stream) {
   int rc = check_common("pangnn_decoder_mlp_loss_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
                         cvec, w2, b2, w3, b3, D);
@@ -615,6 +673,6 @@ extern "C" int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const fl
                "pangnn_decoder_mlp_loss_f32: bad denom / null pointer");
   DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
   LossParams lp{y, pos_weight, 1.0f / (float)denom, logits};
-  return launch_bwd("pangnn_decoder_mlp_loss_f32", a, num_nodes, D, nullptr, &lp, g_h1, g_w2, g_b2, g_w3, g_b3,
+  return launch_bwd("pangnn_decoder_mlp_loss_f32", a, num_nodes, D, nullptr, &lp, part_buf, part_off, g_h1, g_w2, g_b2, g_w3, g_b3,
                     g_cvec, loss, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -242,6 +242,17 @@ def segment_sum(msg, st: EdgeStructure):
     return _SegmentSum.apply(msg, st)
 
 
+def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor) -> torch.Tensor:
+    """out[s] = sum of the consecutive part rows of source s (pangnn_spmm_csr_f32, idx = NULL)"""
+    lib = _lib.load()
+    with torch.cuda.device(part_buf.device):
+        _lib.check(lib.pangnn_spmm_csr_f32(plan.part_rowptr.data_ptr(), None, None, _lib.ptr(part_buf),
+                                           part_buf.stride(0), part_buf.shape[0], None, out.data_ptr(),
+                                           out.stride(0), n_rows, part_buf.shape[0], part_buf.shape[1], 0,
+                                           _lib.stream_ptr()), "pangnn_spmm_csr_f32(parts)")
+    return out
+
+
 def _rows_f32(t: torch.Tensor) -> torch.Tensor:
     """fp32 with unit column stride and a 16-byte friendly row stride; column windows of a wider
     row-major matrix pass through without a copy"""
@@ -299,6 +310,8 @@ class _DecoderMLP(torch.autograd.Function):
         g_w2 = torch.empty_like(w2)
         g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
         g_cv = None if cv is None else torch.empty_like(cv)
+        plan = st.runsum_plan()
+        parts = None if plan is None else torch.empty(plan.n_parts, d, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws_bytes = lib.pangnn_decoder_mlp_bwd_workspace_bytes(e)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -308,15 +321,24 @@ class _DecoderMLP(torch.autograd.Function):
                                                       _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
                                                       w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(g), _lib.ptr(g_h1),
                                                       g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(),
-                                                      g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(), ws_bytes,
+                                                      g_b3.data_ptr(), _lib.ptr(g_cv), _lib.ptr(parts),
+                                                      None if plan is None else plan.part_off.data_ptr(),
+                                                      ws.data_ptr(), ws_bytes,
                                                       _lib.stream_ptr()), "pangnn_decoder_mlp_bwd_f32")
             _timer_stop("dec.bwd", ev)
+
+        def by_source(out=None):
+            if plan is not None:
+                return _sum_parts(plan, parts, p.shape[0],
+                                  out if out is not None else torch.empty(p.shape[0], d, device=dev))
+            return segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0], out=out)
+
         if ctx.joint:
             g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
-            segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0], out=g_pq[:, :d])
+            by_source(g_pq[:, :d])
             segment_sum_rows(st.by_dst, g_h1, 0, d, p.shape[0], out=g_pq[:, d:])
             return g_pq, None, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None
-        gp = segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0]) if ctx.needs_input_grad[0] else None
+        gp = by_source() if ctx.needs_input_grad[0] else None
         gq = segment_sum_rows(st.by_dst, g_h1, 0, d, q.shape[0]) if ctx.needs_input_grad[1] else None
         return gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None
 
@@ -357,6 +379,8 @@ class _DecoderLoss(torch.autograd.Function):
         g_w2 = torch.empty_like(w2)
         g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
         g_cv = None if cv is None else torch.empty_like(cv)
+        plan = st.runsum_plan()
+        parts = None if plan is None else torch.empty(plan.n_parts, d, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws_bytes = lib.pangnn_decoder_mlp_bwd_workspace_bytes(e)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -366,15 +390,23 @@ class _DecoderLoss(torch.autograd.Function):
                 st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
                 w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(y), _lib.ptr(pw), int(denom), _lib.ptr(logits),
                 loss.data_ptr(), _lib.ptr(g_h1), g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(), g_b3.data_ptr(),
-                _lib.ptr(g_cv), ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "pangnn_decoder_mlp_loss_f32")
+                _lib.ptr(g_cv), _lib.ptr(parts), None if plan is None else plan.part_off.data_ptr(),
+                ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "pangnn_decoder_mlp_loss_f32")
             _timer_stop("dec.bwd", ev)
+
+        def by_source(out=None):
+            if plan is not None:       # per-run partial rows came out of the kernel: short contiguous sum
+                return _sum_parts(plan, parts, p.shape[0],
+                                  out if out is not None else torch.empty(p.shape[0], d, device=dev))
+            return segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0], out=out)
+
         if pq_joint:
             g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
-            segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0], out=g_pq[:, :d])
+            by_source(g_pq[:, :d])
             segment_sum_rows(st.by_dst, g_h1, 0, d, p.shape[0], out=g_pq[:, d:])
             gp, gq = g_pq, None
         else:
-            gp = segment_sum_rows(st.by_src, g_h1, 0, d, p.shape[0])
+            gp = by_source()
             gq = segment_sum_rows(st.by_dst, g_h1, 0, d, q.shape[0])
         del g_h1
         ctx.has_cv, ctx.has_q = g_cv is not None, gq is not None

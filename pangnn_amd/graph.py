@@ -73,6 +73,7 @@ class EdgeStructure:
         self._by_dst: Optional[CSR] = None
         self._by_src: Optional[CSR] = None
         self._norm: Dict[Tuple, "GcnNorm"] = {}
+        self._runsum = None
 
     @property
     def by_dst(self) -> CSR:
@@ -89,6 +90,27 @@ class EdgeStructure:
             nmax = max(self.num_nodes, self.num_src)
             self._by_src = build_csr(self.edge_index, nmax, 0, validate=False, num_rows=self.num_src)
         return self._by_src
+
+    def runsum_plan(self):
+        """If the caller's edge order is sorted by source: the layout of the per-(32-edge tile, source) partial
+        rows the decoder backward kernel can emit (include/pangnn_hip.h, `part_buf` / `part_off`), else None.
+          part_off[t]    index of tile t's first part
+          part_rowptr[s] parts of source s are [part_rowptr[s], part_rowptr[s+1])   (consecutive: sorted)"""
+        if self._runsum is None:
+            src, e = self.edge_index[0], self.num_edges
+            if e == 0 or not bool((src[1:] >= src[:-1]).all()):
+                self._runsum = False
+            else:
+                flags = (torch.arange(e, device=src.device) % 32) == 0
+                flags[1:] |= src[1:] != src[:-1]
+                part_id = torch.cumsum(flags, 0) - 1
+                n_parts = int(part_id[-1]) + 1
+                part_rowptr = torch.searchsorted(src[flags].contiguous(),
+                                                 torch.arange(self.num_src + 1, device=src.device))
+                from types import SimpleNamespace
+                self._runsum = SimpleNamespace(n_parts=n_parts, part_off=part_id[::32].to(torch.int32).contiguous(),
+                                               part_rowptr=part_rowptr.contiguous())
+        return self._runsum or None
 
     def gcn_norm(self, edge_weight: Optional[torch.Tensor], gather_dis=None) -> "GcnNorm":
         """norm for this edge_weight tensor (None = unit weights); cached on tensor identity.
