@@ -134,7 +134,9 @@ def _all_to_all_v(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_spli
 
 class HaloPlan:
     """Which owned rows every peer needs from this rank, and the local edge list re-indexed into the
-    compact table [owned rows | received halo rows].  Built once per (graph, partition)."""
+    compact table [halo rows of lower ranks | owned rows | halo rows of higher ranks].  Table order is
+    global-id order, so an edge list that was sorted by source stays sorted (the decoder's per-source
+    partial sums keep working on shards).  Built once per (graph, partition)."""
 
     def __init__(self, ei_local: torch.Tensor, lo: int, n_local: int, group=None, make_csr=None):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -161,7 +163,9 @@ class HaloPlan:
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < n_local)
         self.n_local, self.n_halo = n_local, int(need.numel())
         self.n_table = n_local + self.n_halo
-        new_src = torch.where(remote, n_local + torch.searchsorted(need, src), src - lo)
+        self.n_low = int((need < lo).sum())                       # halo rows owned by lower ranks
+        pos = torch.searchsorted(need, src)                       # rank of a remote source among the needed ids
+        new_src = torch.where(remote, torch.where(src < lo, pos, pos + n_local), src - lo + self.n_low)
         self.edge_index = torch.stack([new_src, ei_local[1]]).contiguous()
         self.group = group
         # fixed-order accumulation of returned halo gradients into the owner's rows
@@ -169,7 +173,8 @@ class HaloPlan:
 
 
 class HaloGather(torch.autograd.Function):
-    """[n_local, F] -> table [n_local + n_halo, F] (own rows, then the referenced rows of the peers)."""
+    """[n_local, F] -> table [n_low + n_local + n_high, F]: the referenced rows of lower ranks, the own rows,
+    the referenced rows of higher ranks."""
 
     @staticmethod
     def forward(ctx, x, plan: HaloPlan, accumulate_back):
@@ -178,16 +183,16 @@ class HaloGather(torch.autograd.Function):
         send = x.index_select(0, plan.send_idx)
         recv = torch.empty((plan.n_halo,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         _all_to_all_v(recv, send, plan.recv_splits, plan.send_splits, plan.group)
-        return torch.cat([x, recv], dim=0)
+        return torch.cat([recv[: plan.n_low], x, recv[plan.n_low:]], dim=0)    # global-id order
 
     @staticmethod
     def backward(ctx, g):
         plan = ctx.plan
         g = g.contiguous()
-        g_halo = g[plan.n_local:].contiguous()
+        g_halo = torch.cat([g[: plan.n_low], g[plan.n_low + plan.n_local:]], dim=0)
         back = torch.empty((plan.send_idx.numel(),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
         _all_to_all_v(back, g_halo, plan.send_splits, plan.recv_splits, plan.group)
-        g_local = g[: plan.n_local].clone()
+        g_local = g[plan.n_low: plan.n_low + plan.n_local].clone()
         if back.shape[0]:
             ctx.acc(g_local, back, plan)
         return g_local, None, None

@@ -59,6 +59,9 @@ def _worker(rank, world, init_file, exchange, out_dir):
     if exchange == "halo":
         plan = model._plan(shard, "sim")
         assert plan.n_halo > 0 and plan.n_table < shard.n_pad        # genuinely smaller than an all-gather
+        # table order = global id order: the source-sorted edge list stays sorted on the shard, so the
+        # decoder's per-source partial sums are used here too
+        assert model._st(shard, "sim").runsum_plan() is not None
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     dist.barrier()
     dist.destroy_process_group()
