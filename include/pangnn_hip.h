@@ -154,6 +154,10 @@ int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t
  *   sums the g_h1 rows of every (32-edge tile, source) run into part_buf[part, 0:D]; part_off[tile] is the
  *   index of the tile's first part, i.e. the number of k < 32*tile with k % 32 == 0 or src_k != src_{k-1}.
  *   g_p[s] is then the sum of the consecutive parts of source s (pangnn_spmm_csr_f32 with idx == NULL).
+ *   precision: 0 = every product on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains);
+ *              1 = the first two products on the bf16 matrix pipe with three-way operand splitting
+ *                  (hi + mid + lo = 24 mantissa bits, six partial products, fp32 accumulation): fp32-level
+ *                  error, but not bit-identical to mode 0.
  * ---------------------------------------------------------------------------------------- */
 int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                const int64_t* edge_index, int64_t ld, int64_t num_edges,
@@ -166,8 +170,8 @@ int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const float* q, int6
                                const float* extra, const float* cvec, const float* w2, const float* b2,
                                const float* w3, const float* b3, int32_t D, const float* g_logits,
                                float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
-                               float* g_cvec, float* part_buf, const int32_t* part_off, void* workspace,
-                               size_t workspace_bytes, pangnn_stream_t stream);
+                               float* g_cvec, float* part_buf, const int32_t* part_off, int32_t precision,
+                               void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
 
 /* Training form of the decoder: logits, BCEWithLogits(pos_weight) mean loss (denominator `denom`) AND every
  * gradient in ONE pass over the edges — the logits of a tile come out of the backward's recomputed first
@@ -180,8 +184,8 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
                                 const float* b3, int32_t D, const float* y, const float* pos_weight,
                                 int64_t denom, float* logits, float* loss, float* g_h1, float* g_w2,
                                 float* g_b2, float* g_w3, float* g_b3, float* g_cvec, float* part_buf,
-                                const int32_t* part_off, void* workspace, size_t workspace_bytes,
-                                pangnn_stream_t stream);
+                                const int32_t* part_off, int32_t precision, void* workspace,
+                                size_t workspace_bytes, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node-level dense layers with a short inner dimension, K (in) and M (out) in {64, 128}

@@ -43,9 +43,12 @@ SIGNATURES = {
                                              _p, _p]),
     "pangnn_decoder_mlp_bwd_workspace_bytes": (_sz, [_i64]),
     "pangnn_decoder_mlp_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
-                                             _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+                                             _p, _p, _p, _p, _p, _p, _p, _p, _p,      # g_logits .. part_off
+                                             _i32, _p, _sz, _p]),                     # precision, workspace, bytes, stream
     "pangnn_decoder_mlp_loss_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
-                                              _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+                                              _p, _p, _i64,                            # y, pos_weight, denom
+                                              _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,  # logits .. part_off
+                                              _i32, _p, _sz, _p]),
 }
 
 _lib = None

@@ -526,6 +526,381 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   for (int i = threadIdx.x; i < 4096 + 194; i += BWD_WAVES * 64) slab[i] = red[i];
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16x3 variant of the backward / training kernel.  v_mfma_f32_32x32x2_f32 executes on the FP32 vector
+// lanes, so in the kernel above matrix and vector instructions serialise.  Here the first two
+// products run on the real matrix pipe as v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three
+// bf16 terms (hi + mid + lo carries 24 mantissa bits; the six largest partial products are accumulated in
+// fp32, smallest first), which keeps fp32-level accuracy while the vector lanes do the splits, epilogues and
+// the third (f32) product.  One wave per SIMD (4 per workgroup) so that a wave owns 512 registers: the W2
+// fragments of the first product live in registers, the gather is software-pipelined.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Split3 { bf16x8 hi, mid, lo; };
+
+__device__ __forceinline__ Split3 split8(const float (&f)[8]) {
+  Split3 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)f[i];
+    const float r1 = f[i] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    s.hi[i] = h;
+    s.mid[i] = m;
+    s.lo[i] = (__bf16)(r1 - (float)m);
+  }
+  return s;
+}
+
+constexpr int X3_WAVES = 4;   // 256 threads, 1 workgroup / CU, 1 wave / SIMD
+constexpr int WTS = 72;       // bf16 row stride of the W2^T images: 144 B, conflict-free ds_read_b128 down rows
+
+template <bool FUSED_LOSS, bool RUNSUM>
+__global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
+    DecParams a, const float* __restrict__ g_logits, LossParams lp, RunSumParams rs, float* __restrict__ g_h1,
+    float* __restrict__ slabs, int64_t n_tiles) {
+  constexpr int PER_WAVE = TE * RS + 64 * GS + 64;   // Ht | H2t | w_e | g_e
+  constexpr int WT_FLOATS = 2 * 64 * WTS / 2;        // two bf16 images [64][WTS] of W2^T (hi, mid)
+  __shared__ __attribute__((aligned(16))) float lds[WT_FLOATS + 3 * 64 + X3_WAVES * PER_WAVE];
+  unsigned short* Wt = reinterpret_cast<unsigned short*>(lds);
+  float* b2l = lds + WT_FLOATS;
+  float* w3l = b2l + 64;
+  float* cvl = w3l + 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* Ht = cvl + 64 + wave * PER_WAVE;
+  float* Gt = Ht + TE * RS;
+  float* wl = Gt + 64 * GS;
+  float* gl = wl + 32;
+  const int hh = lane >> 5, r = lane & 31;
+  // W2^T images for the second product: row k, and inside a row the 64 j in the order the first product's
+  // accumulator hands them over: slot ((b*2+u)*2+half)*8 + jj  <->  j = 32b + (jj&3) + 8(2u + (jj>>2)) + 4 half
+  for (int i = threadIdx.x; i < 64 * 64; i += X3_WAVES * 64) {
+    const int j = i >> 6, kk = i & 63;
+    const float w = a.w2[i];
+    const __bf16 whi = (__bf16)w;
+    const __bf16 wmid = (__bf16)(w - (float)whi);
+    const int j5 = j & 31, t3 = j5 >> 3;
+    const int slot = ((((j >> 5) * 2 + (t3 >> 1)) * 2 + ((j5 >> 2) & 1)) * 8) + (j5 & 3) + 4 * (t3 & 1);
+    Wt[kk * WTS + slot] = __builtin_bit_cast(unsigned short, whi);
+    Wt[64 * WTS + kk * WTS + slot] = __builtin_bit_cast(unsigned short, wmid);
+  }
+  for (int i = threadIdx.x; i < 64; i += X3_WAVES * 64) {
+    b2l[i] = a.b2[i];
+    w3l[i] = a.w3[i];
+    cvl[i] = a.cvec ? a.cvec[i] : 0.f;
+  }
+  // W2 fragments of the first product stay in registers for the whole kernel (one wave per SIMD: 512 VGPRs):
+  // lane (j = r + 32b, half h) holds W2[j][16s + 8h .. + 7], split three ways
+  Split3 Wa[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 lo4 = reinterpret_cast<const float4*>(a.w2 + (r + 32 * b) * 64 + 16 * s4 + 8 * hh)[0];
+      const float4 hi4 = reinterpret_cast<const float4*>(a.w2 + (r + 32 * b) * 64 + 16 * s4 + 8 * hh)[1];
+      const float f[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      Wa[b][s4] = split8(f);
+    }
+  __syncthreads();
+
+  f32x16 acc3[2][2];   // gW2[j = jr(i,hh)+32bj][k = r+32bk]
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc3[x][0][i] = 0.f; acc3[x][1][i] = 0.f; }
+  }
+  const float w3j[2] = {w3l[r], w3l[r + 32]};
+  float gw3p[2] = {0.f, 0.f};   // lane (j = r+32bj, h): partial of gw3[j] over edges e = h mod 2
+  float gb2p[2] = {0.f, 0.f};   // same lanes: partial of gb2[j]
+  float gcv[2] = {0.f, 0.f};    // lane (k = r+32bp, hh): partial of gcvec[k]
+  float gb3p = 0.f;
+  float lossp = 0.f;            // FUSED_LOSS: lanes < 32, partial of the (already 1/denom-scaled) loss
+  const float b3v = a.b3[0];
+  const float pw = (FUSED_LOSS && lp.pos_weight) ? lp.pos_weight[0] : 1.f;
+
+  // software-pipelined gather: ids / labels of the next tile at the top of a tile, its node rows after the
+  // second product's epilogue (they land while the third product runs)
+  const int64_t stride = (int64_t)gridDim.x * X3_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * X3_WAVES + wave;
+  TileIds ids_cur = load_ids(a, tile, n_tiles, lane);
+  float aux_cur = 0.f;      // y_e (fused loss) or upstream dL/dlogit_e of this lane's edge
+  if (tile < n_tiles && tile * TE + r < a.E) aux_cur = FUSED_LOSS ? lp.y[tile * TE + r] : g_logits[tile * TE + r];
+  TileRows rw;
+  issue_rows(a, ids_cur, lane, rw);
+  for (; tile < n_tiles; tile += stride) {
+    const int64_t ebase = tile * TE;
+    commit_rows(a, rw, lane, cvl, Ht);
+    const float w_e = ids_cur.w_e;
+    const int id = ids_cur.id;
+    const TileIds ids_nxt = load_ids(a, tile + stride, n_tiles, lane);
+    float aux_nxt = 0.f;
+    if (tile + stride < n_tiles && (tile + stride) * TE + r < a.E)
+      aux_nxt = FUSED_LOSS ? lp.y[(tile + stride) * TE + r] : g_logits[(tile + stride) * TE + r];
+    float g_e = 0.f;
+    float y_e = 0.f;
+    const bool live = ebase + r < a.E;
+    if (FUSED_LOSS) {
+      y_e = aux_cur;
+      if (lane < 32) wl[lane] = w_e;
+    } else {
+      g_e = aux_cur;
+      if (lane < 32) { wl[lane] = w_e; gl[lane] = g_e; gb3p += g_e; }
+    }
+    wave_lds_sync();
+
+    // C[j][e] = sum_k W2[j][k] h1[e][k] on the bf16 matrix pipe, every operand split three ways
+    // (x = hi + mid + lo, 8 + 8 + 8 mantissa bits): the six products with the largest weights are kept,
+    // smallest first, so the result carries fp32-level error
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 lo4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh));
+      const float4 hi4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh + 1));
+      const float f[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      const Split3 hb = split8(f);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].lo, hb.hi, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].mid, hb.mid, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].hi, hb.lo, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].mid, hb.hi, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].hi, hb.mid, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].hi, hb.hi, acc[b], 0, 0, 0);
+      }
+    }
+
+    if (FUSED_LOSS) {
+      // h2 = relu(C + b2) in place; the tile's logits; then loss and dL/dlogit per edge
+      float part = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int j0 = 32 * b + 8 * qd + 4 * hh;
+          const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
+          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+          const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * qd + c;
+            const float h2 = fmaxf(acc[b][i] + bbv[c], 0.f);
+            acc[b][i] = h2;
+            part = fmaf(h2, wwv[c], part);
+            Gt[(j0 + c) * GS + r] = h2;
+          }
+        }
+      part += __shfl_xor(part, 32);
+      const float xv = part + b3v;
+      const float lw = 1.f + (pw - 1.f) * y_e;
+      const float t = expf(-fabsf(xv));
+      const float sig_neg = xv >= 0.f ? t / (1.f + t) : 1.f / (1.f + t);          // sigmoid(-x)
+      g_e = live ? ((1.f - y_e) - lw * sig_neg) * lp.inv_denom : 0.f;
+      if (lane < 32) {
+        gl[lane] = g_e;
+        gb3p += g_e;
+        if (live) {
+          lp.logits[ebase + r] = xv;
+          lossp += ((1.f - y_e) * xv + lw * (log1pf(t) + fmaxf(-xv, 0.f))) * lp.inv_denom;
+        }
+      }
+      // G[j][e] = g_e * w3[j] * [h2 > 0]  (A operand of the next product)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int j0 = 32 * b + 8 * qd + 4 * hh;
+          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * qd + c;
+            acc[b][i] = acc[b][i] > 0.f ? g_e * wwv[c] : 0.f;
+          }
+        }
+    } else {
+      // G[j][e] = g_e * w3[j] * [h2pre > 0]  (in place in acc; A operand of the next product);
+      // h2[j][e] goes to LDS: the weight-gradient product rebuilds G and g_e * h2 from it
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int j0 = 32 * b + 8 * qd + 4 * hh;
+          const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
+          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+          const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * qd + c;
+            const float pre = acc[b][i] + bbv[c];
+            const bool on = pre > 0.f;
+            acc[b][i] = on ? g_e * wwv[c] : 0.f;
+            Gt[(j0 + c) * GS + r] = on ? pre : 0.f;
+          }
+        }
+    }
+    wave_lds_sync();
+
+    // gH1[e][k] = sum_j G[j][e] W2[j][k]  : A = G from the accumulator registers, B = W2 rows
+    f32x16 acc2[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc2[0][i] = 0.f; acc2[1][i] = 0.f; }
+    // bf16 matrix pipe again: the A fragment of step (b, u) is the accumulator registers 8u .. 8u+7 of
+    // block b, split three ways in registers; B is the matching 8-j slice of row k of the W2^T images
+    // (two-way split: this product only feeds gradients)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float f[8] = {acc[b][8 * u + 0], acc[b][8 * u + 1], acc[b][8 * u + 2], acc[b][8 * u + 3],
+                            acc[b][8 * u + 4], acc[b][8 * u + 5], acc[b][8 * u + 6], acc[b][8 * u + 7]};
+        const Split3 ga = split8(f);
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) {
+          const unsigned short* row = Wt + (r + 32 * bp) * WTS + (((b * 2 + u) * 2 + hh) * 8);
+          const bf16x8 w_hi = *reinterpret_cast<const bf16x8*>(row);
+          const bf16x8 w_mid = *reinterpret_cast<const bf16x8*>(row + 64 * WTS);
+          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.lo, w_hi, acc2[bp], 0, 0, 0);
+          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.mid, w_mid, acc2[bp], 0, 0, 0);
+          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.hi, w_mid, acc2[bp], 0, 0, 0);
+          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.mid, w_hi, acc2[bp], 0, 0, 0);
+          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.hi, w_hi, acc2[bp], 0, 0, 0);
+        }
+      }
+    // mask by h1 > 0, write dL/dh1pre, accumulate gcvec.  Full tiles (all but the last) store through
+    // one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
+    {
+      float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
+      const bool full = ebase + TE <= a.E;
+#pragma unroll
+      for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int e = jr(i, hh);
+          const int k = r + 32 * bp;
+          const float hval = Ht[swz(e, k)];
+          const float v = hval > 0.f ? acc2[bp][i] : 0.f;
+          if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
+          if (a.extra) gcv[bp] = fmaf(wl[e], v, gcv[bp]);
+          if (RUNSUM) acc2[bp][i] = v;
+        }
+    }
+
+    if (tile + stride < n_tiles) issue_rows(a, ids_nxt, lane, rw);   // flies during the third product
+
+    // gW2[j][k] += sum_e G[j][e] h1[e][k]  : f32 MFMA, both operands from LDS, reduction over the tile's edges
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int e = 2 * s + hh;
+      const float ge = gl[e];
+      const float x0 = Gt[r * GS + e];           // h2[j][e]
+      const float x1 = Gt[(r + 32) * GS + e];
+      const float a0 = x0 > 0.f ? ge * w3j[0] : 0.f;
+      const float a1 = x1 > 0.f ? ge * w3j[1] : 0.f;
+      gw3p[0] = fmaf(ge, x0, gw3p[0]);
+      gw3p[1] = fmaf(ge, x1, gw3p[1]);
+      gb2p[0] += a0;
+      gb2p[1] += a1;
+      const float h0 = Ht[swz(e, r)];
+      const float h1v = Ht[swz(e, r + 32)];
+      acc3[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, h0, acc3[0][0], 0, 0, 0);
+      acc3[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, h1v, acc3[0][1], 0, 0, 0);
+      acc3[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h0, acc3[1][0], 0, 0, 0);
+      acc3[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h1v, acc3[1][1], 0, 0, 0);
+    }
+    if (RUNSUM) {
+      // close a part at the last edge of every source run of the tile
+      const int id_nxt = __shfl(id, (lane + 1) & 63);
+      const bool ok = lane < 32 && ebase + lane < a.E;
+      const bool ok_nxt = lane < 31 && ebase + lane + 1 < a.E;
+      const unsigned long long mask = __ballot(ok && (!ok_nxt || id != id_nxt));
+      const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask & 0xffffffffull));
+      int64_t pidx = rs.part_off[tile];
+      if ((m & (m - 1u)) == 0u) {
+        // one run covers the tile (the common case at degree >> 32): column sums straight from registers
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0 += acc2[0][i]; s1 += acc2[1][i]; }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (hh == 0) {
+          rs.part[pidx * DD + r] = s0;
+          rs.part[pidx * DD + 32 + r] = s1;
+        }
+      } else {
+        // several runs: dL/dh1 tile -> LDS (the h1 image is no longer needed); every lane owns one of the 64
+        // columns and walks the 32 rows
+        wave_lds_sync();
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Ht[swz(jr(i, hh), r + 32 * bp)] = acc2[bp][i];
+        wave_lds_sync();
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+          sum += Ht[swz(e, lane)];
+          if ((m >> e) & 1u) {
+            rs.part[pidx * DD + lane] = sum;
+            sum = 0.f;
+            ++pidx;
+          }
+        }
+      }
+    }
+    wave_lds_sync();   // next tile overwrites Ht / Gt / wl
+    ids_cur = ids_nxt;
+    aux_cur = aux_nxt;
+  }
+
+  // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
+  gw3p[0] += __shfl_xor(gw3p[0], 32);
+  gw3p[1] += __shfl_xor(gw3p[1], 32);
+  gb2p[0] += __shfl_xor(gb2p[0], 32);
+  gb2p[1] += __shfl_xor(gb2p[1], 32);
+  gcv[0] += __shfl_xor(gcv[0], 32);
+  gcv[1] += __shfl_xor(gcv[1], 32);
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {
+    gb3p += __shfl_xor(gb3p, off);
+    lossp += __shfl_xor(lossp, off);
+  }
+
+  __syncthreads();
+  float* red = cvl + 64;   // reuse the tile area: SLAB floats
+  for (int w = 0; w < X3_WAVES; ++w) {
+    if (wave == w) {
+      const bool first = (w == 0);
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int idx = (32 * bj + jr(i, hh)) * 64 + r + 32 * bk;
+            red[idx] = (first ? 0.f : red[idx]) + acc3[bj][bk][i];
+          }
+      if (hh == 0) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          red[4096 + r + 32 * x] = (first ? 0.f : red[4096 + r + 32 * x]) + gb2p[x];
+          red[4096 + 64 + r + 32 * x] = (first ? 0.f : red[4096 + 64 + r + 32 * x]) + gw3p[x];
+          red[4096 + 128 + r + 32 * x] = (first ? 0.f : red[4096 + 128 + r + 32 * x]) + gcv[x];
+        }
+      }
+      if (lane == 0) {
+        red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
+        red[4096 + 193] = (first ? 0.f : red[4096 + 193]) + lossp;
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * SLAB;
+  for (int i = threadIdx.x; i < 4096 + 194; i += X3_WAVES * 64) slab[i] = red[i];
+}
+
 // out[i] = sum over workgroup slabs in index order (fixed => reproducible)
 __global__ __launch_bounds__(kBlock) void decoder_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
                                                                 float* __restrict__ g_w2,
@@ -605,12 +980,14 @@ extern "C" size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges) {
 }
 
 static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, int32_t D, const float* g_logits,
-                      const LossParams* lp, float* part_buf, const int32_t* part_off, float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
+                      const LossParams* lp, int precision, float* part_buf, const int32_t* part_off, float* g_h1, float* g_w2, float* g_b2, float* g_w3, float* g_b3,
                       float* g_cvec, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s) {
   PG_CHECK_ARG(g_w2 && g_b2 && g_w3 && g_b3, PANGNN_E_BADARG, "%s: null gradient output", who);
   const int64_t num_edges = a.E;
+  PG_CHECK_ARG(precision == 0 || precision == 1, PANGNN_E_BADARG, "%s: precision must be 0 (f32 MFMA) or 1 (bf16x3)", who);
+  const int waves = precision ? X3_WAVES : BWD_WAVES;
   const int64_t n_tiles = (num_edges + TE - 1) / TE;
-  int64_t grid = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
+  int64_t grid = (n_tiles + waves - 1) / waves;
   const int cus = grid_cus();
   if (grid > cus) grid = cus;
   if (grid < 1) grid = 1;
@@ -626,9 +1003,14 @@ static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, in
     const LossParams none{nullptr, nullptr, 0.f, nullptr};
     const LossParams l = lp ? *lp : none;
     const RunSumParams rs{part_buf, part_off};
-    const dim3 g((unsigned)grid), b(BWD_WAVES * 64);
+    const dim3 g((unsigned)grid), b(waves * 64);
     float* ws = static_cast<float*>(workspace);
-    if (lp && part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<true, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+    if (precision) {
+      if (lp && part_buf) hipLaunchKernelGGL((decoder_bwd_x3_kernel<true, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+      else if (lp) hipLaunchKernelGGL((decoder_bwd_x3_kernel<true, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+      else if (part_buf) hipLaunchKernelGGL((decoder_bwd_x3_kernel<false, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+      else hipLaunchKernelGGL((decoder_bwd_x3_kernel<false, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+    } else if (lp && part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<true, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     else if (lp) hipLaunchKernelGGL((decoder_bwd_kernel<true, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     else if (part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<false, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     else hipLaunchKernelGGL((decoder_bwd_kernel<false, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
@@ -646,14 +1028,14 @@ extern "C" int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const flo
                                           const float* b2, const float* w3, const float* b3, int32_t D,
                                           const float* g_logits, float* g_h1, float* g_w2, float* g_b2,
                                           float* g_w3, float* g_b3, float* g_cvec, float* part_buf,
-                                          const int32_t* part_off, void* workspace,
+                                          const int32_t* part_off, int32_t precision, void* workspace,
                                           size_t workspace_bytes, pangnn_stream_t stream) {
   int rc = check_common("pangnn_decoder_mlp_bwd_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
                         cvec, w2, b2, w3, b3, D);
   if (rc) return rc;
   PG_CHECK_ARG(num_edges == 0 || g_logits, PANGNN_E_BADARG, "pangnn_decoder_mlp_bwd_f32: null g_logits");
   DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
-  return launch_bwd("pangnn_decoder_mlp_bwd_f32", a, num_nodes, D, g_logits, nullptr, part_buf, part_off, g_h1, g_w2, g_b2, g_w3, g_b3,
+  return launch_bwd("pangnn_decoder_mlp_bwd_f32", a, num_nodes, D, g_logits, nullptr, precision, part_buf, part_off, g_h1, g_w2, g_b2, g_w3, g_b3,
                     g_cvec, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -664,7 +1046,7 @@ extern "C" int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const fl
                                            int32_t D, const float* y, const float* pos_weight, int64_t denom,
                                            float* logits, float* loss, float* g_h1, float* g_w2, float* g_b2,
                                            float* g_w3, float* g_b3, float* g_cvec, float* part_buf,
-                                           const int32_t* part_off, void* workspace,
+                                           const int32_t* part_off, int32_t precision, void* workspace,
                                            size_t workspace_bytes, pangnn_stream_t stream) {
   int rc = check_common("pangnn_decoder_mlp_loss_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
                         cvec, w2, b2, w3, b3, D);
@@ -673,6 +1055,6 @@ extern "C" int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const fl
                "pangnn_decoder_mlp_loss_f32: bad denom / null pointer");
   DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
   LossParams lp{y, pos_weight, 1.0f / (float)denom, logits};
-  return launch_bwd("pangnn_decoder_mlp_loss_f32", a, num_nodes, D, nullptr, &lp, part_buf, part_off, g_h1, g_w2, g_b2, g_w3, g_b3,
+  return launch_bwd("pangnn_decoder_mlp_loss_f32", a, num_nodes, D, nullptr, &lp, precision, part_buf, part_off, g_h1, g_w2, g_b2, g_w3, g_b3,
                     g_cvec, loss, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -21,6 +21,10 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 # stream, the one passed to the C ABI) around the launch.
 KERNEL_TIMER = None
 
+# Matrix-pipe mode of the decoder backward / training kernel (include/pangnn_hip.h, `precision`):
+# 0 = f32 MFMA everywhere, 1 = bf16 MFMA with three-way split operands for the first two products.
+DECODER_PRECISION = 0
+
 
 def _timer_start(tag):
     if KERNEL_TIMER is None or tag not in KERNEL_TIMER:
@@ -323,7 +327,7 @@ class _DecoderMLP(torch.autograd.Function):
                                                       g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(),
                                                       g_b3.data_ptr(), _lib.ptr(g_cv), _lib.ptr(parts),
                                                       None if plan is None else plan.part_off.data_ptr(),
-                                                      ws.data_ptr(), ws_bytes,
+                                                      DECODER_PRECISION, ws.data_ptr(), ws_bytes,
                                                       _lib.stream_ptr()), "pangnn_decoder_mlp_bwd_f32")
             _timer_stop("dec.bwd", ev)
 
@@ -391,7 +395,7 @@ class _DecoderLoss(torch.autograd.Function):
                 w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(y), _lib.ptr(pw), int(denom), _lib.ptr(logits),
                 loss.data_ptr(), _lib.ptr(g_h1), g_w2.data_ptr(), g_b2.data_ptr(), g_w3.data_ptr(), g_b3.data_ptr(),
                 _lib.ptr(g_cv), _lib.ptr(parts), None if plan is None else plan.part_off.data_ptr(),
-                ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "pangnn_decoder_mlp_loss_f32")
+                DECODER_PRECISION, ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "pangnn_decoder_mlp_loss_f32")
             _timer_stop("dec.bwd", ev)
 
         def by_source(out=None):

@@ -722,3 +722,80 @@ def test_decoder_run_sums_for_source_sorted_edges(e):
     ref = torch.relu(torch.relu(lv[0][ei[0]] + lv[1][ei[1]]) @ lv[2].t() + lv[3]) @ lv[4] + lv[5]
     torch.nn.functional.binary_cross_entropy_with_logits(ref, y, pos_weight=pw).backward()
     assert close(res[0][1][0], lv[0].grad, atol=1e-4 * (float(lv[0].grad.abs().max()) + 1e-12) + 1e-8, rtol=1e-3)
+
+
+# ---------------------------------------------------------------- bf16x3 matrix-pipe mode of the decoder backward
+class _precision:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from pangnn_amd import functional as PF
+        self.old, PF.DECODER_PRECISION = PF.DECODER_PRECISION, self.mode
+
+    def __exit__(self, *a):
+        from pangnn_amd import functional as PF
+        PF.DECODER_PRECISION = self.old
+
+
+@pytest.mark.parametrize("e", [1, 33, 1000, 70001])
+@pytest.mark.parametrize("skip", [False, True])
+def test_bf16x3_decoder_backward_vs_fp64(e, skip):
+    """precision = 1 (three-way bf16 split on the matrix pipe) must stay at fp32-level error: checked against
+    an fp64 torch evaluation with the same bounds as the f32-MFMA kernel"""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    torch.manual_seed(e + skip)
+    n, d = 97, 64
+    ei, w = random_graph(n, e, seed=e, isolated=0.0)
+    ei = ei[:, torch.argsort(ei[0] * n + ei[1])] if e % 2 else ei          # both the run-sum and generic paths
+    P, Q = torch.randn(n, d), torch.randn(n, d)
+    W2, b2, w3, b3, cv = torch.randn(d, d) / 8, torch.randn(d), torch.randn(d), torch.randn(1), torch.randn(d)
+    extra = (w / 40) if skip else None
+    y = (torch.rand(e) < 0.3).float()
+    pw = torch.tensor(2.5)
+    lv = [t.clone().double().requires_grad_(True) for t in (P, Q, W2, b2, w3, b3, cv)]
+    h1 = lv[0][ei[0]] + lv[1][ei[1]]
+    if skip:
+        h1 = h1 + extra.double().unsqueeze(1) * lv[6]
+    ref = torch.relu(torch.relu(h1) @ lv[2].t() + lv[3]) @ lv[4] + lv[5]
+    lref = torch.nn.functional.binary_cross_entropy_with_logits(ref, y.double(), pos_weight=pw.double())
+    lref.backward()
+    st = EdgeStructure(ei.to(dev()), n)
+    with _precision(1):
+        gl = [t.clone().to(dev()).requires_grad_(True) for t in (P, Q, W2, b2, w3, b3, cv)]
+        loss, logits = PF.decoder_loss(gl[0], gl[1], st, extra.to(dev()) if skip else None, gl[6] if skip else None,
+                                       gl[2], gl[3], gl[4], gl[5], y.to(dev()), pw.to(dev()), e)
+        loss.backward()
+        # the non-fused backward entry point in the same mode
+        gl2 = [t.clone().to(dev()).requires_grad_(True) for t in (P, Q, W2, b2, w3, b3, cv)]
+        out2 = PF.decoder_mlp(gl2[0], gl2[1], st, extra.to(dev()) if skip else None, gl2[6] if skip else None,
+                              gl2[2], gl2[3], gl2[4], gl2[5])
+        torch.nn.functional.binary_cross_entropy_with_logits(out2, y.to(dev()), pos_weight=pw.to(dev())).backward()
+    assert close(logits, ref, atol=2e-5, rtol=2e-5)                    # tighter than the 1e-4 gate
+    assert close(loss, lref, atol=1e-6, rtol=1e-5)
+    for i, name in enumerate(["P", "Q", "W2", "b2", "w3", "b3", "cvec"]):
+        if name == "cvec" and not skip:
+            continue
+        rg = lv[i].grad
+        scale = float(rg.abs().max()) + 1e-12
+        assert close(gl[i].grad, rg, atol=1e-4 * scale + 1e-9, rtol=1e-3), name
+        assert close(gl2[i].grad, rg, atol=1e-4 * scale + 1e-9, rtol=1e-3), name
+
+
+def test_bf16x3_mode_whole_model_and_f32_mode_agree():
+    g, gd, oracle, model = _pair("cfg3_5genomes", (64, 128), dict())
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    res = {}
+    for mode in (0, 1):
+        with _precision(mode):
+            model.zero_grad()
+            loss, logits = model.loss_and_logits(gd, gd.y, pw.to(dev()))
+            loss.backward()
+            res[mode] = (loss.detach(), logits, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert close(res[1][1], oracle(g))                                  # the 1e-4 logit gate
+    assert close(res[1][1], res[0][1], atol=1e-5, rtol=1e-5)
+    assert close(res[1][0], res[0][0], atol=1e-6, rtol=1e-6)
+    for k, gk in res[0][2].items():
+        scale = float(gk.abs().max()) + 1e-12
+        assert close(res[1][2][k], gk, atol=1e-4 * scale + 1e-9, rtol=1e-3), k
