@@ -34,8 +34,6 @@ constructs anything but `HipOps`.
 from __future__ import annotations
 
 from types import SimpleNamespace
-from typing import Optional
-
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -264,9 +262,6 @@ class HipOps:
     def decoder_loss(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
         return PF.decoder_loss(p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
 
-    def pair_rows(self, z_full, z_local, st):
-        """(z[src], z[dst]) per owned edge for the cosine / dot decoders"""
-        raise NotImplementedError("cosine / dot decoders are single-GPU only")
 
 
 class DistAlternateGCN(AlternateGCN):
@@ -279,7 +274,6 @@ class DistAlternateGCN(AlternateGCN):
         if exchange not in ("halo", "allgather"):
             raise ValueError("exchange must be 'halo' or 'allgather'")
         self.exchange = exchange
-        self._structs = {}
         if self.flags.decoder != "mlp":
             raise NotImplementedError("partitioned mode implements the mlp decoder")
         if dims[0] != 64 and isinstance(self.ops, HipOps):

@@ -10,7 +10,6 @@ GPU (stable radix sort => deterministic per-row order) and memoises the GCN norm
 """
 from __future__ import annotations
 
-import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 

@@ -5,8 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (copy_graph, load_golden, random_graph, sub_graphs_from_golden,
-                      whole_graph_from_golden)
+from conftest import copy_graph, random_graph, sub_graphs_from_golden, whole_graph_from_golden
 from oracle import gcn_oracle as go
 
 pytestmark = pytest.mark.gpu

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, load_golden, sub_graphs_from_golden, whole_graph_from_golden, random_graph
+from conftest import ROOT, load_golden, sub_graphs_from_golden, random_graph
 from oracle import construct_oracle as co
 from oracle import gcn_oracle as go
 
