@@ -238,7 +238,7 @@ def main():
                          "achieved": b_alg / t_k / 1e9 if t_k > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": (b_alg / t_k) / HBM_PEAK if t_k > 0 else None, "traffic": traffic,
                          "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_k * 1e3,
-                         "bwd_avg_launch_ms": (sum(k_bwd) / max(len(k_bwd), 1)) * 1e3},
+                         "bwd_avg_launch_ms": (sum(k_bwd) / len(k_bwd)) * 1e3 if k_bwd else None},
         }
         if d_bwd:
             # the decoder kernel is bound by the f32 matrix pipe, not by HBM: report it against the dense

@@ -204,6 +204,17 @@ int    pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int6
                                size_t workspace_bytes, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * out[0, c] = sum_n r[n] g[n, c], out[1, c] = sum_n s[n] g[n, c]  (out [2, F], F divides 256).
+ * Backward of the scalar-feature embedding feeding the first GCN layer (src/gnn.py:97,125,158): the layer's
+ * input is h0 = x w^T + 1 b^T, so dL/dw = (A_hat x)^T g and dL/db = (A_hat 1)^T g with g = dL/d(A_hat h0);
+ * r = A_hat x and s = A_hat 1 are node vectors computed once per graph.  Reproducible two-stage sum.
+ * ---------------------------------------------------------------------------------------- */
+size_t pangnn_weighted_colsum_workspace_bytes(int32_t F);
+int    pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const float* r, const float* s, int64_t n,
+                                  int32_t F, float* out, void* workspace, size_t workspace_bytes,
+                                  pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * BCEWithLogitsLoss(pos_weight), mean reduction (pangnn.py:98,203), loss and dL/dlogits in one pass:
  *   loss[0]     = 1/denom * sum_i (1-y_i) x_i + (1 + (pw-1) y_i) softplus(-x_i)
  *   g_logits[i] = 1/denom * ((1-y_i) - (1 + (pw-1) y_i) sigmoid(-x_i))

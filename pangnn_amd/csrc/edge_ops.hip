@@ -202,6 +202,43 @@ __global__ void bce_finish_kernel(const float* __restrict__ partial, int n, floa
   }
 }
 
+// out[0, c] = sum_n r[n] g[n, c],  out[1, c] = sum_n s[n] g[n, c]   (c < F <= 256, F | 256).
+// Parameter gradients of the scalar-feature embedding that feeds the first GCN layer (src/gnn.py:97,125,158):
+// with h0 = x w^T + 1 b^T one has dL/dw = (A_hat x)^T g and dL/db = (A_hat 1)^T g, so no transposed propagate
+// is needed for a layer whose input carries no other gradient.  Two-stage fixed-order sum.
+constexpr int kColsumBlocks = 512;
+__global__ __launch_bounds__(kBlock) void weighted_colsum_kernel(const float* __restrict__ g, int64_t ldg,
+                                                                 const float* __restrict__ r,
+                                                                 const float* __restrict__ sv, int64_t n, int F,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[2][kBlock];
+  const int c = threadIdx.x % F, rg = threadIdx.x / F, groups = kBlock / F;
+  float a0 = 0.f, a1 = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * groups + rg; row < n; row += (int64_t)gridDim.x * groups) {
+    const float v = g[row * ldg + c];
+    a0 = fmaf(r[row], v, a0);
+    a1 = fmaf(sv[row], v, a1);
+  }
+  red[0][threadIdx.x] = a0;
+  red[1][threadIdx.x] = a1;
+  __syncthreads();
+  if (threadIdx.x < F) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < groups; ++k) { t0 += red[0][k * F + threadIdx.x]; t1 += red[1][k * F + threadIdx.x]; }
+    partial[((int64_t)blockIdx.x * 2 + 0) * F + threadIdx.x] = t0;
+    partial[((int64_t)blockIdx.x * 2 + 1) * F + threadIdx.x] = t1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int F,
+                                                               float* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= 2 * F) return;
+  float t = 0.f;
+  for (int b = 0; b < nblocks; ++b) t += partial[(int64_t)b * 2 * F + i];
+  out[i] = t;
+}
+
 static inline unsigned grid_for(int64_t total) {
   int64_t b = (total + kBlock - 1) / kBlock;
   const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
@@ -377,5 +414,31 @@ extern "C" int pangnn_bce_logits_f32(const float* logits, const float* y, const 
   hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, s, static_cast<const float*>(workspace), blocks,
                      loss);
   PG_CHECK_LAUNCH("pangnn_bce_logits_f32(finish)");
+  return 0;
+}
+
+extern "C" size_t pangnn_weighted_colsum_workspace_bytes(int32_t F) {
+  return (size_t)kColsumBlocks * 2 * (size_t)(F > 0 ? F : 1) * sizeof(float);
+}
+
+extern "C" int pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const float* r, const float* s, int64_t n,
+                                          int32_t F, float* out, void* workspace, size_t workspace_bytes,
+                                          pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0 && F > 0 && F <= kBlock && kBlock % F == 0 && ldg >= F, PANGNN_E_BADARG,
+               "pangnn_weighted_colsum_f32: F must divide 256 (got %d)", (int)F);
+  PG_CHECK_ARG(out && workspace && workspace_bytes >= (size_t)kColsumBlocks * 2 * F * sizeof(float) &&
+                   (n == 0 || (g && r && s)),
+               PANGNN_E_BADARG, "pangnn_weighted_colsum_f32: null pointer / workspace");
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = kBlock / F;
+  int blocks = (int)((n + groups - 1) / groups);
+  if (blocks > kColsumBlocks) blocks = kColsumBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(weighted_colsum_kernel, dim3(blocks), dim3(kBlock), 0, st, g, ldg, r, s, n, (int)F,
+                     static_cast<float*>(workspace));
+  PG_CHECK_LAUNCH("pangnn_weighted_colsum_f32");
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * F + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                     static_cast<const float*>(workspace), blocks, (int)F, out);
+  PG_CHECK_LAUNCH("pangnn_weighted_colsum_f32(finish)");
   return 0;
 }

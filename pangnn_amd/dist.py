@@ -243,6 +243,9 @@ class HipOps:
     def propagate(self, x_full, bias, st, norm, tag=None):
         return PF.propagate(x_full, bias, st, norm, tag)
 
+    def embed_propagate(self, x_tab, w, b, st, norm, tag=None):
+        return PF.embed_propagate(x_tab, w, b, st, norm, tag)
+
     def decoder(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3):
         return PF.decoder_mlp(p_full, q_local, st, extra, cvec, w2, b2, w3, b3)
 
@@ -330,20 +333,35 @@ class DistAlternateGCN(AlternateGCN):
         xw_full = self._table(xw, shard, name)
         return self.ops.propagate(xw_full, conv.bias, st, norm, tag)
 
+    def _embed_conv_in(self, shard, name, weight):
+        """conv_in(embedding(x)): x is constant, so the scalar features of the halo rows are exchanged once
+        (cached on the shard) and the first layer runs without any per-step exchange, forward or backward."""
+        conv = self.conv_in
+        if conv.in_channels < conv.out_channels and self.fuse_embedding and hasattr(self.ops, "embed_propagate"):
+            cache = shard.__dict__.setdefault("_dist_xtab", {})
+            key = (name, self.exchange)
+            if key not in cache:
+                with torch.no_grad():
+                    cache[key] = self._table(shard.x.float().view(-1, 1), shard, name).view(-1).contiguous()
+            st, norm = self._st(shard, name), self._norm(shard, name, weight, "w")
+            agg = self.ops.embed_propagate(cache[key], self.embedding.weight, self.embedding.bias, st, norm, name)
+            return self._linear(agg, conv.lin.weight, conv.bias)
+        h = shard.x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
+        return self._conv(conv, h, shard, name, weight, "w", name)
+
     def encode(self, shard):
         fl, act = self.flags, self.activation_fct
-        h = shard.x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
         if fl.union_edge_weights:
             w = shard.union_edge_attr
-            h = act(self._conv(self.conv_in, h, shard, "union", w, "w", "union"))
+            h = act(self._embed_conv_in(shard, "union", w))
             for _ in range(max(fl.neighbours - 2, 1)):
                 h = act(self._conv(self.conv_hidden, h, shard, "union", w, "w", "union"))
             h = act(self._conv(self.conv_out, h, shard, "union", None, "1", "union"))
         elif fl.base_model:
-            h = act(self._conv(self.conv_in, h, shard, "sim", shard.edge_attr, "w", "sim"))
+            h = act(self._embed_conv_in(shard, "sim", shard.edge_attr))
             h = act(self._linear(h, self.linear_out.weight, self.linear_out.bias))
         else:
-            h = act(self._conv(self.conv_in, h, shard, "sim", shard.edge_attr, "w", "sim"))
+            h = act(self._embed_conv_in(shard, "sim", shard.edge_attr))
             h = act(self._conv(self.conv_out, h, shard, "nb", None, "1", "nb"))
         return h
 

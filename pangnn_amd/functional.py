@@ -521,3 +521,52 @@ class _BCEWithLogits(torch.autograd.Function):
 
 def bce_with_logits(logits, y, pos_weight=None, denom=None):
     return _BCEWithLogits.apply(logits, y, pos_weight, logits.shape[0] if denom is None else denom)
+
+
+class _EmbedPropagate(torch.autograd.Function):
+    """agg = A_hat (x w^T + 1 b^T): the scalar-feature embedding (nn.Linear(1, D), gnn.py:97) followed by the
+    first GCN layer's propagate (gnn.py:158; GCNConv with in < out propagates before its dense layer).
+    `x_tab` [n_src] holds the scalar feature of every row the edges read (on a partitioned graph: own + halo
+    rows, exchanged once since x never changes — this layer then needs no per-step exchange at all).
+    Forward runs the real propagate kernel on h0.  Backward needs only the two parameter gradients, which by
+    linearity are (A_hat x)^T g and (A_hat 1)^T g; the transposed propagate is skipped exactly as autograd
+    skips gradients of inputs that require none.  A_hat x and A_hat 1 are cached on the norm object."""
+
+    @staticmethod
+    def forward(ctx, x_tab, w, b, st, norm, tag):
+        _lib.require_device(x_tab, w, b)
+        xv = x_tab.detach().to(torch.float32).reshape(-1)
+        h0 = torch.addcmul(b.detach().reshape(1, -1), xv.unsqueeze(1), w.detach().reshape(1, -1))
+        agg = spmm_csr(st.by_dst, norm.by_dst, h0, st.num_nodes, tag=None if tag is None else tag + ".fwd")
+        cache = norm.__dict__.setdefault("_node_actions", {})
+        key = (x_tab.data_ptr(), x_tab._version, tuple(x_tab.shape))
+        if key not in cache:
+            x16 = torch.zeros(xv.shape[0], 16, dtype=torch.float32, device=xv.device)
+            x16[:, 0] = xv
+            x16[:, 1] = 1.0
+            rs = spmm_csr(st.by_dst, norm.by_dst, x16, st.num_nodes)
+            cache.clear()
+            cache[key] = (rs[:, 0].contiguous(), rs[:, 1].contiguous(), x_tab)   # x_tab kept alive: key is its address
+        r, s, _ = cache[key]
+        ctx.save_for_backward(r, s)
+        ctx.d = w.shape[0]
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        r, s = ctx.saved_tensors
+        g = _rows_f32(g)
+        n, f = g.shape
+        out = torch.empty(2, f, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            ws_bytes = lib.pangnn_weighted_colsum_workspace_bytes(f)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+            _lib.check(lib.pangnn_weighted_colsum_f32(g.data_ptr(), g.stride(0), r.data_ptr(), s.data_ptr(), n, f,
+                                                      out.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
+                       "pangnn_weighted_colsum_f32")
+        return None, out[0].reshape(ctx.d, 1), out[1], None, None, None
+
+
+def embed_propagate(x_tab, w, b, st, norm, tag=None):
+    return _EmbedPropagate.apply(x_tab, w, b, st, norm, tag)

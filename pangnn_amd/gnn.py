@@ -15,6 +15,11 @@ Decoder: `mlp.0` applied to cat(z[src], z[dst] [, w]) is computed in the re-asso
 P[src] + Q[dst] (+ w*c) with P = z W_a^T, Q = z W_b^T + b — identical algebra, E*2D*D fewer
 multiply-adds and no [E, 2D] intermediate (pangnn_edge_pair_add_f32).  `fused_decoder=False`
 selects the literal gather-concat-Linear form (pangnn_edge_gather_concat_f32).
+
+First layer: `conv_in(embedding(x))` with the scalar node feature is one operator
+(functional._EmbedPropagate): forward is the ordinary propagate of h0 = x w^T + b; backward produces
+the embedding's gradients as (A_hat x)^T g, (A_hat 1)^T g instead of running the transposed
+propagate (nothing else consumes dL/dh0).  `fuse_embedding=False` keeps the layer-by-layer form.
 """
 from __future__ import annotations
 
@@ -36,7 +41,8 @@ _FLAG_DEFAULTS = dict(union_edge_weights=False, base_model=False, skip_connectio
 
 class AlternateGCN(nn.Module):
     def __init__(self, device=None, dataset=None, categorical_nodes: bool = False, dims=(64, 128),
-                 args=None, num_nodes: Optional[int] = None, fused_decoder: bool = True, **flags):
+                 args=None, num_nodes: Optional[int] = None, fused_decoder: bool = True,
+                 fuse_embedding: bool = True, **flags):
         super().__init__()
         self.device = device
         cfg = dict(_FLAG_DEFAULTS)
@@ -50,6 +56,7 @@ class AlternateGCN(nn.Module):
         cfg.update(flags)
         self.flags = SimpleNamespace(**cfg)
         self.fused_decoder = fused_decoder
+        self.fuse_embedding = fuse_embedding
         node_embedding_dim, hidden_dim = dims
 
         if categorical_nodes:
@@ -79,28 +86,40 @@ class AlternateGCN(nn.Module):
             self.to(device)
 
     # ---------------------------------------------------------------------------------
-    def encode(self, graph) -> torch.Tensor:
-        fl = self.flags
-        x = graph.x
+    def _embed_conv_in(self, graph, ei, name):
+        """act-less `conv_in(embedding(x))` (gnn.py:125-131,143-146,156-158)"""
+        x, conv = graph.x, self.conv_in
         _lib.require_device(x)
         if self.categorical_nodes:
-            h = self.embedding(x.long().view(-1))
-        else:
-            # Linear(1, D) on a [N,1] column is an outer product; as a GEMM its weight gradient is a
-            # 64 x 1 x N problem that the BLAS library runs at < 0.1 TB/s
-            h = x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
+            return conv(self.embedding(x.long().view(-1)), ei, graph.edge_attr, graph=graph, name=name)
+        if conv.in_channels < conv.out_channels and self.fuse_embedding:
+            # embedding + propagate as one operator whose backward yields the embedding's two parameter
+            # gradients without the transposed propagate (functional._EmbedPropagate)
+            st = structure_of(ei, x.shape[0], holder=graph, name=name)
+            w = graph.edge_attr
+            if w is not None and w.shape[0] != st.num_edges:
+                raise ValueError(f"edge_weight has {w.shape[0]} entries for {st.num_edges} edges")
+            agg = PF.embed_propagate(x, self.embedding.weight, self.embedding.bias, st, st.gcn_norm(w), tag=name)
+            return PF.linear(agg, conv.lin.weight, conv.bias)
+        # Linear(1, D) on a [N,1] column is an outer product; as a GEMM its weight gradient is a
+        # 64 x 1 x N problem that the BLAS library runs at < 0.1 TB/s
+        h = x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
+        return conv(h, ei, graph.edge_attr, graph=graph, name=name)
+
+    def encode(self, graph) -> torch.Tensor:
+        fl = self.flags
         act = self.activation_fct
         if fl.union_edge_weights:                                              # gnn.py:128-139
             ei = graph.union_edge_index
-            h = act(self.conv_in(h, ei, graph.edge_attr, graph=graph, name="union"))
+            h = act(self._embed_conv_in(graph, ei, "union"))
             for _ in range(max(fl.neighbours - 2, 1)):
                 h = act(self.conv_hidden(h, ei, graph.edge_attr, graph=graph, name="union"))
             h = act(self.conv_out(h, ei, graph=graph, name="union"))
         elif fl.base_model:                                                    # gnn.py:143-150
-            h = act(self.conv_in(h, graph.edge_index, graph.edge_attr, graph=graph, name="sim"))
+            h = act(self._embed_conv_in(graph, graph.edge_index, "sim"))
             h = act(PF.linear(h, self.linear_out.weight, self.linear_out.bias))
         else:                                                                  # gnn.py:153-166
-            h = act(self.conv_in(h, graph.edge_index, graph.edge_attr, graph=graph, name="sim"))
+            h = act(self._embed_conv_in(graph, graph.edge_index, "sim"))
             h = act(self.conv_out(h, graph.neighbour_edge_index, graph=graph, name="nb"))
         return h
 

@@ -40,6 +40,9 @@ class TorchOps:
         out = torch.zeros(st.n_dst, x_full.shape[1]).index_add(0, dst, norm.view(-1, 1) * x_full[src])
         return out if bias is None else out + bias
 
+    def embed_propagate(self, x_tab, w, b, st, norm, tag=None):
+        return self.propagate(x_tab.view(-1, 1) * w.view(1, -1) + b, None, st, norm)
+
     def accumulate_back(self, g_local, back, plan):
         g_local.index_add_(0, plan.send_idx, back)
 

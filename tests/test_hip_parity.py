@@ -798,3 +798,72 @@ def test_bf16x3_mode_whole_model_and_f32_mode_agree():
     for k, gk in res[0][2].items():
         scale = float(gk.abs().max()) + 1e-12
         assert close(res[1][2][k], gk, atol=1e-4 * scale + 1e-9, rtol=1e-3), k
+
+
+# ---------------------------------------------------------------- embedding + first-layer propagate as one operator
+@pytest.mark.parametrize("F", [16, 64, 128, 256])
+@pytest.mark.parametrize("n", [0, 1, 5, 1000, 300007])
+def test_weighted_colsum_kernel(F, n):
+    from pangnn_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(n + F)
+    g = torch.randn(n, F + 4, generator=gen)[:, 2:F + 2]          # strided rows
+    r, s = torch.randn(n, generator=gen), torch.rand(n, generator=gen)
+    gd, rd, sd = g.to(dev()), r.to(dev()), s.to(dev())
+    outs = []
+    for _ in range(2):
+        out = torch.empty(2, F, device=dev())
+        nb = lib.pangnn_weighted_colsum_workspace_bytes(F)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev())
+        _lib.check(lib.pangnn_weighted_colsum_f32(gd.data_ptr(), gd.stride(0), rd.data_ptr(), sd.data_ptr(), n, F,
+                                                  out.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr()), "colsum")
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])                           # fixed summation order
+    ref = torch.stack([(r.double().unsqueeze(1) * g.double()).sum(0), (s.double().unsqueeze(1) * g.double()).sum(0)])
+    scale = float(ref.abs().max()) + 1e-12
+    assert close(outs[0], ref, atol=1e-4 * scale + 1e-7, rtol=1e-4)
+    with pytest.raises(_lib.PangnnHipError):
+        _lib.check(lib.pangnn_weighted_colsum_f32(gd.data_ptr(), gd.stride(0), rd.data_ptr(), sd.data_ptr(), n, 48,
+                                                  out.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr()), "colsum")
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(base_model=True), dict(union_edge_weights=True)],
+                         ids=["default", "base", "union"])
+def test_fused_embedding_layer_equals_layerwise_form_and_oracle(flags):
+    """non-constant scalar node feature: A_hat x and A_hat 1 differ, both embedding gradients are exercised"""
+    import pangnn_amd
+    g, gd, oracle, model = _pair("cfg2_sim_1000x5", (64, 128), flags, seed=5)
+    gen = torch.Generator().manual_seed(9)
+    g.x = torch.randn(g.x.shape[0], 1, generator=gen)
+    gd.x = g.x.to(dev())
+    plain = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], fuse_embedding=False, **flags)
+    plain.load_state_dict(model.state_dict())
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    lr = torch.nn.functional.binary_cross_entropy_with_logits(oracle(g), g.y, pos_weight=pw)
+    lr.backward()
+    grads = []
+    for m in (model, plain):
+        gm = copy_graph(g, dev())
+        loss, out = m.loss_and_logits(gm, gm.y, pw.to(dev()))
+        loss.backward()
+        assert close(loss, lr, atol=1e-5, rtol=1e-5)
+        grads.append({k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+    po = dict(oracle.named_parameters())
+    for k in ("embedding.weight", "embedding.bias", "conv_in.lin.weight", "conv_in.bias"):
+        scale = float(po[k].grad.abs().max()) + 1e-12
+        assert close(grads[0][k], po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), k
+        assert close(grads[0][k], grads[1][k], atol=1e-3 * scale + 1e-7, rtol=1e-3), k
+    # the cached A_hat x is keyed on the feature tensor: an in-place change must be seen
+    gm = copy_graph(g, dev())
+    model.zero_grad()
+    l1, _ = model.loss_and_logits(gm, gm.y, pw.to(dev())); l1.backward()
+    g1 = model.embedding.weight.grad.clone()
+    gm.x.mul_(2.0)
+    model.zero_grad()
+    l2, _ = model.loss_and_logits(gm, gm.y, pw.to(dev())); l2.backward()
+    plain.zero_grad()
+    gp = copy_graph(g, dev()); gp.x = gp.x * 2.0
+    l3, _ = plain.loss_and_logits(gp, gp.y, pw.to(dev())); l3.backward()
+    scale = float(plain.embedding.weight.grad.abs().max()) + 1e-12
+    assert close(model.embedding.weight.grad, plain.embedding.weight.grad, atol=1e-3 * scale + 1e-7, rtol=1e-3)
+    assert not torch.equal(g1, model.embedding.weight.grad)
