@@ -204,6 +204,17 @@ int    pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int6
                                size_t workspace_bytes, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Confusion counts of thresholded link predictions, accumulated on the device:
+ *   counts[2*label + prediction] += 1,  prediction = (score >= threshold),
+ *   score = sigmoid(scores[i]) if apply_sigmoid else scores[i];  label = labels[i] > 0.5.
+ * Replaces  probabilities = torch.sigmoid(output); (probabilities >= binary_th).int();
+ *           BinaryConfusionMatrix.update(prediction, labels)      (pangnn.py:218-222, 257-262)
+ * counts = {tn, fp, fn, tp} (torchmetrics layout [[tn, fp], [fn, tp]]), int64, caller-zeroed, never reset here.
+ * ---------------------------------------------------------------------------------------- */
+int    pangnn_confusion_update_f32(const float* scores, const float* labels, int64_t n, float threshold,
+                                   int apply_sigmoid, int64_t* counts, pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * out[0, c] = sum_n r[n] g[n, c], out[1, c] = sum_n s[n] g[n, c]  (out [2, F], F divides 256).
  * Backward of the scalar-feature embedding feeding the first GCN layer (src/gnn.py:97,125,158): the layer's
  * input is h0 = x w^T + 1 b^T, so dL/dw = (A_hat x)^T g and dL/db = (A_hat 1)^T g with g = dL/d(A_hat h0);

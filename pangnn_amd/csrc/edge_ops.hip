@@ -202,25 +202,69 @@ __global__ void bce_finish_kernel(const float* __restrict__ partial, int n, floa
   }
 }
 
+// counts[2*label + prediction] += 1 with prediction = (score >= threshold), score = sigmoid(x) or x itself.
+// pangnn.py:218-222,257-262: probabilities = sigmoid(output); (probabilities >= binary_th).int();
+// BinaryConfusionMatrix.update(prediction, labels).  Integer atomics: the result is order independent.
+__global__ __launch_bounds__(kBlock) void confusion_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           int64_t n, float threshold, int apply_sigmoid,
+                                                           unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int red[kBlock / kWave][4];
+  unsigned int c[4] = {0u, 0u, 0u, 0u};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float xv = x[i];
+    const float score = apply_sigmoid ? 1.0f / (1.0f + expf(-xv)) : xv;
+    const int pred = score >= threshold ? 1 : 0, lab = y[i] > 0.5f ? 1 : 0;
+    c[2 * lab + pred] += 1u;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned int v = c[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) t += red[w][threadIdx.x];
+    if (t) atomicAdd(&counts[threadIdx.x], t);
+  }
+}
+
 // out[0, c] = sum_n r[n] g[n, c],  out[1, c] = sum_n s[n] g[n, c]   (c < F <= 256, F | 256).
 // Parameter gradients of the scalar-feature embedding that feeds the first GCN layer (src/gnn.py:97,125,158):
 // with h0 = x w^T + 1 b^T one has dL/dw = (A_hat x)^T g and dL/db = (A_hat 1)^T g, so no transposed propagate
 // is needed for a layer whose input carries no other gradient.  Two-stage fixed-order sum.
-constexpr int kColsumBlocks = 512;
+constexpr int kColsumBlocks = 1024;
+// VEC = 4: a thread owns 4 adjacent columns (16-byte loads, F/4 lanes per row); VEC = 1 for F < 4 or odd strides
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void weighted_colsum_kernel(const float* __restrict__ g, int64_t ldg,
                                                                  const float* __restrict__ r,
                                                                  const float* __restrict__ sv, int64_t n, int F,
                                                                  float* __restrict__ partial) {
-  __shared__ float red[2][kBlock];
-  const int c = threadIdx.x % F, rg = threadIdx.x / F, groups = kBlock / F;
-  float a0 = 0.f, a1 = 0.f;
+  __shared__ float red[2][kBlock * VEC];
+  const int lpr = F / VEC;                        // lanes per row
+  const int c = threadIdx.x % lpr, rg = threadIdx.x / lpr, groups = kBlock / lpr;
+  float a0[VEC], a1[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) a0[v] = a1[v] = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * groups + rg; row < n; row += (int64_t)gridDim.x * groups) {
-    const float v = g[row * ldg + c];
-    a0 = fmaf(r[row], v, a0);
-    a1 = fmaf(sv[row], v, a1);
+    float v[VEC];
+    if constexpr (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(g + row * ldg + 4 * c);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      v[0] = g[row * ldg + c];
+    }
+    const float rv = r[row], sw = sv[row];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { a0[k] = fmaf(rv, v[k], a0[k]); a1[k] = fmaf(sw, v[k], a1[k]); }
   }
-  red[0][threadIdx.x] = a0;
-  red[1][threadIdx.x] = a1;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    red[0][rg * F + VEC * c + k] = a0[k];
+    red[1][rg * F + VEC * c + k] = a1[k];
+  }
   __syncthreads();
   if (threadIdx.x < F) {
     float t0 = 0.f, t1 = 0.f;
@@ -430,15 +474,34 @@ extern "C" int pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const flo
                    (n == 0 || (g && r && s)),
                PANGNN_E_BADARG, "pangnn_weighted_colsum_f32: null pointer / workspace");
   hipStream_t st = (hipStream_t)stream;
-  const int groups = kBlock / F;
-  int blocks = (int)((n + groups - 1) / groups);
+  const int groups = kBlock / F;            // rows per block pass of the scalar form; the float4 form takes 4x
+  int blocks = (int)((n + 4 * groups - 1) / (4 * groups));
   if (blocks > kColsumBlocks) blocks = kColsumBlocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(weighted_colsum_kernel, dim3(blocks), dim3(kBlock), 0, st, g, ldg, r, s, n, (int)F,
-                     static_cast<float*>(workspace));
+  if (F % 4 == 0 && ldg % 4 == 0 && aligned16(g))
+    hipLaunchKernelGGL(weighted_colsum_kernel<4>, dim3(blocks), dim3(kBlock), 0, st, g, ldg, r, s, n, (int)F,
+                       static_cast<float*>(workspace));
+  else
+    hipLaunchKernelGGL(weighted_colsum_kernel<1>, dim3(blocks), dim3(kBlock), 0, st, g, ldg, r, s, n, (int)F,
+                       static_cast<float*>(workspace));
   PG_CHECK_LAUNCH("pangnn_weighted_colsum_f32");
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * F + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                      static_cast<const float*>(workspace), blocks, (int)F, out);
   PG_CHECK_LAUNCH("pangnn_weighted_colsum_f32(finish)");
+  return 0;
+}
+
+extern "C" int pangnn_confusion_update_f32(const float* scores, const float* labels, int64_t n, float threshold,
+                                           int apply_sigmoid, int64_t* counts, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0 && counts && (n == 0 || (scores && labels)), PANGNN_E_BADARG,
+               "pangnn_confusion_update_f32: null pointer / negative size");
+  // one thread counts at most 2^32-1 elements of its grid-stride slice
+  PG_CHECK_ARG(n < ((int64_t)1 << 40), PANGNN_E_TOOLARGE, "pangnn_confusion_update_f32: n too large");
+  if (n == 0) return 0;
+  int blocks = (int)((n + kBlock - 1) / kBlock);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, scores, labels, n,
+                     threshold, apply_sigmoid, reinterpret_cast<unsigned long long*>(counts));
+  PG_CHECK_LAUNCH("pangnn_confusion_update_f32");
   return 0;
 }

@@ -40,6 +40,35 @@ def eval_step(model, graph, labels, pos_weight):
     return criterion(out, labels, pos_weight), out
 
 
+@torch.no_grad()
+def evaluate(model, batches, pos_weight, threshold: float = 0.5) -> dict:
+    """The validation pass of pangnn.py:241-290: mean loss over the batches, confusion counts at
+    `threshold`, precision / recall / f1 / accuracy, ROC-AUC and PR-AUC.  Everything accumulates on the
+    GPU; the only host synchronisation is the final read-out."""
+    from .metrics import BinaryAUROC, BinaryAveragePrecision, BinaryConfusionMatrix, summary_from_confusion
+    conf, auroc, ap = None, BinaryAUROC(), BinaryAveragePrecision()
+    loss_sum, n_batches = None, 0
+    was_training = model.training
+    model.eval()
+    for batch in batches:
+        out = model(batch)
+        loss = criterion(out, batch.y, pos_weight)
+        loss_sum = loss if loss_sum is None else loss_sum + loss
+        n_batches += 1
+        if conf is None:
+            conf = BinaryConfusionMatrix(threshold, device=out.device)
+        conf.update_from_logits(out, batch.y)
+        prob = torch.sigmoid(out)
+        auroc.update(prob, batch.y)
+        ap.update(prob, batch.y)
+    model.train(was_training)
+    if conf is None:
+        raise ValueError("evaluate() needs at least one batch")
+    res = summary_from_confusion(conf.compute())
+    res.update(loss=float(loss_sum) / n_batches, roc_auc=float(auroc.compute()), pr_auc=float(ap.compute()))
+    return res
+
+
 class GraphedTrainStep:
     """The whole train step (zero_grad -> forward -> loss -> backward -> Adam) of ONE fixed batch captured
     into a HIP graph and replayed.  For the reference's regime (32 small sub-graphs per batch,
