@@ -198,7 +198,7 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void decoder_fwd_kernel(DecParams a
   float* b2l = lds + 64 * RS;
   float* w3l = b2l + 64;
   float* cvl = w3l + 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR: tile index and its addresses stay scalar
   float* Ht = cvl + 64 + wave * (TE * RS);
   stage_weights(a, Wl, b2l, w3l, cvl, FWD_WAVES * 64);
   __syncthreads();
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   float* b2l = lds + 64 * RS;
   float* w3l = b2l + 64;
   float* cvl = w3l + 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR: tile index and its addresses stay scalar
   float* Ht = cvl + 64 + wave * PER_WAVE;
   float* Gt = Ht + TE * RS;
   float* wl = Gt + 64 * GS;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   float* b2l = lds + WT_FLOATS;
   float* w3l = b2l + 64;
   float* cvl = w3l + 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR: tile index and its addresses stay scalar
   float* Ht = cvl + 64 + wave * PER_WAVE;
   float* Gt = Ht + TE * RS;
   float* wl = Gt + 64 * GS;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kBlock) void degree_kernel(const int64_t* __restric
                                                         const float* __restrict__ w,
                                                         float* __restrict__ dis, int64_t n) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR
   if (row >= n) return;
   const int64_t beg = rowptr[row], end = rowptr[row + 1];
   float s = 0.f;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void edge_norm_kernel(
     const float* __restrict__ dis,
     float* __restrict__ norm_sorted, float* __restrict__ norm_orig, int64_t n) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR
   if (row >= n) return;
   const int64_t beg = rowptr[row], end = rowptr[row + 1];
   const float dc = dis[row];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void segment_max_kernel(
     const float* __restrict__ m, int64_t ldm, float* __restrict__ out, int32_t* __restrict__ arg,
     int64_t ldo, int64_t n_rows, int F) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR
   if (row >= n_rows) return;
   const int64_t beg = rowptr[row], end = rowptr[row + 1];
   for (int f = lane; f < F; f += kWave) {

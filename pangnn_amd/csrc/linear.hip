@@ -13,12 +13,30 @@ namespace pangnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef PANGNN_LIN_NOMFMA   // diagnostic builds only (tools/ablate_linear.sh): one VALU op per MFMA
+#define LIN_MFMA(a, b, c) ([&] { f32x16 t_ = (c); t_[0] += (a) * (b); return t_; }())
+#else
+#define LIN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
+
 __device__ __forceinline__ constexpr int jrow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// wave-uniform base pointer + 32-bit per-lane byte offset: the form that maps to `global_* v_off, v_data, s[base]`
+// (scalar address arithmetic per tile, no 64-bit vector pointer per access).  The compiler only selects it when
+// the base is known to sit in SGPRs and the offset's zero-extension is in the same basic block, hence `pin()`
+// at the top of every block of accesses: an empty asm that ties `base` to an SGPR pair and `off` to a VGPR.
+__device__ __forceinline__ void pin(int64_t& base, uint32_t& off) { asm volatile("" : "+s"(base), "+v"(off)); }
+__device__ __forceinline__ float4 ld_f4(const float* ubase, uint32_t byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ubase) + byte_off);
+}
+__device__ __forceinline__ void st_f32(float* ubase, uint32_t byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byte_off) = v;
 }
 
 // rows [base, base+32) of a [n, C] matrix (leading dim ld): issued into registers one tile ahead
@@ -28,11 +46,27 @@ template <int C>
 struct RowRegs { float4 v[32 / (64 / (C / 4))]; };
 
 template <int C>
-__device__ __forceinline__ void load_rows(const float* __restrict__ src, int64_t ld, int64_t n, int64_t base,
-                                          int lane, RowRegs<C>& rg) {
+__device__ __forceinline__ void load_rows_full(const float* __restrict__ src, int64_t ld, int64_t base, int lane,
+                                               RowRegs<C>& rg) {      // whole tile inside the matrix: no predicate
   constexpr int LPR = C / 4;            // lanes per row
   constexpr int RPI = 64 / LPR;         // rows per wave-instruction
   const int c4 = lane % LPR, r0 = lane / LPR;
+  uint32_t loff = ((uint32_t)r0 * (uint32_t)ld + 4u * c4) * 4u;
+  pin(base, loff);
+#pragma unroll
+  for (int i = 0; i < 32 / RPI; ++i) rg.v[i] = ld_f4(src + (base + i * RPI) * ld, loff);
+}
+
+template <int C>
+__device__ __forceinline__ void load_rows(const float* __restrict__ src, int64_t ld, int64_t n, int64_t base,
+                                          int lane, RowRegs<C>& rg) {
+  constexpr int LPR = C / 4;
+  constexpr int RPI = 64 / LPR;
+  const int c4 = lane % LPR, r0 = lane / LPR;
+  if (base + 32 <= n) {                 // wave-uniform
+    load_rows_full<C>(src, ld, base, lane, rg);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 32 / RPI; ++i) {
     const int row = i * RPI + r0;
@@ -52,61 +86,136 @@ __device__ __forceinline__ void store_rows(const RowRegs<C>& rg, int lane, float
     *reinterpret_cast<float4*>(tile + (i * RPI + r0) * RS + 4 * c4) = rg.v[i];
 }
 
+// Waves per workgroup of the forward kernel.  Measured at N = 1e6 (tools/ablate_linear.sh): 4 waves per CU
+// (one per SIMD) is the fastest arrangement — an f32 MFMA occupies its SIMD's vector lanes, so a second wave
+// on the SIMD cannot hide the first one's epilogue, it only adds LDS / issue contention (8 waves +5..10 %,
+// 12 waves +30 %).
 template <int K, int M>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+struct FwdGeo {
+  static constexpr int KS = K + 4;
+#ifdef PANGNN_LIN_WAVES      // diagnostic builds only
+  static constexpr int WAVES = PANGNN_LIN_WAVES;
+#else
+  static constexpr int WAVES = 4;
+#endif
+};
+
+// one 32-row tile out of LDS: acc[b] = x_tile . w[32b .. 32b+32)^T.  Operand fragments of k-step i+1 are read
+// from LDS before the 4*M/32 MFMAs of step i are issued (sched_barrier keeps that order).
+template <int K, int M>
+__device__ __forceinline__ void tile_product(const float* Xt, const float* Wl, int r, int hh, f32x16 (&acc)[M / 32]) {
+  constexpr int KS = K + 4;
+#pragma unroll
+  for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+  const float* xa = Xt + r * KS + 4 * (K / 8) * hh;
+  const float* wb = Wl + r * KS + 4 * (K / 8) * hh;
+  float4 a = *reinterpret_cast<const float4*>(xa);
+  float4 bw[M / 32];
+#pragma unroll
+  for (int b = 0; b < M / 32; ++b) bw[b] = *reinterpret_cast<const float4*>(wb + 32 * b * KS);
+#pragma unroll
+  for (int i = 0; i < K / 8; ++i) {
+    float4 an = a, bn[M / 32];
+#pragma unroll
+    for (int b = 0; b < M / 32; ++b) bn[b] = bw[b];
+    if (i + 1 < K / 8) {
+      an = *reinterpret_cast<const float4*>(xa + 4 * (i + 1));
+#pragma unroll
+      for (int b = 0; b < M / 32; ++b) bn[b] = *reinterpret_cast<const float4*>(wb + 32 * b * KS + 4 * (i + 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < M / 32; ++b) {
+      acc[b] = LIN_MFMA(a.x, bw[b].x, acc[b]);
+      acc[b] = LIN_MFMA(a.y, bw[b].y, acc[b]);
+      acc[b] = LIN_MFMA(a.z, bw[b].z, acc[b]);
+      acc[b] = LIN_MFMA(a.w, bw[b].w, acc[b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    a = an;
+#pragma unroll
+    for (int b = 0; b < M / 32; ++b) bw[b] = bn[b];
+  }
+}
+
+// Pipeline per wave over the FULL tiles (rows [32t, 32t+32) all inside the matrix):
+//   registers hold the x rows of tile t+1 (global loads issued one tile ahead) while tile t is multiplied out
+//   of LDS; they are committed to LDS at the END of iteration t, in the same basic block as tile t's 64 output
+//   stores.  The loads are older than those stores, so the wait the compiler puts before the LDS write is
+//   vmcnt(63): loads landed, stores still in flight.  Committing at the loop top instead costs vmcnt(0) — every
+//   tile then waits until its predecessor's writes are acknowledged (0.30 ms vs 0.19 ms per launch at N = 1e6).
+//   The loop body has no branch: the prefetch index is clamped instead of guarded.
+// The one partial tile at the end of the matrix is handled after the loop by the wave whose turn it is.
+template <int K, int M>
+__global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ y, int64_t ldy, int64_t n,
                                                          int64_t n_tiles) {
   constexpr int KS = K + 4;
-  __shared__ __attribute__((aligned(16))) float lds[M * KS + 4 * 32 * KS];
+  constexpr int WAVES = FwdGeo<K, M>::WAVES;
+  __shared__ __attribute__((aligned(16))) float lds[M * KS + WAVES * 32 * KS];
   float* Wl = lds;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR
   float* Xt = lds + M * KS + wave * (32 * KS);
-  for (int i = threadIdx.x; i < M * (K / 4); i += 256) {
+  for (int i = threadIdx.x; i < M * (K / 4); i += WAVES * 64) {
     const int m = i / (K / 4), k4 = i % (K / 4);
     *reinterpret_cast<float4*>(Wl + m * KS + 4 * k4) = reinterpret_cast<const float4*>(w)[i];
   }
   __syncthreads();
   const int r = lane & 31, hh = lane >> 5;
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t n_full = n / 32;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  float bv[M / 32];
+#pragma unroll
+  for (int b = 0; b < M / 32; ++b) bv[b] = bias ? bias[r + 32 * b] : 0.f;
+  f32x16 acc[M / 32];
   RowRegs<K> rg;
-  load_rows<K>(x, ldx, n, tile * 32, lane, rg);
-  for (; tile < n_tiles; tile += stride) {
-    const int64_t base = tile * 32;
+  if (tile < n_full) {
+    const int64_t last = n_full - 1;
+    load_rows_full<K>(x, ldx, tile * 32, lane, rg);
     store_rows<K>(rg, lane, Xt);
-    load_rows<K>(x, ldx, n, (tile + stride) * 32, lane, rg);     // next tile flies during the MFMAs
+    load_rows_full<K>(x, ldx, (tile + stride < last ? tile + stride : last) * 32, lane, rg);
     wave_sync_lds();
-    f32x16 acc[M / 32];
+    for (; tile < n_full; tile += stride) {
+      tile_product<K, M>(Xt, Wl, r, hh, acc);
+      // C[row = jrow(i,hh)][m = r + 32b]: 128-byte row segments
+      uint32_t loff = (4u * hh * (uint32_t)ldy + r) * 4u;
+      int64_t sbase = tile * 32;
+      pin(sbase, loff);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* yr = y + (sbase + (i & 3) + 8 * (i >> 2)) * ldy;           // scalar
+#pragma unroll
+        for (int b = 0; b < M / 32; ++b)
+#ifdef PANGNN_LIN_NOSTORE       // diagnostic builds only
+          if (acc[b][i] == 12345.678f)
+#endif
+          st_f32(yr + 32 * b, loff, acc[b][i] + bv[b]);
+      }
+      store_rows<K>(rg, lane, Xt);                    // tile + stride (see the pipeline note)
+      const int64_t nxt = tile + 2 * stride;
+      load_rows_full<K>(x, ldx, (nxt < last ? nxt : last) * 32, lane, rg);
+      wave_sync_lds();
+    }
+  }
+  if (tile == n_full && n_full < n_tiles) {            // the partial tile, rows [32 n_full, n)
+    const int64_t base = n_full * 32;
+    load_rows<K>(x, ldx, n, base, lane, rg);
+    wave_sync_lds();
+    store_rows<K>(rg, lane, Xt);
+    wave_sync_lds();
+    tile_product<K, M>(Xt, Wl, r, hh, acc);
 #pragma unroll
     for (int b = 0; b < M / 32; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < K / 8; ++i) {
-      const int k4 = (K / 8) * hh + i;
-      const float4 a = *reinterpret_cast<const float4*>(Xt + r * KS + 4 * k4);     // A: x[row r][k]
-#pragma unroll
-      for (int b = 0; b < M / 32; ++b) {
-        const float4 bw = *reinterpret_cast<const float4*>(Wl + (r + 32 * b) * KS + 4 * k4);  // B: w[m][k]
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw.x, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw.y, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw.z, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw.w, acc[b], 0, 0, 0);
-      }
-    }
-    // C[row = jrow(i,hh)][m = r + 32b]
-#pragma unroll
-    for (int b = 0; b < M / 32; ++b) {
-      const float bv = bias ? bias[r + 32 * b] : 0.f;
-#pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int64_t row = base + jrow(i, hh);
-        if (row < n) y[row * ldy + r + 32 * b] = acc[b][i] + bv;
+        if (row < n) y[row * ldy + r + 32 * b] = acc[b][i] + bv[b];
       }
-    }
-    wave_sync_lds();
   }
 }
 
@@ -125,7 +234,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   constexpr int SLAB = WgradGeo<K, M>::SLAB;
   constexpr int LDS_F = (4 * PER_WAVE > SLAB) ? 4 * PER_WAVE : SLAB;
   __shared__ __attribute__((aligned(16))) float lds[LDS_F];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR: tile addresses stay scalar
   float* Xt = lds + wave * PER_WAVE;
   float* Gt = Xt + 32 * KS;
   const int r = lane & 31, hh = lane >> 5;
@@ -215,11 +324,12 @@ static int num_cus() {
 template <int K, int M>
 static int launch_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
                       int64_t n, hipStream_t s) {
+  constexpr int WAVES = FwdGeo<K, M>::WAVES;
   const int64_t n_tiles = (n + 31) / 32;
-  int64_t grid = (n_tiles + 3) / 4;
-  const int64_t cap = (int64_t)num_cus() * 2;
+  int64_t grid = (n_tiles + WAVES - 1) / WAVES;
+  const int64_t cap = (int64_t)num_cus();          // one workgroup per CU fills its LDS
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((linear_fwd_kernel<K, M>), dim3((unsigned)grid), dim3(256), 0, s, x, ldx, w, bias, y, ldy,
+  hipLaunchKernelGGL((linear_fwd_kernel<K, M>), dim3((unsigned)grid), dim3(WAVES * 64), 0, s, x, ldx, w, bias, y, ldy,
                      n, n_tiles);
   PG_CHECK_LAUNCH("pangnn_linear_fwd_f32");
   return 0;

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
   static_assert(EPS * U <= 64, "unroll too deep for this feature width");
 
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR
   if (row >= n_rows) return;  // whole wave exits together (row is wave-uniform)
   const int sub = lane / G;   // which of the EPS rows of a step this lane helps with
   const int fl = lane % G;    // which float4 of that row
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void spmm_row_generic_kernel(
     const float* __restrict__ bias, float* __restrict__ out, int64_t ldo, int64_t n_rows, int F,
     int accumulate) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR
   if (row >= n_rows) return;
   const int64_t beg = rowptr[row], end = rowptr[row + 1];
   for (int f = lane; f < F; f += kWave) {
