@@ -20,6 +20,8 @@
 // a second tiny kernel sums the slabs in index order => bitwise reproducible, no float atomics.
 #include "common.h"
 
+#include <type_traits>
+
 namespace pangnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -75,20 +77,38 @@ __device__ __forceinline__ void stage_weights(const DecParams& a, float* Wl, flo
 }
 
 // ---- gather the tile's 32 h1 rows into the wave's LDS image.  Returns w_e / validity per lane e.
+// FULL: all 32 edges exist (every tile but the last): no bounds predicate on the id loads.
+// max(x, 0) as ONE instruction: fmaxf() makes the compiler put a canonicalising v_max(x, x) in front of it
+__device__ __forceinline__ float relu1(float x) {
+  float y;
+  asm("v_max_f32 %0, %1, 0" : "=v"(y) : "v"(x));
+  return y;
+}
+
+// 16-byte row piece at `table + byte_off`: uniform base pointer + 32-bit per-lane byte offset (node tables are
+// < 4 GiB, checked by the host wrapper) — `global_load_dwordx4 v, v_off, s[base]`, no 64-bit vector address
+__device__ __forceinline__ float4 ld_row16(const float* table, uint32_t byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table) + byte_off);
+}
+
+template <bool FULL = false>
 __device__ __forceinline__ void gather_tile(const DecParams& a, int64_t ebase, int lane, float* Ht,
                                             const float* cvl, float& w_e, int& id) {
   const int64_t e = ebase + (lane & 31);
   id = 0;
   w_e = 0.f;
-  if (e < a.E) {
+  if (FULL || e < a.E) {
     id = (int)a.ei[(int64_t)(lane >> 5) * a.ld + e];     // lanes 0-31: source, 32-63: target
     if (a.extra && lane < 32) w_e = a.extra[e];
   }
   const int c4 = lane & 15, r4 = lane >> 4;
-  const float4* P4 = reinterpret_cast<const float4*>(a.p);
-  const float4* Q4 = reinterpret_cast<const float4*>(a.q);
+  // byte offset of this lane's node row in its table (P for the source half, Q for the target half): one
+  // multiply per lane and tile; the 16 row gathers below shuffle the finished offset instead of the id
+  const uint32_t row_off = (uint32_t)id * ((lane >> 5) ? a.ldq4 : a.ldp4) * 16u;
+  const uint32_t col_off = 16u * c4;
+  const bool has_extra = a.extra != nullptr;             // uniform: the w_e * c term only exists with skip connections
   float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.extra) cv = reinterpret_cast<const float4*>(cvl)[c4];
+  if (has_extra) cv = reinterpret_cast<const float4*>(cvl)[c4];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     float4 pv[4], qv[4];
@@ -96,20 +116,31 @@ __device__ __forceinline__ void gather_tile(const DecParams& a, int64_t ebase, i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 4 * (4 * half + i) + r4;
-      const int s = __shfl(id, row);
-      const int d = __shfl(id, 32 + row);
-      wv[i] = __shfl(w_e, row);
-      pv[i] = P4[(uint32_t)s * a.ldp4 + c4];
-      qv[i] = Q4[(uint32_t)d * a.ldq4 + c4];
+      pv[i] = ld_row16(a.p, (uint32_t)__shfl((int)row_off, row) + col_off);
+      qv[i] = ld_row16(a.q, (uint32_t)__shfl((int)row_off, 32 + row) + col_off);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                         // same association as the forward kernel: (p + q) + w c
+      pv[i].x += qv[i].x; pv[i].y += qv[i].y; pv[i].z += qv[i].z; pv[i].w += qv[i].w;
+    }
+    if (has_extra) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wv[i] = __shfl(w_e, 4 * (4 * half + i) + r4);
+        pv[i].x = fmaf(wv[i], cv.x, pv[i].x);
+        pv[i].y = fmaf(wv[i], cv.y, pv[i].y);
+        pv[i].z = fmaf(wv[i], cv.z, pv[i].z);
+        pv[i].w = fmaf(wv[i], cv.w, pv[i].w);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 4 * (4 * half + i) + r4;
       float4 h;
-      h.x = fmaxf(pv[i].x + qv[i].x + wv[i] * cv.x, 0.f);
-      h.y = fmaxf(pv[i].y + qv[i].y + wv[i] * cv.y, 0.f);
-      h.z = fmaxf(pv[i].z + qv[i].z + wv[i] * cv.z, 0.f);
-      h.w = fmaxf(pv[i].w + qv[i].w + wv[i] * cv.w, 0.f);
+      h.x = relu1(pv[i].x);
+      h.y = relu1(pv[i].y);
+      h.z = relu1(pv[i].z);
+      h.w = relu1(pv[i].w);
       *reinterpret_cast<float4*>(Ht + swz4(row, c4)) = h;
     }
   }
@@ -290,15 +321,18 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   const float b3v = a.b3[0];
   const float pw = (FUSED_LOSS && lp.pos_weight) ? lp.pos_weight[0] : 1.f;
 
-  for (int64_t tile = (int64_t)blockIdx.x * BWD_WAVES + wave; tile < n_tiles;
-       tile += (int64_t)gridDim.x * BWD_WAVES) {
+  // One tile.  FULL (every tile but the last of the edge list): all 32 edges exist, so the bounds predicates on
+  // loads / stores and the `live` selects fold away; the instruction count of this body is what the kernel's
+  // time follows (f32 MFMA and vector instructions share the SIMD's lanes), so the common case carries none.
+  auto body = [&](const int64_t tile, auto full_c) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
     const int64_t ebase = tile * TE;
     float w_e;
     int id;
-    gather_tile(a, ebase, lane, Ht, cvl, w_e, id);
+    gather_tile<FULL>(a, ebase, lane, Ht, cvl, w_e, id);
     float g_e = 0.f;
     float y_e = 0.f;
-    const bool live = ebase + r < a.E;
+    const bool live = FULL || ebase + r < a.E;
     if (FUSED_LOSS) {
       if (live) y_e = lp.y[ebase + r];
       if (lane < 32) wl[lane] = w_e;
@@ -312,7 +346,10 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
     gemm1(Wl, Ht, lane, acc);
 
     if (FUSED_LOSS) {
-      // h2 = relu(C + b2) in place; the tile's logits; then loss and dL/dlogit per edge
+      // h2 = relu(C + b2) -> LDS (the weight-gradient product reads it); the tile's logits; the accumulator is
+      // overwritten with the masked w3 ([h2 > 0] w3[j]) while w3 is in registers anyway, so that once the
+      // edge's dL/dlogit is known G = g_e * (masked w3) is one multiply per element — no second pass over w3,
+      // no compare / select after the reduction
       float part = 0.f;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -327,39 +364,34 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
           for (int c = 0; c < 4; ++c) {
             const int i = 4 * qd + c;
             const float h2 = fmaxf(acc[b][i] + bbv[c], 0.f);
-            acc[b][i] = h2;
             part = fmaf(h2, wwv[c], part);
             Gt[(j0 + c) * GS + r] = h2;
+            acc[b][i] = h2 > 0.f ? wwv[c] : 0.f;
           }
         }
-      part += __shfl_xor(part, 32);
+      part += __shfl_xor(part, 32);                 // both halves of the wave now hold edge r's logit
       const float xv = part + b3v;
       const float lw = 1.f + (pw - 1.f) * y_e;
-      const float t = expf(-fabsf(xv));
-      const float sig_neg = xv >= 0.f ? t / (1.f + t) : 1.f / (1.f + t);          // sigmoid(-x)
+      const float t = expf(-fabsf(xv));             // in (0, 1]
+      const float u = 1.f + t;
+      float ru = __builtin_amdgcn_rcpf(u);
+      ru = ru * (2.f - u * ru);                     // 1 / (1 + t), one Newton step on the hardware reciprocal
+      const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
       g_e = live ? ((1.f - y_e) - lw * sig_neg) * lp.inv_denom : 0.f;
-      if (lane < 32) {
-        gl[lane] = g_e;
-        gb3p += g_e;
-        if (live) {
-          lp.logits[ebase + r] = xv;
-          lossp += ((1.f - y_e) * xv + lw * (log1pf(t) + fmaxf(-xv, 0.f))) * lp.inv_denom;
-        }
-      }
-      // G[j][e] = g_e * w3[j] * [h2 > 0]  (A operand of the next product)
+      // softplus(-x) = log1p(t) + max(-x, 0);  log1p(t) = log(u) * t / (u - 1) with u = fl(1 + t) (exact u - 1),
+      // = t when u == 1
+      const float um1 = u - 1.f;
+      float rm = __builtin_amdgcn_rcpf(um1);
+      rm = rm * (2.f - um1 * rm);
+      const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
+      gl[r] = g_e;                                   // the two halves write the same value
+      gb3p += g_e;                                   // per-half partials; lane 0's half is the one read out
+      if (live) lossp += ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom;
+      if (hh == 0 && live) lp.logits[ebase + r] = xv;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int j0 = 32 * b + 8 * qd + 4 * hh;
-          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
-          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int i = 4 * qd + c;
-            acc[b][i] = acc[b][i] > 0.f ? g_e * wwv[c] : 0.f;
-          }
-        }
+        for (int i = 0; i < 16; ++i) acc[b][i] *= g_e;   // G[j][e]: A operand of the next product
     } else {
       // G[j][e] = g_e * w3[j] * [h2pre > 0]  (in place in acc; A operand of the next product);
       // h2[j][e] goes to LDS: the weight-gradient product rebuilds G and g_e * h2 from it
@@ -398,11 +430,11 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
         acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[b][i], w0, acc2[0], 0, 0, 0);
         acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[b][i], w1, acc2[1], 0, 0, 0);
       }
-    // mask by h1 > 0, write dL/dh1pre, accumulate gcvec.  Full tiles (all but the last) store through
-    // one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
+    // mask by h1 > 0, write dL/dh1pre (kept in acc2 for the run sums), accumulate gcvec.  Full tiles store
+    // through one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
     {
       float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
-      const bool full = ebase + TE <= a.E;
+      const bool full = FULL || ebase + TE <= a.E;
 #pragma unroll
       for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
@@ -412,9 +444,14 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
           const float hval = Ht[swz(e, k)];
           const float v = hval > 0.f ? acc2[bp][i] : 0.f;
           if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
-          if (a.extra) gcv[bp] = fmaf(wl[e], v, gcv[bp]);
-          if (RUNSUM) acc2[bp][i] = v;
+          acc2[bp][i] = v;
         }
+      if (a.extra) {                                 // uniform; only with skip connections
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) gcv[bp] = fmaf(wl[jr(i, hh)], acc2[bp][i], gcv[bp]);
+      }
     }
 
     // gW2[j][k] += sum_e G[j][e] h1[e][k]  : both operands from LDS, reduction over the tile's edges
@@ -440,8 +477,8 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
     if (RUNSUM) {
       // close a part at the last edge of every source run of the tile
       const int id_nxt = __shfl(id, (lane + 1) & 63);
-      const bool ok = lane < 32 && ebase + lane < a.E;
-      const bool ok_nxt = lane < 31 && ebase + lane + 1 < a.E;
+      const bool ok = lane < 32 && (FULL || ebase + lane < a.E);
+      const bool ok_nxt = lane < 31 && (FULL || ebase + lane + 1 < a.E);
       const unsigned long long mask = __ballot(ok && (!ok_nxt || id != id_nxt));
       const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask & 0xffffffffull));
       int64_t pidx = rs.part_off[tile];
@@ -478,7 +515,11 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
       }
     }
     wave_lds_sync();   // next tile overwrites Ht / Gt / wl
-  }
+  };
+  const int64_t n_full = a.E / TE, stride = (int64_t)gridDim.x * BWD_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * BWD_WAVES + wave;
+  for (; tile < n_full; tile += stride) body(tile, std::true_type{});
+  if (tile < n_tiles) body(tile, std::false_type{});     // tile == n_full: the partial tile, one wave's turn
 
   // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
   gw3p[0] += __shfl_xor(gw3p[0], 32);
@@ -551,6 +592,33 @@ __device__ __forceinline__ Split3 split8(const float (&f)[8]) {
   return s;
 }
 
+typedef short short4v __attribute__((ext_vector_type(4)));
+constexpr int IRS = 68;       // row stride (16-bit elements) of the per-tile bf16 images: 136 B, 8-byte aligned rows
+
+// 8 bf16 -> two 8-byte LDS stores (rows are only 8-byte aligned)
+__device__ __forceinline__ void st_img8(short* dst, const bf16x8& v) {
+  struct P { short4v lo, hi; };
+  const P p = __builtin_bit_cast(P, v);
+  *reinterpret_cast<short4v*>(dst) = p.lo;
+  *reinterpret_cast<short4v*>(dst + 4) = p.hi;
+}
+// elements 0..3 at dst, elements 4..7 eight columns further
+__device__ __forceinline__ void st_img4x2(short* dst, const bf16x8& v) {
+  struct P { short4v lo, hi; };
+  const P p = __builtin_bit_cast(P, v);
+  *reinterpret_cast<short4v*>(dst) = p.lo;
+  *reinterpret_cast<short4v*>(dst + 8) = p.hi;
+}
+// 8-deep MFMA fragment from a rows-are-K image: two transposing reads, 4 rows apart
+__device__ __forceinline__ bf16x8 ld_tr8(const short* src) {
+  typedef __attribute__((address_space(3))) short4v lds_s4;
+  struct P { short4v lo, hi; };
+  P p;
+  p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(src));
+  p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(src + 4 * IRS));
+  return __builtin_bit_cast(bf16x8, p);
+}
+
 constexpr int X3_WAVES = 4;   // 256 threads, 1 workgroup / CU, 1 wave / SIMD
 constexpr int WTS = 72;       // bf16 row stride of the W2^T images: 144 B, conflict-free ds_read_b128 down rows
 
@@ -558,7 +626,8 @@ template <bool FUSED_LOSS, bool RUNSUM>
 __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     DecParams a, const float* __restrict__ g_logits, LossParams lp, RunSumParams rs, float* __restrict__ g_h1,
     float* __restrict__ slabs, int64_t n_tiles) {
-  constexpr int PER_WAVE = TE * RS + 64 * GS + 64;   // Ht | H2t | w_e | g_e
+  constexpr int IMG = TE * IRS / 2;                  // one bf16 image [32 edges][64] of the tile, in floats
+  constexpr int PER_WAVE = TE * RS + 64 * GS + 64 + 4 * IMG;   // Ht | H2t | w_e | g_e | G hi,mid | h1 hi,mid
   constexpr int WT_FLOATS = 2 * 64 * WTS / 2;        // two bf16 images [64][WTS] of W2^T (hi, mid)
   __shared__ __attribute__((aligned(16))) float lds[WT_FLOATS + 3 * 64 + X3_WAVES * PER_WAVE];
   unsigned short* Wt = reinterpret_cast<unsigned short*>(lds);
@@ -570,7 +639,15 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   float* Gt = Ht + TE * RS;
   float* wl = Gt + 64 * GS;
   float* gl = wl + 32;
+  short* GIh = reinterpret_cast<short*>(gl + 32);   // G[j][e] as rows e, columns j (bf16 hi / mid): A operand of
+  short* GIm = GIh + TE * IRS;                      //   the third product through transposing reads
+  short* HIh = GIm + TE * IRS;                      // h1[e][k] as rows e, columns k (bf16 hi / mid): its B operand
+  short* HIm = HIh + TE * IRS;
   const int hh = lane >> 5, r = lane & 31;
+  // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and
+  // lane i receives column i of the 4 rows.  Group g covers columns 16(g&1).., rows 8(g>>1)..; +4 rows for the
+  // second half of an 8-deep fragment, +16 rows for the second k-step, +32 columns for the second block.
+  const int tr_base = (8 * hh + ((lane >> 2) & 3)) * IRS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   // W2^T images for the second product: row k, and inside a row the 64 j in the order the first product's
   // accumulator hands them over: slot ((b*2+u)*2+half)*8 + jj  <->  j = 32b + (jj&3) + 8(2u + (jj>>2)) + 4 half
   for (int i = threadIdx.x; i < 64 * 64; i += X3_WAVES * 64) {
@@ -659,6 +736,8 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
       const float4 hi4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh + 1));
       const float f[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
       const Split3 hb = split8(f);
+      st_img8(HIh + r * IRS + 16 * s4 + 8 * hh, hb.hi);
+      st_img8(HIm + r * IRS + 16 * s4 + 8 * hh, hb.mid);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].lo, hb.hi, acc[b], 0, 0, 0);
@@ -671,7 +750,10 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     }
 
     if (FUSED_LOSS) {
-      // h2 = relu(C + b2) in place; the tile's logits; then loss and dL/dlogit per edge
+      // h2 = relu(C + b2) -> LDS (the weight-gradient product reads it); the tile's logits; the accumulator is
+      // overwritten with the masked w3 ([h2 > 0] w3[j]) while w3 is in registers anyway, so that once the
+      // edge's dL/dlogit is known G = g_e * (masked w3) is one multiply per element — no second pass over w3,
+      // no compare / select after the reduction
       float part = 0.f;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -686,39 +768,34 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           for (int c = 0; c < 4; ++c) {
             const int i = 4 * qd + c;
             const float h2 = fmaxf(acc[b][i] + bbv[c], 0.f);
-            acc[b][i] = h2;
             part = fmaf(h2, wwv[c], part);
             Gt[(j0 + c) * GS + r] = h2;
+            acc[b][i] = h2 > 0.f ? wwv[c] : 0.f;
           }
         }
-      part += __shfl_xor(part, 32);
+      part += __shfl_xor(part, 32);                 // both halves of the wave now hold edge r's logit
       const float xv = part + b3v;
       const float lw = 1.f + (pw - 1.f) * y_e;
-      const float t = expf(-fabsf(xv));
-      const float sig_neg = xv >= 0.f ? t / (1.f + t) : 1.f / (1.f + t);          // sigmoid(-x)
+      const float t = expf(-fabsf(xv));             // in (0, 1]
+      const float u = 1.f + t;
+      float ru = __builtin_amdgcn_rcpf(u);
+      ru = ru * (2.f - u * ru);                     // 1 / (1 + t), one Newton step on the hardware reciprocal
+      const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
       g_e = live ? ((1.f - y_e) - lw * sig_neg) * lp.inv_denom : 0.f;
-      if (lane < 32) {
-        gl[lane] = g_e;
-        gb3p += g_e;
-        if (live) {
-          lp.logits[ebase + r] = xv;
-          lossp += ((1.f - y_e) * xv + lw * (log1pf(t) + fmaxf(-xv, 0.f))) * lp.inv_denom;
-        }
-      }
-      // G[j][e] = g_e * w3[j] * [h2 > 0]  (A operand of the next product)
+      // softplus(-x) = log1p(t) + max(-x, 0);  log1p(t) = log(u) * t / (u - 1) with u = fl(1 + t) (exact u - 1),
+      // = t when u == 1
+      const float um1 = u - 1.f;
+      float rm = __builtin_amdgcn_rcpf(um1);
+      rm = rm * (2.f - um1 * rm);
+      const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
+      gl[r] = g_e;                                   // the two halves write the same value
+      gb3p += g_e;                                   // per-half partials; lane 0's half is the one read out
+      if (live) lossp += ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom;
+      if (hh == 0 && live) lp.logits[ebase + r] = xv;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int j0 = 32 * b + 8 * qd + 4 * hh;
-          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
-          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int i = 4 * qd + c;
-            acc[b][i] = acc[b][i] > 0.f ? g_e * wwv[c] : 0.f;
-          }
-        }
+        for (int i = 0; i < 16; ++i) acc[b][i] *= g_e;   // G[j][e]: A operand of the next product
     } else {
       // G[j][e] = g_e * w3[j] * [h2pre > 0]  (in place in acc; A operand of the next product);
       // h2[j][e] goes to LDS: the weight-gradient product rebuilds G and g_e * h2 from it
@@ -757,6 +834,9 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
         const float f[8] = {acc[b][8 * u + 0], acc[b][8 * u + 1], acc[b][8 * u + 2], acc[b][8 * u + 3],
                             acc[b][8 * u + 4], acc[b][8 * u + 5], acc[b][8 * u + 6], acc[b][8 * u + 7]};
         const Split3 ga = split8(f);
+        // registers 8u .. 8u+3 are j = 32b + 16u + 4hh + (0..3), 8u+4 .. 8u+7 the same + 8
+        st_img4x2(GIh + r * IRS + 32 * b + 16 * u + 4 * hh, ga.hi);
+        st_img4x2(GIm + r * IRS + 32 * b + 16 * u + 4 * hh, ga.mid);
 #pragma unroll
         for (int bp = 0; bp < 2; ++bp) {
           const unsigned short* row = Wt + (r + 32 * bp) * WTS + (((b * 2 + u) * 2 + hh) * 8);
@@ -769,8 +849,8 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.hi, w_hi, acc2[bp], 0, 0, 0);
         }
       }
-    // mask by h1 > 0, write dL/dh1pre, accumulate gcvec.  Full tiles (all but the last) store through
-    // one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
+    // mask by h1 > 0, write dL/dh1pre (kept in acc2 for the run sums), accumulate gcvec.  Full tiles store
+    // through one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
     {
       float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
       const bool full = ebase + TE <= a.E;
@@ -783,32 +863,53 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           const float hval = Ht[swz(e, k)];
           const float v = hval > 0.f ? acc2[bp][i] : 0.f;
           if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
-          if (a.extra) gcv[bp] = fmaf(wl[e], v, gcv[bp]);
-          if (RUNSUM) acc2[bp][i] = v;
+          acc2[bp][i] = v;
         }
+      if (a.extra) {                                 // uniform; only with skip connections
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) gcv[bp] = fmaf(wl[jr(i, hh)], acc2[bp][i], gcv[bp]);
+      }
     }
 
     if (tile + stride < n_tiles) issue_rows(a, ids_nxt, lane, rw);   // flies during the third product
 
-    // gW2[j][k] += sum_e G[j][e] h1[e][k]  : f32 MFMA, both operands from LDS, reduction over the tile's edges
+    // gW2[j][k] += sum_e G[j][e] h1[e][k] on the bf16 matrix pipe too: K = the tile's 32 edges (two k-steps),
+    // A = G and B = h1 come from the bf16 images written above (rows = edges) through transposing reads;
+    // two-way split operands, the three largest partial products (this product only feeds a gradient)
+    wave_lds_sync();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], am[2], bh[2], bm[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int off = tr_base + 16 * ks * IRS + 32 * x;
+        ah[x] = ld_tr8(GIh + off);
+        am[x] = ld_tr8(GIm + off);
+        bh[x] = ld_tr8(HIh + off);
+        bm[x] = ld_tr8(HIm + off);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mb], bh[nb], acc3[mb][nb], 0, 0, 0);
+          acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bm[nb], acc3[mb][nb], 0, 0, 0);
+          acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc3[mb][nb], 0, 0, 0);
+        }
+    }
+    // gb2[j] = sum_e G[j][e], gw3[j] = sum_e g_e h2[j][e]: lane j walks the f32 h2 image (vector work only)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int e = 2 * s + hh;
       const float ge = gl[e];
       const float x0 = Gt[r * GS + e];           // h2[j][e]
       const float x1 = Gt[(r + 32) * GS + e];
-      const float a0 = x0 > 0.f ? ge * w3j[0] : 0.f;
-      const float a1 = x1 > 0.f ? ge * w3j[1] : 0.f;
       gw3p[0] = fmaf(ge, x0, gw3p[0]);
       gw3p[1] = fmaf(ge, x1, gw3p[1]);
-      gb2p[0] += a0;
-      gb2p[1] += a1;
-      const float h0 = Ht[swz(e, r)];
-      const float h1v = Ht[swz(e, r + 32)];
-      acc3[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, h0, acc3[0][0], 0, 0, 0);
-      acc3[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, h1v, acc3[0][1], 0, 0, 0);
-      acc3[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h0, acc3[1][0], 0, 0, 0);
-      acc3[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, h1v, acc3[1][1], 0, 0, 0);
+      gb2p[0] += x0 > 0.f ? ge : 0.f;            // times w3[j] after the last tile
+      gb2p[1] += x1 > 0.f ? ge : 0.f;
     }
     if (RUNSUM) {
       // close a part at the last edge of every source run of the tile
@@ -856,6 +957,8 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   }
 
   // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
+  gb2p[0] *= w3j[0];
+  gb2p[1] *= w3j[1];
   gw3p[0] += __shfl_xor(gw3p[0], 32);
   gw3p[1] += __shfl_xor(gw3p[1], 32);
   gb2p[0] += __shfl_xor(gb2p[0], 32);
