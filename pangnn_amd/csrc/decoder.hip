@@ -627,7 +627,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     DecParams a, const float* __restrict__ g_logits, LossParams lp, RunSumParams rs, float* __restrict__ g_h1,
     float* __restrict__ slabs, int64_t n_tiles) {
   constexpr int IMG = TE * IRS / 2;                  // one bf16 image [32 edges][64] of the tile, in floats
-  constexpr int PER_WAVE = TE * RS + 64 * GS + 64 + 4 * IMG;   // Ht | H2t | w_e | g_e | G hi,mid | h1 hi,mid
+  constexpr int PER_WAVE = TE * RS + 64 + 4 * IMG;   // Ht | w_e | (pad) | G hi,mid | h1 hi,mid
   constexpr int WT_FLOATS = 2 * 64 * WTS / 2;        // two bf16 images [64][WTS] of W2^T (hi, mid)
   __shared__ __attribute__((aligned(16))) float lds[WT_FLOATS + 3 * 64 + X3_WAVES * PER_WAVE];
   unsigned short* Wt = reinterpret_cast<unsigned short*>(lds);
@@ -636,10 +636,8 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   float* cvl = w3l + 64;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR: tile index and its addresses stay scalar
   float* Ht = cvl + 64 + wave * PER_WAVE;
-  float* Gt = Ht + TE * RS;
-  float* wl = Gt + 64 * GS;
-  float* gl = wl + 32;
-  short* GIh = reinterpret_cast<short*>(gl + 32);   // G[j][e] as rows e, columns j (bf16 hi / mid): A operand of
+  float* wl = Ht + TE * RS;
+  short* GIh = reinterpret_cast<short*>(wl + 64);   // G[j][e] as rows e, columns j (bf16 hi / mid): A operand of
   short* GIm = GIh + TE * IRS;                      //   the third product through transposing reads
   short* HIh = GIm + TE * IRS;                      // h1[e][k] as rows e, columns k (bf16 hi / mid): its B operand
   short* HIm = HIh + TE * IRS;
@@ -685,9 +683,22 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc3[x][0][i] = 0.f; acc3[x][1][i] = 0.f; }
   }
-  const float w3j[2] = {w3l[r], w3l[r + 32]};
-  float gw3p[2] = {0.f, 0.f};   // lane (j = r+32bj, h): partial of gw3[j] over edges e = h mod 2
-  float gb2p[2] = {0.f, 0.f};   // same lanes: partial of gb2[j]
+  // b2 / w3 in the accumulator layout (register i of block b is j = 32b + jr(i, hh)): constants of the whole kernel.
+  // gw3 / gb2 partials live in the same layout, one per register and lane (= per (j, edge slot)); they are summed
+  // over tiles here and over the 32 edge slots once, after the last tile — no h2 image, no per-tile reduction.
+  float gw3a[2][16], gb2a[2][16];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gw3a[b][i] = 0.f;
+      gb2a[b][i] = 0.f;
+    }
+  // b2 / w3 of register i of block b (j = 32b + jr(i, hh)): 16-byte LDS reads, 4 registers at a time
+  auto ld4 = [&](const float* v, int b, int qd, float (&o)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(v + 32 * b + 8 * qd + 4 * hh);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  };
   float gcv[2] = {0.f, 0.f};    // lane (k = r+32bp, hh): partial of gcvec[k]
   float gb3p = 0.f;
   float lossp = 0.f;            // FUSED_LOSS: lanes < 32, partial of the (already 1/denom-scaled) loss
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
       if (lane < 32) wl[lane] = w_e;
     } else {
       g_e = aux_cur;
-      if (lane < 32) { wl[lane] = w_e; gl[lane] = g_e; gb3p += g_e; }
+      if (lane < 32) { wl[lane] = w_e; gb3p += g_e; }
     }
     wave_lds_sync();
 
@@ -750,27 +761,20 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     }
 
     if (FUSED_LOSS) {
-      // h2 = relu(C + b2) -> LDS (the weight-gradient product reads it); the tile's logits; the accumulator is
-      // overwritten with the masked w3 ([h2 > 0] w3[j]) while w3 is in registers anyway, so that once the
-      // edge's dL/dlogit is known G = g_e * (masked w3) is one multiply per element — no second pass over w3,
-      // no compare / select after the reduction
+      // h2 = relu(C + b2) in place; the tile's logits; then loss and dL/dlogit per edge
       float part = 0.f;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          const int j0 = 32 * b + 8 * qd + 4 * hh;
-          const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
-          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
-          const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
-          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+          float bbv[4], wwv[4];
+          ld4(b2l, b, qd, bbv);
+          ld4(w3l, b, qd, wwv);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const int i = 4 * qd + c;
-            const float h2 = fmaxf(acc[b][i] + bbv[c], 0.f);
+            const float h2 = relu1(acc[b][4 * qd + c] + bbv[c]);
+            acc[b][4 * qd + c] = h2;
             part = fmaf(h2, wwv[c], part);
-            Gt[(j0 + c) * GS + r] = h2;
-            acc[b][i] = h2 > 0.f ? wwv[c] : 0.f;
           }
         }
       part += __shfl_xor(part, 32);                 // both halves of the wave now hold edge r's logit
@@ -782,42 +786,41 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
       ru = ru * (2.f - u * ru);                     // 1 / (1 + t), one Newton step on the hardware reciprocal
       const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
       g_e = live ? ((1.f - y_e) - lw * sig_neg) * lp.inv_denom : 0.f;
-      // softplus(-x) = log1p(t) + max(-x, 0);  log1p(t) = log(u) * t / (u - 1) with u = fl(1 + t) (exact u - 1),
-      // = t when u == 1
-      const float um1 = u - 1.f;
+      const float um1 = u - 1.f;                    // log1p(t) = log(u) t / (u - 1), = t when u == 1
       float rm = __builtin_amdgcn_rcpf(um1);
       rm = rm * (2.f - um1 * rm);
       const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
-      gl[r] = g_e;                                   // the two halves write the same value
       gb3p += g_e;                                   // per-half partials; lane 0's half is the one read out
       if (live) lossp += ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom;
       if (hh == 0 && live) lp.logits[ebase + r] = xv;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[b][i] *= g_e;   // G[j][e]: A operand of the next product
     } else {
-      // G[j][e] = g_e * w3[j] * [h2pre > 0]  (in place in acc; A operand of the next product);
-      // h2[j][e] goes to LDS: the weight-gradient product rebuilds G and g_e * h2 from it
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          const int j0 = 32 * b + 8 * qd + 4 * hh;
-          const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
-          const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
-          const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
-          const float wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+          float bbv[4];
+          ld4(b2l, b, qd, bbv);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int i = 4 * qd + c;
-            const float pre = acc[b][i] + bbv[c];
-            const bool on = pre > 0.f;
-            acc[b][i] = on ? g_e * wwv[c] : 0.f;
-            Gt[(j0 + c) * GS + r] = on ? pre : 0.f;
-          }
+          for (int c = 0; c < 4; ++c) acc[b][4 * qd + c] = relu1(acc[b][4 * qd + c] + bbv[c]);
         }
     }
+    // gw3[j] += g_e h2[j][e];  gb2[j] += G[j][e] / w3[j];  G[j][e] = g_e w3[j] [h2 > 0] (A operand of the next product)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float wwv[4];
+        ld4(w3l, b, qd, wwv);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = 4 * qd + c;
+          const float h2 = acc[b][i];
+          gw3a[b][i] = fmaf(g_e, h2, gw3a[b][i]);
+          const float tg = h2 > 0.f ? g_e : 0.f;
+          gb2a[b][i] += tg;
+          acc[b][i] = tg * wwv[c];
+        }
+      }
     wave_lds_sync();
 
     // gH1[e][k] = sum_j G[j][e] W2[j][k]  : A = G from the accumulator registers, B = W2 rows
@@ -899,18 +902,6 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc3[mb][nb], 0, 0, 0);
         }
     }
-    // gb2[j] = sum_e G[j][e], gw3[j] = sum_e g_e h2[j][e]: lane j walks the f32 h2 image (vector work only)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int e = 2 * s + hh;
-      const float ge = gl[e];
-      const float x0 = Gt[r * GS + e];           // h2[j][e]
-      const float x1 = Gt[(r + 32) * GS + e];
-      gw3p[0] = fmaf(ge, x0, gw3p[0]);
-      gw3p[1] = fmaf(ge, x1, gw3p[1]);
-      gb2p[0] += x0 > 0.f ? ge : 0.f;            // times w3[j] after the last tile
-      gb2p[1] += x1 > 0.f ? ge : 0.f;
-    }
     if (RUNSUM) {
       // close a part at the last edge of every source run of the tile
       const int id_nxt = __shfl(id, (lane + 1) & 63);
@@ -957,12 +948,17 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   }
 
   // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
-  gb2p[0] *= w3j[0];
-  gb2p[1] *= w3j[1];
-  gw3p[0] += __shfl_xor(gw3p[0], 32);
-  gw3p[1] += __shfl_xor(gw3p[1], 32);
-  gb2p[0] += __shfl_xor(gb2p[0], 32);
-  gb2p[1] += __shfl_xor(gb2p[1], 32);
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gb2a[b][i] *= w3l[32 * b + jr(i, hh)];
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {      // over the 32 edge slots of this half (fixed tree)
+        gw3a[b][i] += __shfl_xor(gw3a[b][i], off);
+        gb2a[b][i] += __shfl_xor(gb2a[b][i], off);
+      }
+    }
   gcv[0] += __shfl_xor(gcv[0], 32);
   gcv[1] += __shfl_xor(gcv[1], 32);
 #pragma unroll
@@ -985,13 +981,20 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
             const int idx = (32 * bj + jr(i, hh)) * 64 + r + 32 * bk;
             red[idx] = (first ? 0.f : red[idx]) + acc3[bj][bk][i];
           }
+      if (r == 0) {                                    // lane 0 / 32: the j's of its half, summed over edges
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int j = 32 * b + jr(i, hh);
+            red[4096 + j] = (first ? 0.f : red[4096 + j]) + gb2a[b][i];
+            red[4096 + 64 + j] = (first ? 0.f : red[4096 + 64 + j]) + gw3a[b][i];
+          }
+      }
       if (hh == 0) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          red[4096 + r + 32 * x] = (first ? 0.f : red[4096 + r + 32 * x]) + gb2p[x];
-          red[4096 + 64 + r + 32 * x] = (first ? 0.f : red[4096 + 64 + r + 32 * x]) + gw3p[x];
+        for (int x = 0; x < 2; ++x)
           red[4096 + 128 + r + 32 * x] = (first ? 0.f : red[4096 + 128 + r + 32 * x]) + gcv[x];
-        }
       }
       if (lane == 0) {
         red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
