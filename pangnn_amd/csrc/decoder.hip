@@ -175,7 +175,7 @@ constexpr int BWD_WAVES = 8;    // 512 threads, 1 workgroup / CU, 2 waves / SIMD
 
 // ---- software-pipelined gather: edge ids two tiles ahead, node rows one tile ahead, so a wave never
 // waits on HBM between two MFMA phases (the rows of tile t+1 land while tile t is in the matrix pipe).
-struct TileIds { int id; float w_e; };
+struct TileIds { int id; float w_e; uint32_t row_off; };     // row_off: byte offset of the lane's node row in P / Q
 struct TileRows { float4 pv[8]; float4 qv[8]; float wv[8]; };
 
 __device__ __forceinline__ TileIds load_ids(const DecParams& a, int64_t tile, int64_t n_tiles, int lane) {
@@ -187,37 +187,44 @@ __device__ __forceinline__ TileIds load_ids(const DecParams& a, int64_t tile, in
     t.id = (int)a.ei[(int64_t)(lane >> 5) * a.ld + e];   // lanes 0-31: source, 32-63: target
     if (a.extra && lane < 32) t.w_e = a.extra[e];
   }
+  t.row_off = (uint32_t)t.id * ((lane >> 5) ? a.ldq4 : a.ldp4) * 16u;
   return t;
 }
 
 __device__ __forceinline__ void issue_rows(const DecParams& a, const TileIds& t, int lane, TileRows& rw) {
-  const int c4 = lane & 15, r4 = lane >> 4;
-  const float4* P4 = reinterpret_cast<const float4*>(a.p);
-  const float4* Q4 = reinterpret_cast<const float4*>(a.q);
+  const int r4 = lane >> 4;
+  const uint32_t col_off = 16u * (lane & 15);
+  const bool has_extra = a.extra != nullptr;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = 4 * i + r4;
-    const int s = __shfl(t.id, row);
-    const int d = __shfl(t.id, 32 + row);
-    rw.wv[i] = __shfl(t.w_e, row);
-    rw.pv[i] = P4[(uint32_t)s * a.ldp4 + c4];
-    rw.qv[i] = Q4[(uint32_t)d * a.ldq4 + c4];
+    rw.wv[i] = has_extra ? __shfl(t.w_e, row) : 0.f;
+    rw.pv[i] = ld_row16(a.p, (uint32_t)__shfl((int)t.row_off, row) + col_off);
+    rw.qv[i] = ld_row16(a.q, (uint32_t)__shfl((int)t.row_off, 32 + row) + col_off);
   }
 }
 
 __device__ __forceinline__ void commit_rows(const DecParams& a, const TileRows& rw, int lane, const float* cvl,
                                             float* Ht) {
   const int c4 = lane & 15, r4 = lane >> 4;
+  const bool has_extra = a.extra != nullptr;
   float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.extra) cv = reinterpret_cast<const float4*>(cvl)[c4];
+  if (has_extra) cv = reinterpret_cast<const float4*>(cvl)[c4];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = 4 * i + r4;
     float4 h;
-    h.x = fmaxf(rw.pv[i].x + rw.qv[i].x + rw.wv[i] * cv.x, 0.f);
-    h.y = fmaxf(rw.pv[i].y + rw.qv[i].y + rw.wv[i] * cv.y, 0.f);
-    h.z = fmaxf(rw.pv[i].z + rw.qv[i].z + rw.wv[i] * cv.z, 0.f);
-    h.w = fmaxf(rw.pv[i].w + rw.qv[i].w + rw.wv[i] * cv.w, 0.f);
+    h.x = rw.pv[i].x + rw.qv[i].x;
+    h.y = rw.pv[i].y + rw.qv[i].y;
+    h.z = rw.pv[i].z + rw.qv[i].z;
+    h.w = rw.pv[i].w + rw.qv[i].w;
+    if (has_extra) {
+      h.x = fmaf(rw.wv[i], cv.x, h.x);
+      h.y = fmaf(rw.wv[i], cv.y, h.y);
+      h.z = fmaf(rw.wv[i], cv.z, h.z);
+      h.w = fmaf(rw.wv[i], cv.w, h.w);
+    }
+    h.x = relu1(h.x); h.y = relu1(h.y); h.z = relu1(h.z); h.w = relu1(h.w);
     *reinterpret_cast<float4*>(Ht + swz4(row, c4)) = h;
   }
 }
@@ -714,7 +721,8 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   if (tile < n_tiles && tile * TE + r < a.E) aux_cur = FUSED_LOSS ? lp.y[tile * TE + r] : g_logits[tile * TE + r];
   TileRows rw;
   issue_rows(a, ids_cur, lane, rw);
-  for (; tile < n_tiles; tile += stride) {
+  auto tile_body = [&](auto full_c) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;     // all 32 edges of the tile exist: no bounds predicates
     const int64_t ebase = tile * TE;
     commit_rows(a, rw, lane, cvl, Ht);
     const float w_e = ids_cur.w_e;
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
       aux_nxt = FUSED_LOSS ? lp.y[(tile + stride) * TE + r] : g_logits[(tile + stride) * TE + r];
     float g_e = 0.f;
     float y_e = 0.f;
-    const bool live = ebase + r < a.E;
+    const bool live = FULL || ebase + r < a.E;
     if (FUSED_LOSS) {
       y_e = aux_cur;
       if (lane < 32) wl[lane] = w_e;
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     // through one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
     {
       float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
-      const bool full = ebase + TE <= a.E;
+      const bool full = FULL || ebase + TE <= a.E;
 #pragma unroll
       for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
@@ -905,8 +913,8 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     if (RUNSUM) {
       // close a part at the last edge of every source run of the tile
       const int id_nxt = __shfl(id, (lane + 1) & 63);
-      const bool ok = lane < 32 && ebase + lane < a.E;
-      const bool ok_nxt = lane < 31 && ebase + lane + 1 < a.E;
+      const bool ok = lane < 32 && (FULL || ebase + lane < a.E);
+      const bool ok_nxt = lane < 31 && (FULL || ebase + lane + 1 < a.E);
       const unsigned long long mask = __ballot(ok && (!ok_nxt || id != id_nxt));
       const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask & 0xffffffffull));
       int64_t pidx = rs.part_off[tile];
@@ -942,10 +950,13 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
         }
       }
     }
-    wave_lds_sync();   // next tile overwrites Ht / Gt / wl
+    wave_lds_sync();   // next tile overwrites Ht / wl / the images
     ids_cur = ids_nxt;
     aux_cur = aux_nxt;
-  }
+  };
+  const int64_t n_full = a.E / TE;
+  for (; tile < n_full; tile += stride) tile_body(std::true_type{});
+  if (tile < n_tiles) tile_body(std::false_type{});     // the partial tile, when it is this wave's turn
 
   // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
 #pragma unroll
