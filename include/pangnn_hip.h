@@ -155,9 +155,12 @@ int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t
  *   index of the tile's first part, i.e. the number of k < 32*tile with k % 32 == 0 or src_k != src_{k-1}.
  *   g_p[s] is then the sum of the consecutive parts of source s (pangnn_spmm_csr_f32 with idx == NULL).
  *   precision: 0 = every product on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains);
- *              1 = the first two products on the bf16 matrix pipe with three-way operand splitting
- *                  (hi + mid + lo = 24 mantissa bits, six partial products, fp32 accumulation): fp32-level
- *                  error, but not bit-identical to mode 0.
+ *              1 = every product on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) with the fp32 operands
+ *                  split into bf16 terms and fp32 accumulation: the logit product and dL/dh1 with hi + mid + lo
+ *                  (24 significand bits; the six largest partial products, five where W2 is split two-way),
+ *                  dL/dW2 with hi + mid of both operands.  fp32-level error (logits within 2e-5 of fp64 in the
+ *                  tests), not bit-identical to mode 0; 0.78x its time, because the f32 MFMA occupies the
+ *                  SIMD's vector lanes while the bf16 one leaves them to the epilogues.
  * ---------------------------------------------------------------------------------------- */
 int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                const int64_t* edge_index, int64_t ld, int64_t num_edges,

@@ -80,9 +80,13 @@ __device__ __forceinline__ void stage_weights(const DecParams& a, float* Wl, flo
 // FULL: all 32 edges exist (every tile but the last): no bounds predicate on the id loads.
 // max(x, 0) as ONE instruction: fmaxf() makes the compiler put a canonicalising v_max(x, x) in front of it
 __device__ __forceinline__ float relu1(float x) {
+#ifdef PANGNN_NO_ASM_RELU
+  return fmaxf(x, 0.f);
+#else
   float y;
   asm("v_max_f32 %0, %1, 0" : "=v"(y) : "v"(x));
   return y;
+#endif
 }
 
 // 16-byte row piece at `table + byte_off`: uniform base pointer + 32-bit per-lane byte offset (node tables are
@@ -860,30 +864,6 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.hi, w_hi, acc2[bp], 0, 0, 0);
         }
       }
-    // mask by h1 > 0, write dL/dh1pre (kept in acc2 for the run sums), accumulate gcvec.  Full tiles store
-    // through one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
-    {
-      float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
-      const bool full = FULL || ebase + TE <= a.E;
-#pragma unroll
-      for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int e = jr(i, hh);
-          const int k = r + 32 * bp;
-          const float hval = Ht[swz(e, k)];
-          const float v = hval > 0.f ? acc2[bp][i] : 0.f;
-          if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
-          acc2[bp][i] = v;
-        }
-      if (a.extra) {                                 // uniform; only with skip connections
-#pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) gcv[bp] = fmaf(wl[jr(i, hh)], acc2[bp][i], gcv[bp]);
-      }
-    }
-
     if (tile + stride < n_tiles) issue_rows(a, ids_nxt, lane, rw);   // flies during the third product
 
     // gW2[j][k] += sum_e G[j][e] h1[e][k] on the bf16 matrix pipe too: K = the tile's 32 edges (two k-steps),
@@ -910,6 +890,32 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc3[mb][nb], 0, 0, 0);
         }
     }
+    // (the third product sits BEFORE the bounds-predicated stores below: its transposing reads need every lane
+    // active, and in the partial tile the compiler may otherwise schedule them into a predicated region)
+    // mask by h1 > 0, write dL/dh1pre (kept in acc2 for the run sums), accumulate gcvec.  Full tiles store
+    // through one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
+    {
+      float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
+      const bool full = FULL || ebase + TE <= a.E;
+#pragma unroll
+      for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int e = jr(i, hh);
+          const int k = r + 32 * bp;
+          const float hval = Ht[swz(e, k)];
+          const float v = hval > 0.f ? acc2[bp][i] : 0.f;
+          if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
+          acc2[bp][i] = v;
+        }
+      if (a.extra) {                                 // uniform; only with skip connections
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) gcv[bp] = fmaf(wl[jr(i, hh)], acc2[bp][i], gcv[bp]);
+      }
+    }
+
     if (RUNSUM) {
       // close a part at the last edge of every source run of the tile
       const int id_nxt = __shfl(id, (lane + 1) & 63);
@@ -955,8 +961,13 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     aux_cur = aux_nxt;
   };
   const int64_t n_full = a.E / TE;
+#ifdef PANGNN_X3_NOFULL
+  (void)n_full;
+  for (; tile < n_tiles; tile += stride) tile_body(std::false_type{});
+#else
   for (; tile < n_full; tile += stride) tile_body(std::true_type{});
   if (tile < n_tiles) tile_body(std::false_type{});     // the partial tile, when it is this wave's turn
+#endif
 
   // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
 #pragma unroll

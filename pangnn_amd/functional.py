@@ -22,8 +22,11 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 KERNEL_TIMER = None
 
 # Matrix-pipe mode of the decoder backward / training kernel (include/pangnn_hip.h, `precision`):
-# 0 = f32 MFMA everywhere, 1 = bf16 MFMA with three-way split operands for the first two products.
-DECODER_PRECISION = 0
+# 1 (default) = every product on the bf16 matrix pipe with operands split into bf16 terms (hi + mid + lo carries
+#     the 24 significand bits; partial products accumulated in fp32) — fp32-level error (tests: 2e-5 on logits
+#     against fp64), 0.78x the time of mode 0 because f32 MFMA shares the SIMD's vector lanes;
+# 0 = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fp32 FMA chains).
+DECODER_PRECISION = 1
 
 
 def _timer_start(tag):

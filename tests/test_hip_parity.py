@@ -739,9 +739,10 @@ class _precision:
 
 @pytest.mark.parametrize("e", [1, 33, 1000, 70001])
 @pytest.mark.parametrize("skip", [False, True])
-def test_bf16x3_decoder_backward_vs_fp64(e, skip):
-    """precision = 1 (three-way bf16 split on the matrix pipe) must stay at fp32-level error: checked against
-    an fp64 torch evaluation with the same bounds as the f32-MFMA kernel"""
+@pytest.mark.parametrize("mode", [1, 0], ids=["bf16x3", "f32mfma"])
+def test_decoder_training_kernels_vs_fp64(e, skip, mode):
+    """both matrix-pipe modes of the training decoder against an fp64 torch evaluation, same bounds: precision = 1
+    (bf16 terms of the fp32 operands on the matrix pipe, the default) must stay at fp32-level error"""
     from pangnn_amd import functional as PF
     from pangnn_amd.graph import EdgeStructure
     torch.manual_seed(e + skip)
@@ -761,7 +762,7 @@ def test_bf16x3_decoder_backward_vs_fp64(e, skip):
     lref = torch.nn.functional.binary_cross_entropy_with_logits(ref, y.double(), pos_weight=pw.double())
     lref.backward()
     st = EdgeStructure(ei.to(dev()), n)
-    with _precision(1):
+    with _precision(mode):
         gl = [t.clone().to(dev()).requires_grad_(True) for t in (P, Q, W2, b2, w3, b3, cv)]
         loss, logits = PF.decoder_loss(gl[0], gl[1], st, extra.to(dev()) if skip else None, gl[6] if skip else None,
                                        gl[2], gl[3], gl[4], gl[5], y.to(dev()), pw.to(dev()), e)
