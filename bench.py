@@ -241,17 +241,24 @@ def main():
                          "bwd_avg_launch_ms": (sum(k_bwd) / len(k_bwd)) * 1e3 if k_bwd else None},
         }
         if d_bwd:
-            # the decoder kernel is bound by the f32 matrix pipe, not by HBM: report it against the dense
-            # f32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s).  2*64*64 flop per edge per product; the
-            # training pass (logits + BCE + all gradients in one kernel) runs 3 products per edge:
-            # W2 h1, dL/dh1 = G^T W2, dL/dW2 += G h1.  (`fwd_*` is null when no separate forward ran.)
+            # The decoder kernel (largest of the step): logits + BCE + all gradients in one pass, three 64-wide
+            # products per edge (W2 h1, dL/dh1 = G^T W2, dL/dW2 += G h1) = 3 * 2*64*64 fp32-equivalent flop.
+            # Default mode runs them on the bf16 matrix pipe with the fp32 operands split into bf16 terms
+            # (6 + 5 + 3 partial products): 112 v_mfma_f32_32x32x16_bf16 per 32-edge tile are EXECUTED; that
+            # count is priced against the dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s).  The kernel
+            # is bound by vector-ALU issue (operand splitting, epilogues), not by the matrix pipe.
+            from pangnn_amd import functional as _PF
             e_loc = getattr(graph, "e_sim_local", e_sim)
             tb, tfw = sum(d_bwd) / len(d_bwd), sum(d_fwd) / max(len(d_fwd), 1)
+            x3 = _PF.DECODER_PRECISION == 1
+            executed = (112 * 32 * 32 * 16 * 2 / 32.0 if x3 else 3 * 8192) * e_loc
+            peak = 2500.0 if x3 else 157.3
             line["roofline_decoder"] = {
-                "bound": "mfma", "kernel": "decoder_bwd_kernel<fused loss> (largest single kernel of the step)",
-                "achieved": 3 * 8192 * e_loc / tb / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                "frac": 3 * 8192 * e_loc / tb / 157.3e12, "avg_launch_ms": tb * 1e3,
-                "fwd_achieved": 8192 * e_loc / tfw / 1e12 if tfw > 0 else None,
+                "bound": "mfma",
+                "kernel": ("decoder_bwd_x3_kernel<fused loss> (bf16 matrix pipe, split fp32 operands)" if x3 else
+                           "decoder_bwd_kernel<fused loss> (f32 MFMA)"),
+                "achieved": executed / tb / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": executed / tb / 1e12 / peak,
+                "fp32_equivalent_tflops": 3 * 8192 * e_loc / tb / 1e12, "avg_launch_ms": tb * 1e3,
                 "fwd_avg_launch_ms": tfw * 1e3 if tfw > 0 else None}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, d, h)
