@@ -231,7 +231,7 @@ def main():
             "config": {"workload": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf}, whole graph as one batch, "
                                    f"node_dim={d} hidden_dim={h}, AlternateGCN default topology, mlp decoder",
                        "nodes": n, "sim_edges": e_sim, "neighbour_edges": e_nb,
-                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, all-gather/reduce-scatter",
+                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, halo rows by all-to-all-v (conv_in needs no exchange)",
                        "graph_build_s": round(t_gen, 3), "warmup_incl_structure_s": round(t_struct, 3),
                        "final_loss": float(loss.item())},
             "roofline": {"bound": "hbm", "kernel": f"spmm_row_kernel<{f_spmm}> (conv_in propagate fwd)",
