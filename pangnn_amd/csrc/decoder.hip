@@ -723,6 +723,9 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   TileIds ids_cur = load_ids(a, tile, n_tiles, lane);
   float aux_cur = 0.f;      // y_e (fused loss) or upstream dL/dlogit_e of this lane's edge
   if (tile < n_tiles && tile * TE + r < a.E) aux_cur = FUSED_LOSS ? lp.y[tile * TE + r] : g_logits[tile * TE + r];
+  // index of the tile's first run part: fetched one tile ahead like the ids (a wave has nothing else to hide a
+  // load-and-use behind: fetched where it is used it cost 1.2 ms of the kernel)
+  int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile] : 0;
   TileRows rw;
   issue_rows(a, ids_cur, lane, rw);
   auto tile_body = [&](auto full_c) __attribute__((always_inline)) {
@@ -732,6 +735,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     const float w_e = ids_cur.w_e;
     const int id = ids_cur.id;
     const TileIds ids_nxt = load_ids(a, tile + stride, n_tiles, lane);
+    const int poff_nxt = (RUNSUM && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
     float aux_nxt = 0.f;
     if (tile + stride < n_tiles && (tile + stride) * TE + r < a.E)
       aux_nxt = FUSED_LOSS ? lp.y[(tile + stride) * TE + r] : g_logits[(tile + stride) * TE + r];
@@ -870,6 +874,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
     // A = G and B = h1 come from the bf16 images written above (rows = edges) through transposing reads;
     // two-way split operands, the three largest partial products (this product only feeds a gradient)
     wave_lds_sync();
+#ifndef PANGNN_X3_ABL_P3
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[2], am[2], bh[2], bm[2];
@@ -890,6 +895,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc3[mb][nb], 0, 0, 0);
         }
     }
+#endif
     // (the third product sits BEFORE the bounds-predicated stores below: its transposing reads need every lane
     // active, and in the partial tile the compiler may otherwise schedule them into a predicated region)
     // mask by h1 > 0, write dL/dh1pre (kept in acc2 for the run sums), accumulate gcvec.  Full tiles store
@@ -905,7 +911,9 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           const int k = r + 32 * bp;
           const float hval = Ht[swz(e, k)];
           const float v = hval > 0.f ? acc2[bp][i] : 0.f;
+#ifndef PANGNN_X3_ABL_STORE
           if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
+#endif
           acc2[bp][i] = v;
         }
       if (a.extra) {                                 // uniform; only with skip connections
@@ -916,6 +924,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
       }
     }
 
+#ifndef PANGNN_X3_ABL_RUNSUM
     if (RUNSUM) {
       // close a part at the last edge of every source run of the tile
       const int id_nxt = __shfl(id, (lane + 1) & 63);
@@ -923,7 +932,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
       const bool ok_nxt = lane < 31 && (FULL || ebase + lane + 1 < a.E);
       const unsigned long long mask = __ballot(ok && (!ok_nxt || id != id_nxt));
       const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask & 0xffffffffull));
-      int64_t pidx = rs.part_off[tile];
+      int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
       if ((m & (m - 1u)) == 0u) {
         // one run covers the tile (the common case at degree >> 32): column sums straight from registers
         float s0 = 0.f, s1 = 0.f;
@@ -956,9 +965,11 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
         }
       }
     }
+#endif
     wave_lds_sync();   // next tile overwrites Ht / wl / the images
     ids_cur = ids_nxt;
     aux_cur = aux_nxt;
+    poff_cur = poff_nxt;
   };
   const int64_t n_full = a.E / TE;
 #ifdef PANGNN_X3_NOFULL
