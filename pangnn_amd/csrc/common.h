@@ -32,4 +32,27 @@ constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 
+// Second stage of the two-stage reductions (per-workgroup partial rows -> one row), reproducible and short:
+// a 1024-thread block owns 64 consecutive elements; wave g adds parts g, g+16, g+32, ... in that order, then the
+// 16 wave sums are added in wave order.  (One thread walking all parts serially took 60-240 us per call.)
+// Launch with kSumThreads threads and (len + 63) / 64 blocks; the result is valid in wave 0 (threadIdx.x < 64).
+constexpr int kSumGroups = 16;
+constexpr int kSumThreads = kSumGroups * kWave;
+#ifdef __HIPCC__
+__device__ __forceinline__ float ordered_parts_sum(const float* __restrict__ part, int n_parts, int64_t stride, int i,
+                                                   int len) {
+  __shared__ float red[kSumGroups][kWave];
+  const int e = threadIdx.x & (kWave - 1), g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (i < len)
+    for (int p = g; p < n_parts; p += kSumGroups) s += part[(int64_t)p * stride + i];
+  red[g][e] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (g == 0)
+    for (int k = 0; k < kSumGroups; ++k) t += red[k][e];
+  return t;
+}
+#endif
+
 }  // namespace pangnn

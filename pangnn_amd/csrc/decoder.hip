@@ -1041,17 +1041,16 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
 }
 
 // out[i] = sum over workgroup slabs in index order (fixed => reproducible)
-__global__ __launch_bounds__(kBlock) void decoder_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+__global__ __launch_bounds__(kSumThreads) void decoder_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
                                                                 float* __restrict__ g_w2,
                                                                 float* __restrict__ g_b2,
                                                                 float* __restrict__ g_w3,
                                                                 float* __restrict__ g_cvec,
                                                                 float* __restrict__ g_b3,
                                                                 float* __restrict__ loss) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= 4096 + 194) return;
-  float s = 0.f;
-  for (int w = 0; w < n_slabs; ++w) s += slabs[(int64_t)w * SLAB + i];
+  const int i = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const float s = ordered_parts_sum(slabs, n_slabs, SLAB, i, 4096 + 194);
+  if (threadIdx.x >= kWave || i >= 4096 + 194) return;
   if (i < 4096) g_w2[i] = s;
   else if (i < 4096 + 64) g_b2[i - 4096] = s;
   else if (i < 4096 + 128) g_w3[i - 4096 - 64] = s;
@@ -1155,7 +1154,7 @@ static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, in
     else hipLaunchKernelGGL((decoder_bwd_kernel<false, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     PG_CHECK_LAUNCH(who);
   }
-  hipLaunchKernelGGL(decoder_reduce_kernel, dim3((4096 + 194 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+  hipLaunchKernelGGL(decoder_reduce_kernel, dim3((4096 + 194 + kWave - 1) / kWave), dim3(kSumThreads), 0, s,
                      static_cast<const float*>(workspace), (int)grid, g_w2, g_b2, g_w3, g_cvec, g_b3, loss);
   PG_CHECK_LAUNCH(who);
   return 0;

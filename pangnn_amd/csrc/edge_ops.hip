@@ -274,13 +274,11 @@ __global__ __launch_bounds__(kBlock) void weighted_colsum_kernel(const float* __
   }
 }
 
-__global__ __launch_bounds__(kBlock) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int F,
-                                                               float* __restrict__ out) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= 2 * F) return;
-  float t = 0.f;
-  for (int b = 0; b < nblocks; ++b) t += partial[(int64_t)b * 2 * F + i];
-  out[i] = t;
+__global__ __launch_bounds__(kSumThreads) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks,
+                                                                    int F, float* __restrict__ out) {
+  const int i = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const float t = ordered_parts_sum(partial, nblocks, 2 * F, i, 2 * F);
+  if (threadIdx.x < kWave && i < 2 * F) out[i] = t;
 }
 
 static inline unsigned grid_for(int64_t total) {
@@ -485,7 +483,7 @@ extern "C" int pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const flo
     hipLaunchKernelGGL(weighted_colsum_kernel<1>, dim3(blocks), dim3(kBlock), 0, st, g, ldg, r, s, n, (int)F,
                        static_cast<float*>(workspace));
   PG_CHECK_LAUNCH("pangnn_weighted_colsum_f32");
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * F + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * F + kWave - 1) / kWave), dim3(kSumThreads), 0, st,
                      static_cast<const float*>(workspace), blocks, (int)F, out);
   PG_CHECK_LAUNCH("pangnn_weighted_colsum_f32(finish)");
   return 0;

@@ -301,14 +301,13 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   for (int i = threadIdx.x; i < SLAB; i += 256) slab[i] = red[i];
 }
 
-__global__ __launch_bounds__(kBlock) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
-                                                             int slab_len, int split,
-                                                             float* __restrict__ out0,
-                                                             float* __restrict__ out1) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= slab_len) return;
-  float s = 0.f;
-  for (int wv = 0; wv < n_slabs; ++wv) s += slabs[(int64_t)wv * slab_len + i];
+__global__ __launch_bounds__(kSumThreads) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                                  int slab_len, int split,
+                                                                  float* __restrict__ out0,
+                                                                  float* __restrict__ out1) {
+  const int i = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const float s = ordered_parts_sum(slabs, n_slabs, slab_len, i, slab_len);
+  if (threadIdx.x >= kWave || i >= slab_len) return;
   if (i < split) out0[i] = s;
   else if (out1) out1[i - split] = s;
 }
@@ -349,7 +348,7 @@ static int launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
   hipLaunchKernelGGL((linear_wgrad_kernel<K, M>), dim3((unsigned)grid), dim3(256), 0, s, g, ldg, x, ldx, n,
                      n_tiles, ws);
   PG_CHECK_LAUNCH("pangnn_linear_wgrad_f32");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ws, (int)grid,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB + kWave - 1) / kWave), dim3(kSumThreads), 0, s, ws, (int)grid,
                      SLAB, M * K, gw, gb);
   PG_CHECK_LAUNCH("pangnn_linear_wgrad_f32(reduce)");
   return 0;
