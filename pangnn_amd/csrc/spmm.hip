@@ -106,6 +106,46 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
   }
 }
 
+// Thin rows (the positional-neighbour graph has 3 entries per row, the per-source run parts of the decoder
+// 2-3): one wave per row would use 3 of the 64 / G row slots of a wave-instruction and retire after one step.
+// Here a group of G = F/4 lanes owns a row (64/G rows per wave) and walks its entries serially; the index and
+// weight loads of a group hit one address (broadcast), the row gather is the same 16-byte-per-lane access.
+template <int F, bool BIG>
+__global__ __launch_bounds__(kBlock) void spmm_thin_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ bias, float* __restrict__ out,
+    int64_t ldo, int64_t n_rows, int accumulate) {
+  constexpr int G = F / 4;
+  constexpr int RPB = kBlock / G;       // rows per workgroup
+  const int fl = threadIdx.x % G;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  if (row >= n_rows) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const char* xbase = reinterpret_cast<const char*>(x) + fl * 16;
+  const uint32_t ldx_b32 = (uint32_t)(ldx * 4);
+  for (int64_t e = beg; e < end; ++e) {
+    const int c = idx ? idx[e] : (int)e;
+    const float v = val ? val[e] : 1.f;
+    const float4 xv = BIG ? *reinterpret_cast<const float4*>(xbase + (int64_t)c * ldx * 4)
+                          : *reinterpret_cast<const float4*>(xbase + (uint32_t)c * ldx_b32);
+    acc.x = fmaf(v, xv.x, acc.x);
+    acc.y = fmaf(v, xv.y, acc.y);
+    acc.z = fmaf(v, xv.z, acc.z);
+    acc.w = fmaf(v, xv.w, acc.w);
+  }
+  if (bias) {
+    const float4 b = reinterpret_cast<const float4*>(bias)[fl];
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  }
+  float4* o = reinterpret_cast<float4*>(out + row * ldo) + fl;
+  if (accumulate) {
+    const float4 p = *o;
+    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+  }
+  *o = acc;
+}
+
 // Any feature width: lanes stride over features, edges serial.  Correctness path for odd F.
 __global__ __launch_bounds__(kBlock) void spmm_row_generic_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
@@ -144,6 +184,23 @@ static int launch_spmm(const int64_t* rowptr, const int32_t* idx, const float* v
   return 0;
 }
 
+template <int F>
+static int launch_thin(const int64_t* rowptr, const int32_t* idx, const float* val, const float* x,
+                       int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
+                       int64_t n_rows, int accumulate, hipStream_t s) {
+  constexpr int RPB = kBlock / (F / 4);
+  const int64_t blocks = (n_rows + RPB - 1) / RPB;
+  const bool big = (double)n_src_rows * (double)ldx * 4.0 >= 4294967296.0;
+  if (big)
+    hipLaunchKernelGGL((spmm_thin_kernel<F, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       rowptr, idx, val, x, ldx, bias, out, ldo, n_rows, accumulate);
+  else
+    hipLaunchKernelGGL((spmm_thin_kernel<F, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       rowptr, idx, val, x, ldx, bias, out, ldo, n_rows, accumulate);
+  PG_CHECK_LAUNCH("pangnn_spmm_csr_f32(thin)");
+  return 0;
+}
+
 }  // namespace pangnn
 
 using namespace pangnn;
@@ -165,18 +222,18 @@ extern "C" int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, co
   hipStream_t s = (hipStream_t)stream;
   const bool vec_ok = aligned16(x) && aligned16(out) && (!bias || aligned16(bias)) &&
                       (ldx % 4 == 0) && (ldo % 4 == 0);
-  // Rows that average fewer entries than one unrolled step holds (the positional-neighbour graph has 3
-  // per row) gain nothing from keeping 4 gathers per lane in flight: U = 1 for them, U = 4 otherwise.
+  // Rows that average fewer than 8 entries (the positional-neighbour graph has 3 per row) go to the kernel
+  // that packs 64/G rows into a wave; everything else to the wave-per-row kernel with 4 gathers in flight.
   const bool thin = nnz >= 0 && nnz < 8 * n_rows;
   if (vec_ok) {
     switch (F) {
       case 16:  return launch_spmm<16, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       case 32:  return launch_spmm<32, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       case 64:
-        if (thin) return launch_spmm<64, 1>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+        if (thin) return launch_thin<64>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
         return launch_spmm<64, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       case 128:
-        if (thin) return launch_spmm<128, 1>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+        if (thin) return launch_thin<128>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
         return launch_spmm<128, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       case 256: return launch_spmm<256, 4>(rowptr, idx, val, x, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
       default: break;

@@ -68,7 +68,8 @@ def test_gcn_norm_matches_oracle(weighted):
 
 # ---------------------------------------------------------------- propagate (the ★ kernel)
 @pytest.mark.parametrize("F", [16, 32, 64, 128, 256, 20, 3])
-@pytest.mark.parametrize("n,e,hub", [(64, 0, None), (1, 5, None), (513, 7000, 3000), (2000, 30000, None)])
+@pytest.mark.parametrize("n,e,hub", [(64, 0, None), (1, 5, None), (513, 7000, 3000), (2000, 30000, None),
+                                     (3001, 9000, None), (700, 5000, 900)])      # last two: thin rows (< 8 per row)
 def test_spmm_forward_backward_match_oracle(F, n, e, hub):
     import pangnn_amd
     from pangnn_amd import functional as PF
