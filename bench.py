@@ -237,6 +237,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"spmm_row_kernel<{f_spmm}> (conv_in propagate fwd)",
                          "achieved": b_alg / t_k / 1e9 if t_k > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": (b_alg / t_k) / HBM_PEAK if t_k > 0 else None, "traffic": traffic,
+                         "hbm_side_frac": (traffic / t_k) / HBM_PEAK if (traffic and t_k > 0) else None,
                          "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_k * 1e3,
                          "bwd_avg_launch_ms": (sum(k_bwd) / len(k_bwd)) * 1e3 if k_bwd else None},
         }
