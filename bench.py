@@ -178,7 +178,8 @@ def main():
         step_fn = lambda: pdist.train_step(model, opt, graph, labels, pos_weight)   # noqa: E731
         del g
     else:
-        model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h])
+        model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h],
+                                        fold_activation=os.environ.get("PANGNN_FOLD_ACT", "1") == "1")   # A/B switch
         graph, labels, pos_weight = g, g.y, g.class_balance
         step_fn = lambda: train_step(model, opt, graph, labels, pos_weight)         # noqa: E731
     opt = make_optimizer(model)

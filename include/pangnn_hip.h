@@ -205,6 +205,20 @@ size_t pangnn_linear_wgrad_workspace_bytes(int32_t K, int32_t M);
 int    pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
                                int32_t K, int32_t M, float* gw, float* gb, void* workspace,
                                size_t workspace_bytes, pangnn_stream_t stream);
+/* The same layers with the encoder's activation folded in (src/gnn.py:108,129-166: h = ELU(conv(...)) is always
+ * followed by exactly one dense layer — GCNConv.lin of the next conv, linear_out, or mlp[0] — so ELU(x) never has
+ * to exist in HBM, and neither does its backward pass as a kernel of its own):
+ *   act_fwd   in_act = 1 : y = ELU(x) . w^T (+ bias)          (x is the PRE-activation; alpha = 1)
+ *             gate != NULL: y = (x . w^T) * ELU'(gate[n, 0:M]) — dL/d(pre-activation) straight from the dL/dx
+ *                           product of the following layer (gate = that pre-activation); excludes in_act
+ *   act_wgrad in_act = 1 : gw = g^T . ELU(x)
+ * in_act = 0, gate = NULL are the plain entry points above. */
+int    pangnn_linear_act_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                                 int64_t ldy, int64_t n, int32_t K, int32_t M, int32_t in_act,
+                                 const float* gate, int64_t ldgate, pangnn_stream_t stream);
+int    pangnn_linear_act_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
+                                   int32_t K, int32_t M, int32_t in_act, float* gw, float* gb,
+                                   void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Confusion counts of thresholded link predictions, accumulated on the device:

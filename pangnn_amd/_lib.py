@@ -37,6 +37,8 @@ SIGNATURES = {
     "pangnn_linear_fwd_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     "pangnn_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32]),
     "pangnn_linear_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
+    "pangnn_linear_act_fwd_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),
+    "pangnn_linear_act_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
     "pangnn_confusion_update_f32": (C.c_int, [_p, _p, _i64, C.c_float, C.c_int, _p, _p]),
     "pangnn_weighted_colsum_workspace_bytes": (_sz, [_i32]),
     "pangnn_weighted_colsum_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _p, _p, _sz, _p]),

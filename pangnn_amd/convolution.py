@@ -91,8 +91,8 @@ class _GlorotLinear(nn.Module):
         a = math.sqrt(6.0 / (self.in_channels + self.out_channels))
         nn.init.uniform_(self.weight, -a, a)
 
-    def forward(self, x):
-        return PF.linear(x, self.weight)
+    def forward(self, x, in_act: int = 0):
+        return PF.linear(x, self.weight, None, in_act)
 
 
 class GCNConv(MessagePassing):
@@ -119,7 +119,10 @@ class GCNConv(MessagePassing):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, edge_weight: Optional[torch.Tensor] = None, graph=None, name: str = ""):
+    def forward(self, x, edge_index, edge_weight: Optional[torch.Tensor] = None, graph=None, name: str = "",
+                in_elu: bool = False):
+        """`in_elu=True`: `x` is the pre-activation of an ELU (alpha 1) the caller deferred — the layer computes
+        conv(ELU(x)); when its dense part comes first the activation is folded into that kernel."""
         _lib.require_device(x, edge_index, edge_weight)
         st = edge_index if isinstance(edge_index, EdgeStructure) else \
             structure_of(edge_index, x.shape[0], holder=graph, name=name)
@@ -129,12 +132,14 @@ class GCNConv(MessagePassing):
             raise ValueError(f"edge_weight has {edge_weight.shape[0]} entries for {st.num_edges} edges")
         norm = st.gcn_norm(edge_weight)
         x = x.float()
+        if in_elu and self.in_channels < self.out_channels:
+            x, in_elu = torch.nn.functional.elu(x), False       # propagate comes first: nothing to fold into
         if self.in_channels < self.out_channels:
             # A_hat (x W^T) == (A_hat x) W^T: propagate on the narrower side (half the gather bytes for
             # 64 -> 128), then the dense layer with the bias fused
             agg = PF.propagate(x, None, st, norm, tag=name or None)
             return PF.linear(agg, self.lin.weight, self.bias)
-        xw = self.lin(x)
+        xw = self.lin(x, 1 if in_elu else 0)
         return PF.propagate(xw, self.bias, st, norm, tag=name or None)
 
     def message(self, x_j, edge_weight):            # kept for API parity; forward() is fused

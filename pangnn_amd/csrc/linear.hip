@@ -75,15 +75,24 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ src, int64_t
   }
 }
 
-template <int C>
+// ELU (alpha = 1) and its derivative, both as functions of the PRE-activation value
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) - 1.f; }   // v_exp_f32: 2 ulp, abs 1e-7
+__device__ __forceinline__ float elu1_grad(float v) { return v > 0.f ? 1.f : __expf(v); }
+
+// ACT = 1: the rows go through ELU on their way to LDS, i.e. the kernel multiplies elu(x) without elu(x) ever
+// existing in HBM (gnn.py:131-166: every activation of the encoder is followed by exactly one dense layer)
+template <int C, int ACT = 0>
 __device__ __forceinline__ void store_rows(const RowRegs<C>& rg, int lane, float* tile) {
   constexpr int LPR = C / 4;
   constexpr int RPI = 64 / LPR;
   constexpr int RS = C + 4;
   const int c4 = lane % LPR, r0 = lane / LPR;
 #pragma unroll
-  for (int i = 0; i < 32 / RPI; ++i)
-    *reinterpret_cast<float4*>(tile + (i * RPI + r0) * RS + 4 * c4) = rg.v[i];
+  for (int i = 0; i < 32 / RPI; ++i) {
+    float4 v = rg.v[i];
+    if (ACT == 1) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+    *reinterpret_cast<float4*>(tile + (i * RPI + r0) * RS + 4 * c4) = v;
+  }
 }
 
 // Waves per workgroup of the forward kernel.  Measured at N = 1e6 (tools/ablate_linear.sh): 4 waves per CU
@@ -148,12 +157,15 @@ __device__ __forceinline__ void tile_product(const float* Xt, const float* Wl, i
 //   tile then waits until its predecessor's writes are acknowledged (0.30 ms vs 0.19 ms per launch at N = 1e6).
 //   The loop body has no branch: the prefetch index is clamped instead of guarded.
 // The one partial tile at the end of the matrix is handled after the loop by the wave whose turn it is.
-template <int K, int M>
+// ACT: input activation (0 none, 1 ELU).  GATE: the result is multiplied by elu'(gate[row][col]) — the backward of
+// "dense layer after ELU" w.r.t. the pre-activation, produced directly by the dL/dx product.
+template <int K, int M, int ACT, bool GATE>
 __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ y, int64_t ldy, int64_t n,
-                                                         int64_t n_tiles) {
+                                                         int64_t n_tiles, const float* __restrict__ gate,
+                                                         int64_t ldgate) {
   constexpr int KS = K + 4;
   constexpr int WAVES = FwdGeo<K, M>::WAVES;
   __shared__ __attribute__((aligned(16))) float lds[M * KS + WAVES * 32 * KS];
@@ -177,10 +189,25 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
   if (tile < n_full) {
     const int64_t last = n_full - 1;
     load_rows_full<K>(x, ldx, tile * 32, lane, rg);
-    store_rows<K>(rg, lane, Xt);
+    store_rows<K, ACT>(rg, lane, Xt);
     load_rows_full<K>(x, ldx, (tile + stride < last ? tile + stride : last) * 32, lane, rg);
     wave_sync_lds();
     for (; tile < n_full; tile += stride) {
+      // GATE: the tile's gate values are fetched before the product so that they land behind the MFMAs (fetched
+      // in the epilogue, one load-and-use at a time, the 128-wide variant took 0.98 ms instead of 0.17)
+      float gv[GATE ? M / 32 : 1][16];
+      if (GATE) {
+        uint32_t goff = (4u * hh * (uint32_t)ldgate + r) * 4u;
+        int64_t gbase = tile * 32;
+        pin(gbase, goff);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float* gr = gate + (gbase + (i & 3) + 8 * (i >> 2)) * ldgate;
+#pragma unroll
+          for (int b = 0; b < M / 32; ++b)
+            gv[b][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gr + 32 * b) + goff);
+        }
+      }
       tile_product<K, M>(Xt, Wl, r, hh, acc);
       // C[row = jrow(i,hh)][m = r + 32b]: 128-byte row segments
       uint32_t loff = (4u * hh * (uint32_t)ldy + r) * 4u;
@@ -190,13 +217,13 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
       for (int i = 0; i < 16; ++i) {
         float* yr = y + (sbase + (i & 3) + 8 * (i >> 2)) * ldy;           // scalar
 #pragma unroll
-        for (int b = 0; b < M / 32; ++b)
-#ifdef PANGNN_LIN_NOSTORE       // diagnostic builds only
-          if (acc[b][i] == 12345.678f)
-#endif
-          st_f32(yr + 32 * b, loff, acc[b][i] + bv[b]);
+        for (int b = 0; b < M / 32; ++b) {
+          float v = acc[b][i] + bv[b];
+          if (GATE) v *= elu1_grad(gv[b][i]);
+          st_f32(yr + 32 * b, loff, v);
+        }
       }
-      store_rows<K>(rg, lane, Xt);                    // tile + stride (see the pipeline note)
+      store_rows<K, ACT>(rg, lane, Xt);               // tile + stride (see the pipeline note)
       const int64_t nxt = tile + 2 * stride;
       load_rows_full<K>(x, ldx, (nxt < last ? nxt : last) * 32, lane, rg);
       wave_sync_lds();
@@ -206,7 +233,7 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
     const int64_t base = n_full * 32;
     load_rows<K>(x, ldx, n, base, lane, rg);
     wave_sync_lds();
-    store_rows<K>(rg, lane, Xt);
+    store_rows<K, ACT>(rg, lane, Xt);
     wave_sync_lds();
     tile_product<K, M>(Xt, Wl, r, hh, acc);
 #pragma unroll
@@ -214,7 +241,11 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int64_t row = base + jrow(i, hh);
-        if (row < n) y[row * ldy + r + 32 * b] = acc[b][i] + bv[b];
+        if (row < n) {
+          float v = acc[b][i] + bv[b];
+          if (GATE) v *= elu1_grad(gate[row * ldgate + r + 32 * b]);
+          y[row * ldy + r + 32 * b] = v;
+        }
       }
   }
 }
@@ -224,7 +255,7 @@ struct WgradGeo {
   static constexpr int SLAB = M * K + M;     // gw | gb
 };
 
-template <int K, int M>
+template <int K, int M, int ACT>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ g, int64_t ldg,
                                                            const float* __restrict__ x, int64_t ldx,
                                                            int64_t n, int64_t n_tiles,
@@ -255,7 +286,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   load_rows<K>(x, ldx, n, tile * 32, lane, rx);
   load_rows<M>(g, ldg, n, tile * 32, lane, rgm);
   for (; tile < n_tiles; tile += stride) {
-    store_rows<K>(rx, lane, Xt);
+    store_rows<K, ACT>(rx, lane, Xt);
     store_rows<M>(rgm, lane, Gt);
     load_rows<K>(x, ldx, n, (tile + stride) * 32, lane, rx);
     load_rows<M>(g, ldg, n, (tile + stride) * 32, lane, rgm);
@@ -322,20 +353,25 @@ static int num_cus() {
 
 template <int K, int M>
 static int launch_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
-                      int64_t n, hipStream_t s) {
+                      int64_t n, int in_act, const float* gate, int64_t ldgate, hipStream_t s) {
   constexpr int WAVES = FwdGeo<K, M>::WAVES;
   const int64_t n_tiles = (n + 31) / 32;
   int64_t grid = (n_tiles + WAVES - 1) / WAVES;
   const int64_t cap = (int64_t)num_cus();          // one workgroup per CU fills its LDS
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((linear_fwd_kernel<K, M>), dim3((unsigned)grid), dim3(WAVES * 64), 0, s, x, ldx, w, bias, y, ldy,
-                     n, n_tiles);
+  const dim3 g((unsigned)grid), b(WAVES * 64);
+  if (gate)
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, true>), g, b, 0, s, x, ldx, w, bias, y, ldy, n, n_tiles, gate, ldgate);
+  else if (in_act)
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 1, false>), g, b, 0, s, x, ldx, w, bias, y, ldy, n, n_tiles, gate, ldgate);
+  else
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, false>), g, b, 0, s, x, ldx, w, bias, y, ldy, n, n_tiles, gate, ldgate);
   PG_CHECK_LAUNCH("pangnn_linear_fwd_f32");
   return 0;
 }
 
 template <int K, int M>
-static int launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n, float* gw,
+static int launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n, int in_act, float* gw,
                         float* gb, float* ws, size_t ws_bytes, hipStream_t s) {
   constexpr int SLAB = WgradGeo<K, M>::SLAB;
   const int64_t n_tiles = (n + 31) / 32;
@@ -345,8 +381,12 @@ static int launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
   if (grid < 1) grid = 1;
   PG_CHECK_ARG(ws && ws_bytes >= (size_t)grid * SLAB * sizeof(float), PANGNN_E_WORKSPACE,
                "pangnn_linear_wgrad_f32: workspace too small");
-  hipLaunchKernelGGL((linear_wgrad_kernel<K, M>), dim3((unsigned)grid), dim3(256), 0, s, g, ldg, x, ldx, n,
-                     n_tiles, ws);
+  if (in_act)
+    hipLaunchKernelGGL((linear_wgrad_kernel<K, M, 1>), dim3((unsigned)grid), dim3(256), 0, s, g, ldg, x, ldx, n,
+                       n_tiles, ws);
+  else
+    hipLaunchKernelGGL((linear_wgrad_kernel<K, M, 0>), dim3((unsigned)grid), dim3(256), 0, s, g, ldg, x, ldx, n,
+                       n_tiles, ws);
   PG_CHECK_LAUNCH("pangnn_linear_wgrad_f32");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB + kWave - 1) / kWave), dim3(kSumThreads), 0, s, ws, (int)grid,
                      SLAB, M * K, gw, gb);
@@ -365,39 +405,54 @@ extern "C" int pangnn_linear_supported(int32_t K, int32_t M, int wgrad) {
   return 1;
 }
 
-extern "C" int pangnn_linear_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
-                                     int64_t ldy, int64_t n, int32_t K, int32_t M, pangnn_stream_t stream) {
+extern "C" int pangnn_linear_act_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                                         int64_t ldy, int64_t n, int32_t K, int32_t M, int32_t in_act,
+                                         const float* gate, int64_t ldgate, pangnn_stream_t stream) {
   PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_fwd_f32: negative size");
   PG_CHECK_ARG(pangnn_linear_supported(K, M, 0), PANGNN_E_BADARG,
                "pangnn_linear_fwd_f32: K and M must be 64 or 128 (got %d, %d)", (int)K, (int)M);
+  PG_CHECK_ARG((in_act == 0 || in_act == 1) && !(in_act && gate) && (!gate || ldgate >= M), PANGNN_E_BADARG,
+               "pangnn_linear_act_fwd_f32: in_act must be 0 or 1 (ELU) and excludes gate; ldgate >= M");
   if (n == 0) return 0;
   PG_CHECK_ARG(x && w && y && ldx >= K && ldy >= M, PANGNN_E_BADARG, "pangnn_linear_fwd_f32: bad pointer / ld");
   PG_CHECK_ARG(aligned16(x) && aligned16(w) && ldx % 4 == 0, PANGNN_E_ALIGN,
                "pangnn_linear_fwd_f32: x / w must be 16-byte aligned, ldx a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
-  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, ldx, w, bias, y, ldy, n, s);
-  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, ldx, w, bias, y, ldy, n, s);
-  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, ldx, w, bias, y, ldy, n, s);
-  return launch_fwd<128, 128>(x, ldx, w, bias, y, ldy, n, s);
+  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
+  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
+  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
+  return launch_fwd<128, 128>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
+}
+
+extern "C" int pangnn_linear_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                                     int64_t ldy, int64_t n, int32_t K, int32_t M, pangnn_stream_t stream) {
+  return pangnn_linear_act_fwd_f32(x, ldx, w, bias, y, ldy, n, K, M, 0, nullptr, 0, stream);
 }
 
 extern "C" size_t pangnn_linear_wgrad_workspace_bytes(int32_t K, int32_t M) {
   return (size_t)num_cus() * ((size_t)M * K + M) * sizeof(float);
 }
 
-extern "C" int pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
-                                       int32_t K, int32_t M, float* gw, float* gb, void* workspace,
-                                       size_t workspace_bytes, pangnn_stream_t stream) {
+extern "C" int pangnn_linear_act_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
+                                           int32_t K, int32_t M, int32_t in_act, float* gw, float* gb,
+                                           void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
   PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_wgrad_f32: negative size");
   PG_CHECK_ARG(pangnn_linear_supported(K, M, 1), PANGNN_E_BADARG,
                "pangnn_linear_wgrad_f32: unsupported (K, M) = (%d, %d)", (int)K, (int)M);
+  PG_CHECK_ARG(in_act == 0 || in_act == 1, PANGNN_E_BADARG, "pangnn_linear_act_wgrad_f32: in_act must be 0 or 1");
   PG_CHECK_ARG(gw && (n == 0 || (g && x)) && ldg >= M && ldx >= K, PANGNN_E_BADARG,
                "pangnn_linear_wgrad_f32: bad pointer / ld");
   PG_CHECK_ARG(aligned16(g) && aligned16(x) && ldg % 4 == 0 && ldx % 4 == 0, PANGNN_E_ALIGN,
                "pangnn_linear_wgrad_f32: g / x must be 16-byte aligned, ld multiples of 4");
   hipStream_t s = (hipStream_t)stream;
   float* ws = static_cast<float*>(workspace);
-  if (K == 64 && M == 64) return launch_wgrad<64, 64>(g, ldg, x, ldx, n, gw, gb, ws, workspace_bytes, s);
-  if (K == 64 && M == 128) return launch_wgrad<64, 128>(g, ldg, x, ldx, n, gw, gb, ws, workspace_bytes, s);
-  return launch_wgrad<128, 64>(g, ldg, x, ldx, n, gw, gb, ws, workspace_bytes, s);
+  if (K == 64 && M == 64) return launch_wgrad<64, 64>(g, ldg, x, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+  if (K == 64 && M == 128) return launch_wgrad<64, 128>(g, ldg, x, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+  return launch_wgrad<128, 64>(g, ldg, x, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+}
+
+extern "C" int pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
+                                       int32_t K, int32_t M, float* gw, float* gb, void* workspace,
+                                       size_t workspace_bytes, pangnn_stream_t stream) {
+  return pangnn_linear_act_wgrad_f32(g, ldg, x, ldx, n, K, M, 0, gw, gb, workspace, workspace_bytes, stream);
 }

@@ -319,17 +319,22 @@ class DistAlternateGCN(AlternateGCN):
             cache[key] = self.ops.norm(self._st(shard, name), weight, gather)
         return cache[key]
 
-    def _linear(self, x, w, b):
-        return PF.linear(x, w, b) if x.is_cuda else F.linear(x, w, b)      # CPU only in the gloo tests
+    def _linear(self, x, w, b, in_act: int = 0):
+        if x.is_cuda:
+            return PF.linear(x, w, b, in_act)
+        return F.linear(F.elu(x) if in_act else x, w, b)                   # CPU only in the gloo tests
 
-    def _conv(self, conv, h_local, shard, name, weight, wkey, tag):
+    def _conv(self, conv, h_local, shard, name, weight, wkey, tag, in_elu: bool = False):
+        """`in_elu`: h_local is the pre-activation of the deferred ELU (see AlternateGCN._encode_pre)"""
         st, norm = self._st(shard, name), self._norm(shard, name, weight, wkey)
+        if in_elu and conv.in_channels < conv.out_channels:
+            h_local, in_elu = F.elu(h_local), False
         if conv.in_channels < conv.out_channels:
             # propagate (and exchange) on the narrower side: half the all-gather bytes for 64 -> 128
             h_full = self._table(h_local, shard, name)
             agg = self.ops.propagate(h_full, None, st, norm, tag)
             return self._linear(agg, conv.lin.weight, conv.bias)
-        xw = self._linear(h_local, conv.lin.weight, None)
+        xw = self._linear(h_local, conv.lin.weight, None, 1 if in_elu else 0)
         xw_full = self._table(xw, shard, name)
         return self.ops.propagate(xw_full, conv.bias, st, norm, tag)
 
@@ -349,29 +354,35 @@ class DistAlternateGCN(AlternateGCN):
         h = shard.x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
         return self._conv(conv, h, shard, name, weight, "w", name)
 
-    def encode(self, shard):
-        fl, act = self.flags, self.activation_fct
+    def _encode_pre(self, shard):
+        """as AlternateGCN._encode_pre, on a shard: (z or its pre-activation, pending)"""
+        fl, act, fold = self.flags, self.activation_fct, self._fold_elu()
+        pre = (lambda h: h) if fold else act
         if fl.union_edge_weights:
             w = shard.union_edge_attr
-            h = act(self._embed_conv_in(shard, "union", w))
+            h = self._embed_conv_in(shard, "union", w)
             for _ in range(max(fl.neighbours - 2, 1)):
-                h = act(self._conv(self.conv_hidden, h, shard, "union", w, "w", "union"))
-            h = act(self._conv(self.conv_out, h, shard, "union", None, "1", "union"))
+                h = self._conv(self.conv_hidden, pre(h), shard, "union", w, "w", "union", in_elu=fold)
+            h = self._conv(self.conv_out, pre(h), shard, "union", None, "1", "union", in_elu=fold)
         elif fl.base_model:
-            h = act(self._embed_conv_in(shard, "sim", shard.edge_attr))
-            h = act(self._linear(h, self.linear_out.weight, self.linear_out.bias))
+            h = self._embed_conv_in(shard, "sim", shard.edge_attr)
+            h = self._linear(pre(h), self.linear_out.weight, self.linear_out.bias, 1 if fold else 0)
         else:
-            h = act(self._embed_conv_in(shard, "sim", shard.edge_attr))
-            h = act(self._conv(self.conv_out, h, shard, "nb", None, "1", "nb"))
-        return h
+            h = self._embed_conv_in(shard, "sim", shard.edge_attr)
+            h = self._conv(self.conv_out, pre(h), shard, "nb", None, "1", "nb", in_elu=fold)
+        return h, True
 
-    def _dec_in(self, z, shard):
+    def encode(self, shard):
+        h, pending = self._encode_pre(shard)
+        return self.activation_fct(h) if pending else h
+
+    def _dec_in(self, z, shard, in_act: int = 0):
         fl = self.flags
         d = z.shape[1]
         lin0 = self.mlp[0]
         w = lin0.weight
-        p = self._linear(z, w[:, :d].contiguous(), None)
-        q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias)
+        p = self._linear(z, w[:, :d].contiguous(), None, in_act)
+        q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias, in_act)
         p_full = self._table(p, shard, "sim")
         extra = shard.edge_attr if fl.skip_connections else None
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
@@ -387,13 +398,16 @@ class DistAlternateGCN(AlternateGCN):
 
     def loss_and_logits(self, shard, labels, pos_weight=None):
         """global-mean BCE loss share of this rank + local logits; one decoder pass on the HIP back end"""
-        z = self.encode(shard)
+        z, pending = self._encode_pre(shard)
+        fold = pending and self._fold_elu()
+        if not fold:
+            z = self.activation_fct(z) if pending else z
         if hasattr(self.ops, "decoder_loss") and torch.is_grad_enabled():
-            p_full, q, extra, cvec = self._dec_in(z, shard)
+            p_full, q, extra, cvec = self._dec_in(z, shard, 1 if fold else 0)
             return self.ops.decoder_loss(p_full, q, self._st(shard, "sim"), extra, cvec, self.mlp[2].weight,
                                          self.mlp[2].bias, self.mlp[4].weight.view(-1), self.mlp[4].bias, labels,
                                          pos_weight, shard.e_sim_total)
-        out = self.decode_mlp(z, shard)
+        out = self.decode_mlp(self.activation_fct(z) if fold else z, shard)
         if out.is_cuda:
             return PF.bce_with_logits(out, labels, pos_weight, denom=shard.e_sim_total), out.detach()
         return F.binary_cross_entropy_with_logits(out, labels, pos_weight=pos_weight,

@@ -438,11 +438,13 @@ def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
 
 
 class _Linear(torch.autograd.Function):
-    """y = x w^T (+ b) over ~1e6 node rows with K, M in {64, 128}: streaming f32-MFMA kernels
-    (pangnn_linear_fwd_f32 / pangnn_linear_wgrad_f32); dL/dx is the forward kernel with w^T."""
+    """y = act(x) w^T (+ b) over ~1e6 node rows with K, M in {64, 128}: streaming f32-MFMA kernels
+    (pangnn_linear_act_fwd_f32 / pangnn_linear_act_wgrad_f32); dL/dx is the forward kernel with w^T.
+    in_act = 1: x is the PRE-activation of an ELU (alpha = 1) that is applied on the fly — ELU(x) is never
+    written, and dL/dx comes out already multiplied by ELU'(x) (no activation-backward kernel)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, in_act=0):
         lib = _lib.load()
         _lib.require_device(x, w, bias)
         x, w = _rows_f32(x), _f32c(w)
@@ -451,10 +453,12 @@ class _Linear(torch.autograd.Function):
         m = w.shape[0]
         y = torch.empty(n, m, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(lib.pangnn_linear_fwd_f32(x.data_ptr(), x.stride(0), w.data_ptr(), _lib.ptr(b), y.data_ptr(),
-                                                 y.stride(0), n, k, m, _lib.stream_ptr()), "pangnn_linear_fwd_f32")
+            _lib.check(lib.pangnn_linear_act_fwd_f32(x.data_ptr(), x.stride(0), w.data_ptr(), _lib.ptr(b), y.data_ptr(),
+                                                     y.stride(0), n, k, m, int(in_act), None, 0, _lib.stream_ptr()),
+                       "pangnn_linear_act_fwd_f32")
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.in_act = int(in_act)
         return y
 
     @staticmethod
@@ -470,27 +474,31 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 wt = w.t().contiguous()                       # [K, M]: gx = g . w = linear(g, w^T)
                 gx = torch.empty(n, k, dtype=torch.float32, device=dev)
-                _lib.check(lib.pangnn_linear_fwd_f32(g.data_ptr(), g.stride(0), wt.data_ptr(), None, gx.data_ptr(),
-                                                     gx.stride(0), n, m, k, _lib.stream_ptr()),
-                           "pangnn_linear_fwd_f32(dx)")
+                gate, ldgate = (x.data_ptr(), x.stride(0)) if ctx.in_act else (None, 0)
+                _lib.check(lib.pangnn_linear_act_fwd_f32(g.data_ptr(), g.stride(0), wt.data_ptr(), None, gx.data_ptr(),
+                                                         gx.stride(0), n, m, k, 0, gate, ldgate, _lib.stream_ptr()),
+                           "pangnn_linear_act_fwd_f32(dx)")
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 gw = torch.empty_like(w)
                 gb = torch.empty(m, dtype=torch.float32, device=dev) if ctx.has_bias else None
                 ws_bytes = lib.pangnn_linear_wgrad_workspace_bytes(k, m)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                _lib.check(lib.pangnn_linear_wgrad_f32(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), n, k, m,
-                                                       gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(), ws_bytes,
-                                                       _lib.stream_ptr()), "pangnn_linear_wgrad_f32")
-        return gx, gw, gb
+                _lib.check(lib.pangnn_linear_act_wgrad_f32(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), n, k, m,
+                                                           ctx.in_act, gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(),
+                                                           ws_bytes, _lib.stream_ptr()), "pangnn_linear_act_wgrad_f32")
+        return gx, gw, gb, None
 
 
-def linear(x, w, bias=None):
+def linear(x, w, bias=None, in_act: int = 0):
     """torch.nn.functional.linear for node-level layers; shapes the HIP kernels do not cover
-    (K or M outside {64,128}, or the 128x128 weight gradient) go to hipBLASLt via torch."""
+    (K or M outside {64,128}, or the 128x128 weight gradient) go to hipBLASLt via torch.
+    in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels (see _Linear)."""
     lib = _lib.load()
     k, m = w.shape[1], w.shape[0]
     if x.dim() == 2 and x.is_cuda and lib.pangnn_linear_supported(k, m, 1):
-        return _Linear.apply(x, w, bias)
+        return _Linear.apply(x, w, bias, in_act)
+    if in_act:
+        x = torch.nn.functional.elu(x)
     return torch.nn.functional.linear(x, w, bias)
 
 

@@ -20,6 +20,10 @@ First layer: `conv_in(embedding(x))` with the scalar node feature is one operato
 (functional._EmbedPropagate): forward is the ordinary propagate of h0 = x w^T + b; backward produces
 the embedding's gradients as (A_hat x)^T g, (A_hat 1)^T g instead of running the transposed
 propagate (nothing else consumes dL/dh0).  `fuse_embedding=False` keeps the layer-by-layer form.
+
+Activations: every `h = ELU(layer(...))` of the encoder is consumed by exactly one dense layer, so the ELU runs
+inside that layer's kernels (`functional.linear(..., in_act=1)`); `fold_activation=False` applies it as its own
+op.  `encode()` always returns activated embeddings.
 """
 from __future__ import annotations
 
@@ -42,7 +46,7 @@ _FLAG_DEFAULTS = dict(union_edge_weights=False, base_model=False, skip_connectio
 class AlternateGCN(nn.Module):
     def __init__(self, device=None, dataset=None, categorical_nodes: bool = False, dims=(64, 128),
                  args=None, num_nodes: Optional[int] = None, fused_decoder: bool = True,
-                 fuse_embedding: bool = True, **flags):
+                 fuse_embedding: bool = True, fold_activation: bool = True, **flags):
         super().__init__()
         self.device = device
         cfg = dict(_FLAG_DEFAULTS)
@@ -57,6 +61,7 @@ class AlternateGCN(nn.Module):
         self.flags = SimpleNamespace(**cfg)
         self.fused_decoder = fused_decoder
         self.fuse_embedding = fuse_embedding
+        self.fold_activation = fold_activation
         node_embedding_dim, hidden_dim = dims
 
         if categorical_nodes:
@@ -106,24 +111,41 @@ class AlternateGCN(nn.Module):
         h = x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
         return conv(h, ei, graph.edge_attr, graph=graph, name=name)
 
-    def encode(self, graph) -> torch.Tensor:
+    def _fold_elu(self) -> bool:
+        """the encoder's activation (gnn.py:108: ELU) can be folded into the dense layer that follows it"""
+        a = self.activation_fct
+        return self.fold_activation and isinstance(a, nn.ELU) and float(a.alpha) == 1.0
+
+    def _encode_pre(self, graph):
+        """(z or its pre-activation, pending): every `h = act(layer(...))` of gnn.py:125-166 is consumed by exactly
+        one dense layer (GCNConv.lin of the next conv, linear_out, or the decoder's first layer), so with ELU the
+        activation runs inside that layer's kernels (functional._Linear, in_act) and only the LAST one can be
+        left pending for the caller."""
         fl = self.flags
-        act = self.activation_fct
+        act, fold = self.activation_fct, self._fold_elu()
         if fl.union_edge_weights:                                              # gnn.py:128-139
             ei = graph.union_edge_index
-            h = act(self._embed_conv_in(graph, ei, "union"))
+            h = self._embed_conv_in(graph, ei, "union")
             for _ in range(max(fl.neighbours - 2, 1)):
-                h = act(self.conv_hidden(h, ei, graph.edge_attr, graph=graph, name="union"))
-            h = act(self.conv_out(h, ei, graph=graph, name="union"))
+                h = self.conv_hidden(h, ei, graph.edge_attr, graph=graph, name="union", in_elu=True) if fold \
+                    else self.conv_hidden(act(h), ei, graph.edge_attr, graph=graph, name="union")
+            h = self.conv_out(h, ei, graph=graph, name="union", in_elu=True) if fold \
+                else self.conv_out(act(h), ei, graph=graph, name="union")
         elif fl.base_model:                                                    # gnn.py:143-150
-            h = act(self._embed_conv_in(graph, graph.edge_index, "sim"))
-            h = act(PF.linear(h, self.linear_out.weight, self.linear_out.bias))
+            h = self._embed_conv_in(graph, graph.edge_index, "sim")
+            h = PF.linear(h, self.linear_out.weight, self.linear_out.bias, 1) if fold \
+                else PF.linear(act(h), self.linear_out.weight, self.linear_out.bias)
         else:                                                                  # gnn.py:153-166
-            h = act(self._embed_conv_in(graph, graph.edge_index, "sim"))
-            h = act(self.conv_out(h, graph.neighbour_edge_index, graph=graph, name="nb"))
-        return h
+            h = self._embed_conv_in(graph, graph.edge_index, "sim")
+            h = self.conv_out(h, graph.neighbour_edge_index, graph=graph, name="nb", in_elu=True) if fold \
+                else self.conv_out(act(h), graph.neighbour_edge_index, graph=graph, name="nb")
+        return h, True
 
-    def _decoder_inputs(self, z, graph):
+    def encode(self, graph) -> torch.Tensor:
+        h, pending = self._encode_pre(graph)
+        return self.activation_fct(h) if pending else h
+
+    def _decoder_inputs(self, z, graph, in_act: int = 0):
         """(pq [N,2D], structure, extra, cvec) of the re-associated first decoder layer"""
         fl = self.flags
         ei = graph.edge_index
@@ -134,16 +156,19 @@ class AlternateGCN(nn.Module):
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
         w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
         b_pq = torch.cat([torch.zeros_like(self.mlp[0].bias), self.mlp[0].bias])
-        return PF.linear(z, w_pq, b_pq), st, extra, cvec
+        return PF.linear(z, w_pq, b_pq, in_act), st, extra, cvec
 
     def loss_and_logits(self, graph, labels, pos_weight=None):
         """`criterion(model(graph), labels)` (pangnn.py:200-203) as ONE decoder pass when the fused kernel
         applies (mlp decoder, node_dim 64): returns (loss, detached logits).  Falls back to forward +
         criterion otherwise."""
         from .train import criterion
-        z = self.encode(graph)
-        if "mlp" in self.flags.decoder and self.fused_decoder is True and z.shape[1] == 64 and torch.is_grad_enabled():
-            pq, st, extra, cvec = self._decoder_inputs(z, graph)
+        z, pending = self._encode_pre(graph)
+        fused = "mlp" in self.flags.decoder and self.fused_decoder is True and z.shape[1] == 64 and torch.is_grad_enabled()
+        if not (fused and pending and self._fold_elu()):
+            z, pending = (self.activation_fct(z) if pending else z), False
+        if fused:
+            pq, st, extra, cvec = self._decoder_inputs(z, graph, 1 if pending else 0)
             return PF.decoder_loss_pq(pq, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
                                       self.mlp[4].weight.view(-1), self.mlp[4].bias, labels, pos_weight,
                                       labels.shape[0])

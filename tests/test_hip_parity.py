@@ -869,3 +869,47 @@ def test_fused_embedding_layer_equals_layerwise_form_and_oracle(flags):
     scale = float(plain.embedding.weight.grad.abs().max()) + 1e-12
     assert close(model.embedding.weight.grad, plain.embedding.weight.grad, atol=1e-3 * scale + 1e-7, rtol=1e-3)
     assert not torch.equal(g1, model.embedding.weight.grad)
+
+
+# ---------------------------------------------------------------- dense layer with the preceding ELU folded in
+@pytest.mark.parametrize("k,m", [(64, 64), (64, 128), (128, 64)])
+@pytest.mark.parametrize("n", [1, 33, 1000, 40007])
+def test_linear_with_folded_elu_matches_torch(k, m, n):
+    from pangnn_amd import functional as PF
+    gen = torch.Generator().manual_seed(n + k + m)
+    x = torch.randn(n, k, generator=gen) * 2
+    w = torch.randn(m, k, generator=gen) / 8
+    b = torch.randn(m, generator=gen)
+    gy = torch.randn(n, m, generator=gen)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+    ref = torch.nn.functional.linear(torch.nn.functional.elu(ref_in[0]), ref_in[1], ref_in[2])
+    ref.backward(gy.double())
+    leaves = [t.clone().to(dev()).requires_grad_(True) for t in (x, w, b)]
+    out = PF.linear(leaves[0], leaves[1], leaves[2], in_act=1)
+    out.backward(gy.to(dev()))
+    assert close(out, ref)
+    for a, r in zip(leaves, ref_in):
+        scale = float(r.grad.abs().max()) + 1e-12
+        assert close(a.grad, r.grad, atol=1e-4 * scale + 1e-7, rtol=1e-3)
+
+
+def test_folded_activation_model_equals_layerwise_model():
+    import pangnn_amd
+    for flags in (dict(), dict(base_model=True), dict(union_edge_weights=True), dict(skip_connections=True)):
+        g, gd, oracle, model = _pair("cfg2_sim_1000x5", (64, 128), flags, seed=3)
+        plain = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], fold_activation=False, **flags)
+        plain.load_state_dict(model.state_dict())
+        pw = torch.tensor(2.0, device=dev())
+        res = []
+        for m in (model, plain):
+            gm = copy_graph(g, dev())
+            loss, out = m.loss_and_logits(gm, gm.y, pw)
+            loss.backward()
+            res.append((loss.detach(), out, {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+            assert close(m(gm), out, atol=1e-5, rtol=1e-5)          # inference path (activation applied explicitly)
+        assert close(res[0][1], oracle(g))
+        assert close(res[0][0], res[1][0], atol=1e-6, rtol=1e-5)
+        assert close(res[0][1], res[1][1], atol=1e-5, rtol=1e-5)
+        for k, gk in res[1][2].items():
+            scale = float(gk.abs().max()) + 1e-12
+            assert close(res[0][2][k], gk, atol=1e-4 * scale + 1e-9, rtol=1e-3), (flags, k)
