@@ -2,6 +2,7 @@
 current stream.  No torch-native arithmetic stands in for a kernel here."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -25,8 +26,8 @@ KERNEL_TIMER = None
 # 1 (default) = every product on the bf16 matrix pipe with operands split into bf16 terms (hi + mid + lo carries
 #     the 24 significand bits; partial products accumulated in fp32) — fp32-level error (tests: 2e-5 on logits
 #     against fp64), 0.78x the time of mode 0 because f32 MFMA shares the SIMD's vector lanes;
-# 0 = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fp32 FMA chains).
-DECODER_PRECISION = 1
+# 0 = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fp32 FMA chains).  Environment: PANGNN_DECODER_PRECISION.
+DECODER_PRECISION = int(os.environ.get("PANGNN_DECODER_PRECISION", "1"))
 
 
 def _timer_start(tag):
