@@ -432,7 +432,7 @@ def train_step(model: DistAlternateGCN, optimizer, shard, labels, pos_weight):
     by the global edge count and the gradient all-reduce is a plain sum."""
     optimizer.zero_grad(set_to_none=True)
     loss, out = model.loss_and_logits(shard, labels, pos_weight)
-    loss.backward()
+    loss.backward(PF.unit_grad(loss.device) if loss.is_cuda else None)
     model.sync_gradients()
     optimizer.step()
     return loss.detach(), out.detach()

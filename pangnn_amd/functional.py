@@ -360,6 +360,26 @@ def decoder_mlp_pq(pq, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
     return _DecoderMLP.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, True)
 
 
+# The training decoder computes every gradient in its forward pass; its backward only has to scale them by the
+# upstream gradient of the loss, which for `loss.backward()` is 1 — but a device tensor cannot be compared with 1
+# without a sync.  A training loop that owns the call passes this cached tensor as the root gradient instead
+# (`loss.backward(unit_grad(device))`), recognised by identity: no [N,128] multiply per step.
+_UNIT_GRAD = {}
+
+
+def unit_grad(device) -> torch.Tensor:
+    key = torch.device(device)
+    t = _UNIT_GRAD.get(key)
+    if t is None:
+        t = _UNIT_GRAD[key] = torch.ones((), dtype=torch.float32, device=key)
+    return t
+
+
+def is_unit_grad(g: torch.Tensor) -> bool:
+    t = _UNIT_GRAD.get(g.device)
+    return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0
+
+
 class _DecoderLoss(torch.autograd.Function):
     """Training form of the fused decoder: mean BCEWithLogits(pos_weight) loss, logits and ALL gradients in
     one pass over the edges (pangnn_decoder_mlp_loss_f32).  Everything is computed in forward(); backward()
@@ -426,6 +446,9 @@ class _DecoderLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go, _go_logits):
         gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
+        if is_unit_grad(go):         # `loss.backward(unit_grad(device))` (train.train_step): nothing to scale
+            return (gp, gq if ctx.has_q else None, None, None, g_cv if ctx.has_cv else None,
+                    g_w2, g_b2, g_w3, g_b3, None, None, None, None)
         return (gp * go, (gq * go) if ctx.has_q else None, None, None, (g_cv * go) if ctx.has_cv else None,
                 g_w2 * go, g_b2 * go, g_w3 * go, g_b3 * go, None, None, None, None)
 

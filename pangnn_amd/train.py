@@ -29,7 +29,7 @@ def train_step(model, optimizer, graph, labels, pos_weight):
     else:
         out = model(graph)
         loss = criterion(out, labels, pos_weight)                                   # pangnn.py:98,203
-    loss.backward()
+    loss.backward(PF.unit_grad(loss.device) if loss.is_cuda else None)              # = loss.backward(), see unit_grad
     optimizer.step()
     return loss.detach(), out.detach()
 
@@ -103,7 +103,7 @@ class GraphedTrainStep:
         else:
             out = self.model(self.graph)
             loss = criterion(out, self.labels, self.pos_weight)
-        loss.backward()
+        loss.backward(PF.unit_grad(loss.device))
         self.optimizer.step()
         return loss.detach(), out.detach()
 
