@@ -1,3 +1,6 @@
+"""Diagnostic (kept as the reproducer of DESIGN.md §4 (iii)): runs the bf16 matrix-pipe training decoder six times
+on a 30-edge list (one partial tile) and reports which gradient entries differ from the f32-MFMA mode.  With
+decoder.hip built WITHOUT -mllvm -amdgpu-mfma-vgpr-form=1 about four runs in six are wrong."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
