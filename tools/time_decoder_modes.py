@@ -17,7 +17,7 @@ par = [torch.randn(64, 64, device=dev) / 8, torch.randn(64, device=dev), torch.r
        torch.randn(1, device=dev)]
 y = (torch.rand(e, device=dev) < 0.03).float()
 pw = torch.tensor(30.0, device=dev)
-for mode in (1, 1):
+for mode in (0, 1, 0, 1):
     PF.DECODER_PRECISION = mode
     PF.KERNEL_TIMER = {"dec.bwd": []}
     for _ in range(4):
