@@ -167,6 +167,13 @@ int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int6
                                const float* extra, const float* cvec, const float* w2, const float* b2,
                                const float* w3, const float* b3, int32_t D, float* logits,
                                pangnn_stream_t stream);
+/* the same forward with the matrix-pipe mode of the training kernel (`precision`, see above): 0 = f32 MFMA,
+ * 1 = bf16 matrix pipe with three-way split operands (fp32-level error, about half the time) */
+int pangnn_decoder_mlp_infer_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
+                                 const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                                 const float* extra, const float* cvec, const float* w2, const float* b2,
+                                 const float* w3, const float* b3, int32_t D, float* logits,
+                                 int32_t precision, pangnn_stream_t stream);
 size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges);
 int pangnn_decoder_mlp_bwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                const int64_t* edge_index, int64_t ld, int64_t num_edges,

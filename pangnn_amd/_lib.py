@@ -46,6 +46,8 @@ SIGNATURES = {
     "pangnn_bce_logits_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "pangnn_decoder_mlp_fwd_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
                                              _p, _p]),
+    "pangnn_decoder_mlp_infer_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
+                                               _p, _i32, _p]),
     "pangnn_decoder_mlp_bwd_workspace_bytes": (_sz, [_i64]),
     "pangnn_decoder_mlp_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
                                              _p, _p, _p, _p, _p, _p, _p, _p, _p,      # g_logits .. part_off

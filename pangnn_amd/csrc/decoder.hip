@@ -1040,6 +1040,96 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
   for (int i = threadIdx.x; i < 4096 + 194; i += X3_WAVES * 64) slab[i] = red[i];
 }
 
+// Inference form of the bf16 matrix-pipe mode: logits only.  Same first product as the training kernel (six
+// partial products of three-way split operands), then bias + relu + the w3 dot in the accumulator layout.
+// 8 waves per CU (two per SIMD): the W2 terms are LDS images shared by the workgroup (in the training kernel they
+// are registers of its single wave per SIMD), which leaves room for the software-pipelined gather — edge ids two
+// tiles ahead, node rows one tile ahead — of the f32 forward kernel.
+constexpr int FWD_X3_WAVES = 8;
+__global__ __launch_bounds__(FWD_X3_WAVES * 64) void decoder_fwd_x3_kernel(DecParams a, float* __restrict__ logits,
+                                                                            int64_t n_tiles) {
+  constexpr int WIMG = 64 * WTS / 2;      // one bf16 image [64][WTS] of W2, in floats
+  __shared__ __attribute__((aligned(16))) float lds[3 * WIMG + 3 * 64 + FWD_X3_WAVES * TE * RS];
+  unsigned short* Wi = reinterpret_cast<unsigned short*>(lds);      // hi | mid | lo
+  float* b2l = lds + 3 * WIMG;
+  float* w3l = b2l + 64;
+  float* cvl = w3l + 64;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* Ht = cvl + 64 + wave * (TE * RS);
+  const int hh = lane >> 5, r = lane & 31;
+  for (int i = threadIdx.x; i < 64 * 64; i += FWD_X3_WAVES * 64) {
+    const int j = i >> 6, kk = i & 63;
+    const float w = a.w2[i];
+    const __bf16 whi = (__bf16)w;
+    const float r1 = w - (float)whi;
+    const __bf16 wmid = (__bf16)r1;
+    const __bf16 wlo = (__bf16)(r1 - (float)wmid);
+    Wi[j * WTS + kk] = __builtin_bit_cast(unsigned short, whi);
+    Wi[64 * WTS + j * WTS + kk] = __builtin_bit_cast(unsigned short, wmid);
+    Wi[128 * WTS + j * WTS + kk] = __builtin_bit_cast(unsigned short, wlo);
+  }
+  for (int i = threadIdx.x; i < 64; i += FWD_X3_WAVES * 64) {
+    b2l[i] = a.b2[i];
+    w3l[i] = a.w3[i];
+    cvl[i] = a.cvec ? a.cvec[i] : 0.f;
+  }
+  __syncthreads();
+  const float b3 = a.b3[0];
+  const int64_t stride = (int64_t)gridDim.x * FWD_X3_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * FWD_X3_WAVES + wave;
+  TileIds cur = load_ids(a, tile, n_tiles, lane);
+  TileIds nxt = load_ids(a, tile + stride, n_tiles, lane);
+  TileRows rw;
+  issue_rows(a, cur, lane, rw);
+  for (; tile < n_tiles; tile += stride) {
+    const int64_t ebase = tile * TE;
+    commit_rows(a, rw, lane, cvl, Ht);
+    const TileIds nn = load_ids(a, tile + 2 * stride, n_tiles, lane);
+    issue_rows(a, nxt, lane, rw);                            // next tile's rows fly during the MFMAs
+    nxt = nn;
+    wave_lds_sync();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 lo4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh));
+      const float4 hi4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh + 1));
+      const float f[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      const Split3 hb = split8(f);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const unsigned short* wrow = Wi + (r + 32 * b) * WTS + 16 * s4 + 8 * hh;     // W2[j][16s + 8hh .. + 7]
+        const bf16x8 w_hi = *reinterpret_cast<const bf16x8*>(wrow);
+        const bf16x8 w_mid = *reinterpret_cast<const bf16x8*>(wrow + 64 * WTS);
+        const bf16x8 w_lo = *reinterpret_cast<const bf16x8*>(wrow + 128 * WTS);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo, hb.hi, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid, hb.mid, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, hb.lo, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid, hb.hi, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, hb.mid, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, hb.hi, acc[b], 0, 0, 0);
+      }
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int j0 = 32 * b + 8 * qd + 4 * hh;
+        const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
+        const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
+        part = fmaf(relu1(acc[b][4 * qd + 0] + bb.x), ww.x, part);
+        part = fmaf(relu1(acc[b][4 * qd + 1] + bb.y), ww.y, part);
+        part = fmaf(relu1(acc[b][4 * qd + 2] + bb.z), ww.z, part);
+        part = fmaf(relu1(acc[b][4 * qd + 3] + bb.w), ww.w, part);
+      }
+    part += __shfl_xor(part, 32);
+    if (lane < 32 && ebase + lane < a.E) logits[ebase + lane] = part + b3;
+    wave_lds_sync();   // the next commit overwrites Ht
+  }
+}
+
 // out[i] = sum over workgroup slabs in index order (fixed => reproducible)
 __global__ __launch_bounds__(kSumThreads) void decoder_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
                                                                 float* __restrict__ g_w2,
@@ -1091,25 +1181,40 @@ static int check_common(const char* who, const float* p, const float* q, int64_t
 
 using namespace pangnn;
 
+extern "C" int pangnn_decoder_mlp_infer_f32(const float* p, int64_t ldp, const float* q, int64_t ldq,
+                                            int64_t num_nodes, const int64_t* edge_index, int64_t ld,
+                                            int64_t num_edges, const float* extra, const float* cvec,
+                                            const float* w2, const float* b2, const float* w3, const float* b3,
+                                            int32_t D, float* logits, int32_t precision, pangnn_stream_t stream) {
+  int rc = check_common("pangnn_decoder_mlp_fwd_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
+                        cvec, w2, b2, w3, b3, D);
+  if (rc) return rc;
+  PG_CHECK_ARG(precision == 0 || precision == 1, PANGNN_E_BADARG, "pangnn_decoder_mlp_infer_f32: precision must be 0 or 1");
+  if (num_edges == 0) return 0;
+  PG_CHECK_ARG(logits, PANGNN_E_BADARG, "pangnn_decoder_mlp_fwd_f32: null logits");
+  const int64_t n_tiles = (num_edges + TE - 1) / TE;
+  const int waves = precision ? FWD_X3_WAVES : FWD_WAVES;
+  int64_t grid = (n_tiles + waves - 1) / waves;
+  const int cus = grid_cus();
+  if (grid > cus) grid = cus;
+  DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  if (precision)
+    hipLaunchKernelGGL(decoder_fwd_x3_kernel, dim3((unsigned)grid), dim3(FWD_X3_WAVES * 64), 0,
+                       (hipStream_t)stream, a, logits, n_tiles);
+  else
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0,
+                       (hipStream_t)stream, a, logits, n_tiles);
+  PG_CHECK_LAUNCH("pangnn_decoder_mlp_fwd_f32");
+  return 0;
+}
+
 extern "C" int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq,
                                           int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                           const float* extra, const float* cvec, const float* w2,
                                           const float* b2, const float* w3, const float* b3,
                                           int32_t D, float* logits, pangnn_stream_t stream) {
-  int rc = check_common("pangnn_decoder_mlp_fwd_f32", p, q, ldp, ldq, num_nodes, edge_index, ld, num_edges, extra,
-                        cvec, w2, b2, w3, b3, D);
-  if (rc) return rc;
-  if (num_edges == 0) return 0;
-  PG_CHECK_ARG(logits, PANGNN_E_BADARG, "pangnn_decoder_mlp_fwd_f32: null logits");
-  const int64_t n_tiles = (num_edges + TE - 1) / TE;
-  int64_t grid = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
-  const int cus = grid_cus();
-  if (grid > cus) grid = cus;
-  DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
-  hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0,
-                     (hipStream_t)stream, a, logits, n_tiles);
-  PG_CHECK_LAUNCH("pangnn_decoder_mlp_fwd_f32");
-  return 0;
+  return pangnn_decoder_mlp_infer_f32(p, ldp, q, ldq, num_nodes, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3,
+                                      D, logits, 0, stream);
 }
 
 extern "C" size_t pangnn_decoder_mlp_bwd_workspace_bytes(int64_t num_edges) {

@@ -296,11 +296,12 @@ class _DecoderMLP(torch.autograd.Function):
         logits = torch.empty(e, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
             ev = _timer_start("dec.fwd")
-            _lib.check(lib.pangnn_decoder_mlp_fwd_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
-                                                      max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
-                                                      _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
-                                                      w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(logits),
-                                                      _lib.stream_ptr()), "pangnn_decoder_mlp_fwd_f32")
+            _lib.check(lib.pangnn_decoder_mlp_infer_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
+                                                        max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
+                                                        _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
+                                                        w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(logits),
+                                                        DECODER_PRECISION, _lib.stream_ptr()),
+                       "pangnn_decoder_mlp_infer_f32")
             _timer_stop("dec.fwd", ev)
         ctx.st, ctx.joint = st, pq_joint
         ctx.save_for_backward(p, q, ex, cv, w2, b2, w3, b3)

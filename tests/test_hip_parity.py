@@ -219,7 +219,8 @@ def test_three_decoder_forms_agree(skip):
 
 @pytest.mark.parametrize("e", [0, 1, 31, 32, 33, 1000, 70001])
 @pytest.mark.parametrize("skip", [False, True])
-def test_fused_decoder_kernel_vs_torch(e, skip):
+@pytest.mark.parametrize("mode", [1, 0], ids=["bf16x3", "f32mfma"])
+def test_fused_decoder_kernel_vs_torch(e, skip, mode):
     """pangnn_decoder_mlp_{fwd,bwd}_f32 against the same MLP written with torch ops on the CPU,
     ragged tile tails included (tile = 32 edges)."""
     from pangnn_amd import functional as PF
@@ -240,13 +241,17 @@ def test_fused_decoder_kernel_vs_torch(e, skip):
     ref = torch.relu(torch.relu(h1) @ W2r.t() + b2r) @ w3r + b3r
     gl = [t.clone().to(dev()).requires_grad_(True) for t in (P, Q, W2, b2, w3, b3, cv)]
     st = EdgeStructure(ei.to(dev()), n)
-    out = PF.decoder_mlp(gl[0], gl[1], st, extra.to(dev()) if skip else None, gl[6] if skip else None,
-                         gl[2], gl[3], gl[4], gl[5])
-    assert out.shape == (e,)
-    assert close(out, ref)
-    go_ = torch.randn(e)
-    ref.backward(go_)
-    out.backward(go_.to(dev()))
+    old_mode, PF.DECODER_PRECISION = PF.DECODER_PRECISION, mode      # inference kernel and backward kernel of this mode
+    try:
+        out = PF.decoder_mlp(gl[0], gl[1], st, extra.to(dev()) if skip else None, gl[6] if skip else None,
+                             gl[2], gl[3], gl[4], gl[5])
+        assert out.shape == (e,)
+        assert close(out, ref)
+        go_ = torch.randn(e)
+        ref.backward(go_)
+        out.backward(go_.to(dev()))
+    finally:
+        PF.DECODER_PRECISION = old_mode
     for i, name in enumerate(["P", "Q", "W2", "b2", "w3", "b3", "cvec"]):
         if name == "cvec" and not skip:
             continue

@@ -26,3 +26,10 @@ for mode in (0, 1, 0, 1):
     torch.cuda.synchronize()
     ts = [a.elapsed_time(b) for a, b in PF.KERNEL_TIMER["dec.bwd"]][1:]
     print("mode", mode, "kernel ms", sum(ts) / len(ts), "loss", float(loss))
+    PF.KERNEL_TIMER = {"dec.fwd": []}
+    with torch.no_grad():
+        for _ in range(4):
+            out = PF.decoder_mlp_pq(pq, st, None, None, *par)
+    torch.cuda.synchronize()
+    tf = [a.elapsed_time(b) for a, b in PF.KERNEL_TIMER["dec.fwd"]][1:]
+    print("mode", mode, "inference kernel ms", sum(tf) / len(tf), "max |logit - training logit|", float((out - logits).abs().max()))
