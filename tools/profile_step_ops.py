@@ -18,3 +18,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
         train_step(model, opt, g, g.y, g.class_balance)
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=60))
+print("---- aten ops on edge-sized tensors")
+for ev in prof.key_averages(group_by_input_shape=True):
+    if ev.key.startswith("aten::") and any(len(sh) and max(sh) > 10_000_000 for sh in (ev.input_shapes or []) if isinstance(sh, (list, tuple))):
+        print(ev.key, ev.input_shapes, ev.count, round(ev.device_time_total / 1e3, 3), "ms")
