@@ -397,7 +397,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
       const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
       gl[r] = g_e;                                   // the two halves write the same value
       gb3p += g_e;                                   // per-half partials; lane 0's half is the one read out
-      if (live) lossp += ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom;
+      lossp += live ? ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom : 0.f;   // select, not a branch
       if (hh == 0 && live) lp.logits[ebase + r] = xv;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
       rm = rm * (2.f - um1 * rm);
       const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
       gb3p += g_e;                                   // per-half partials; lane 0's half is the one read out
-      if (live) lossp += ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom;
+      lossp += live ? ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom : 0.f;   // select, not a branch
       if (hh == 0 && live) lp.logits[ebase + r] = xv;
     } else {
 #pragma unroll
