@@ -912,7 +912,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           const float hval = Ht[swz(e, k)];
           const float v = hval > 0.f ? acc2[bp][i] : 0.f;
 #ifndef PANGNN_X3_ABL_STORE
-          if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
+          if (full || ebase + e < a.E) __builtin_nontemporal_store(v, &gout[jr(i, 0) * DD + 32 * bp]);   // 19 GB written once
 #endif
           acc2[bp][i] = v;
         }

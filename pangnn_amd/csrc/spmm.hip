@@ -66,7 +66,10 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
         vv[u] = __shfl(v_cur, k);
         if (k < cnt) {
           if (BIG) {
-            xv[u] = *reinterpret_cast<const float4*>(xbase + (int64_t)c * ldx * 4);
+            // > 4 GiB tables are the per-edge gradient rows of the decoder: each row is read exactly once
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (int64_t)c * ldx * 4));
+            xv[u] = make_float4(t[0], t[1], t[2], t[3]);
           } else {
             xv[u] = *reinterpret_cast<const float4*>(xbase + (uint32_t)c * ldx_b32);
           }
