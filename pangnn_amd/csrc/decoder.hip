@@ -454,7 +454,7 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
           const int k = r + 32 * bp;
           const float hval = Ht[swz(e, k)];
           const float v = hval > 0.f ? acc2[bp][i] : 0.f;
-          if (full || ebase + e < a.E) gout[jr(i, 0) * DD + 32 * bp] = v;
+          if (full || ebase + e < a.E) __builtin_nontemporal_store(v, &gout[jr(i, 0) * DD + 32 * bp]);   // 19 GB written once
           acc2[bp][i] = v;
         }
       if (a.extra) {                                 // uniform; only with skip connections
