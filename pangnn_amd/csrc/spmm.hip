@@ -39,8 +39,9 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
   int c_nxt = 0;
   float v_nxt = 0.f;
   if (beg + lane < end) {
-    c_nxt = idx ? idx[beg + lane] : (int)(beg + lane);     // idx == NULL: identity (contiguous segments)
-    v_nxt = val ? val[beg + lane] : 1.f;
+    // the entry lists are streamed once per launch: non-temporal, so that they do not displace gathered rows
+    c_nxt = idx ? __builtin_nontemporal_load(idx + beg + lane) : (int)(beg + lane);     // idx == NULL: identity
+    v_nxt = val ? __builtin_nontemporal_load(val + beg + lane) : 1.f;
   }
   for (int64_t e0 = beg; e0 < end; e0 += kWave) {
     const int c_cur = c_nxt;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
       c_nxt = 0;
       v_nxt = 0.f;
       if (en < end) {
-        c_nxt = idx ? idx[en] : (int)en;
-        v_nxt = val ? val[en] : 1.f;
+        c_nxt = idx ? __builtin_nontemporal_load(idx + en) : (int)en;
+        v_nxt = val ? __builtin_nontemporal_load(val + en) : 1.f;
       }
     }
     for (int s = 0; s < cnt; s += EPS * U) {
