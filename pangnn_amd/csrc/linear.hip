@@ -33,7 +33,13 @@ __device__ __forceinline__ void wave_sync_lds() {
 // at the top of every block of accesses: an empty asm that ties `base` to an SGPR pair and `off` to a VGPR.
 __device__ __forceinline__ void pin(int64_t& base, uint32_t& off) { asm volatile("" : "+s"(base), "+v"(off)); }
 __device__ __forceinline__ float4 ld_f4(const float* ubase, uint32_t byte_off) {
+#ifndef PANGNN_LIN_NO_NT      // rows are read once per kernel: streaming loads (3-8 % in isolation, tools/ablate_linear.sh)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ubase) + byte_off));
+  return make_float4(t[0], t[1], t[2], t[3]);
+#else
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ubase) + byte_off);
+#endif
 }
 __device__ __forceinline__ void st_f32(float* ubase, uint32_t byte_off, float v) {
   *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byte_off) = v;

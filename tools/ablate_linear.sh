@@ -4,12 +4,10 @@
 set -e
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/ablate_lin; mkdir -p $OUT
-for v in base nomfma; do
+for v in base nont; do
   flags=""
-    [ $v = w4 ] && flags="-DPANGNN_LIN_WAVES=4"
-  [ $v = w8 ] && flags="-DPANGNN_LIN_WAVES=8"
-  [ $v = nomfma ] && flags="-DPANGNN_LIN_NOMFMA"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -shared pangnn_amd/csrc/linear.hip pangnn_amd/csrc/edge_ops.hip -o $OUT/liblin_$v.so
+  [ $v = nont ] && flags="-DPANGNN_LIN_NO_NT"
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -shared pangnn_amd/csrc/linear.hip pangnn_amd/csrc/edge_ops.hip -o $OUT/liblin_$v.so
 done
 python - <<'PY'
 import ctypes as C, torch
@@ -17,7 +15,7 @@ dev = torch.device('cuda')
 n = 1_000_000
 P = C.c_void_p
 bufs = {k: [torch.randn(n, k, device=dev) for _ in range(3)] for k in (64, 128)}
-for v in ["base", "nomfma"]:
+for v in ["base", "nont"]:
     lib = C.CDLL(f'gpurun_out/ablate_lin/liblin_{v}.so')
     for (k, m) in ((64, 128), (128, 64), (64, 64)):
         w = torch.randn(m, k, device=dev) / 8
