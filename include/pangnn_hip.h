@@ -99,6 +99,13 @@ int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, const float* 
                         const float* x, int64_t ldx, int64_t n_src_rows,
                         const float* bias, float* out, int64_t ldo, int64_t n_rows,
                         int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream);
+/* The same product with the gathered rows stored as bfloat16 (8 bytes per lane and row piece instead of 16): x is
+ * [n_src_rows, ldx] bf16, 8-byte aligned; weights, accumulation, bias and the result are fp32.  This is what the
+ * reference computes under `accelerate` bf16 mixed precision (PyG: bf16 x_j * fp32 edge weight -> fp32, scatter-add
+ * into fp32), and the storage format SURVEY.md §8b lists for config 5.  F in {32, 64, 128, 256}. */
+int pangnn_spmm_csr_bf16(const int64_t* rowptr, const int32_t* idx, const float* val, const void* x_bf16,
+                         int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
+                         int64_t n_rows, int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * edge decoder gather (k7; src/gnn.py:171-177):

@@ -28,6 +28,7 @@ SIGNATURES = {
     "pangnn_gcn_edge_norm_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p]),
     "pangnn_permute_f32": (C.c_int, [_p, _p, _p, _i64, _p]),
     "pangnn_spmm_csr_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, C.c_int, _p]),
+    "pangnn_spmm_csr_bf16": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, C.c_int, _p]),
     "pangnn_edge_gather_concat_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _i32, _p]),
     "pangnn_edge_pair_add_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _i32, _p]),
     "pangnn_segment_sum_rows_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32, C.c_int, _p]),

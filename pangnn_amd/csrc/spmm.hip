@@ -11,7 +11,17 @@
 
 namespace pangnn {
 
-template <int F, int U, bool BIG>
+// XBF: the gathered rows are stored as bfloat16 (8 bytes per lane instead of 16; SURVEY.md §8b `X f32/bf16`, the
+// storage format of config 5).  Weights, accumulation and the result stay fp32 — what PyG's propagate computes
+// under bf16 autocast (bf16 x_j times fp32 edge weight promotes to fp32, scatter-add into an fp32 output).
+__device__ __forceinline__ float4 row_piece(const char* p, bool xbf) {
+  if (!xbf) return *reinterpret_cast<const float4*>(p);
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                     __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+}
+
+template <int F, int U, bool BIG, bool XBF = false>
 __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
     const float* __restrict__ val, const float* __restrict__ x, int64_t ldx,
@@ -32,8 +42,9 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
   const int64_t end = rowptr[row + 1];
 
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const char* xbase = reinterpret_cast<const char*>(x) + fl * 16;
-  const uint32_t ldx_b32 = (uint32_t)(ldx * 4);
+  constexpr int ES = XBF ? 2 : 4;                     // bytes per stored element
+  const char* xbase = reinterpret_cast<const char*>(x) + fl * 4 * ES;
+  const uint32_t ldx_b32 = (uint32_t)(ldx * ES);
 
   // prefetch first block of 64 list entries
   int c_nxt = 0;
@@ -66,13 +77,15 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
         const int c = __shfl(c_cur, k);
         vv[u] = __shfl(v_cur, k);
         if (k < cnt) {
-          if (BIG) {
+          if (BIG && !XBF) {
             // > 4 GiB tables are the per-edge gradient rows of the decoder: each row is read exactly once
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (int64_t)c * ldx * 4));
             xv[u] = make_float4(t[0], t[1], t[2], t[3]);
+          } else if (BIG) {
+            xv[u] = row_piece(xbase + (int64_t)c * ldx * ES, XBF);
           } else {
-            xv[u] = *reinterpret_cast<const float4*>(xbase + (uint32_t)c * ldx_b32);
+            xv[u] = row_piece(xbase + (uint32_t)c * ldx_b32, XBF);
           }
         } else {
           xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -173,6 +186,23 @@ __global__ __launch_bounds__(kBlock) void spmm_row_generic_kernel(
 }
 
 template <int F, int U>
+static int launch_spmm_bf16(const int64_t* rowptr, const int32_t* idx, const float* val, const void* x,
+                            int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
+                            int64_t n_rows, int accumulate, hipStream_t s) {
+  const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  const bool big = (double)n_src_rows * (double)ldx * 2.0 >= 4294967296.0;
+  const float* xf = static_cast<const float*>(x);
+  if (big)
+    hipLaunchKernelGGL((spmm_row_kernel<F, U, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       rowptr, idx, val, xf, ldx, bias, out, ldo, n_rows, accumulate);
+  else
+    hipLaunchKernelGGL((spmm_row_kernel<F, U, false, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       rowptr, idx, val, xf, ldx, bias, out, ldo, n_rows, accumulate);
+  PG_CHECK_LAUNCH("pangnn_spmm_csr_bf16");
+  return 0;
+}
+
+template <int F, int U>
 static int launch_spmm(const int64_t* rowptr, const int32_t* idx, const float* val, const float* x,
                        int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
                        int64_t n_rows, int accumulate, hipStream_t s) {
@@ -260,4 +290,30 @@ extern "C" int pangnn_segment_sum_rows_f32(const int64_t* rowptr, const int32_t*
                (long long)col_off, (long long)(col_off + F), (long long)ldm);
   return pangnn_spmm_csr_f32(rowptr, perm, nullptr, m + col_off, ldm, n_m_rows, nullptr,
                              out, ldo, n_rows, n_m_rows, F, accumulate, stream);
+}
+
+extern "C" int pangnn_spmm_csr_bf16(const int64_t* rowptr, const int32_t* idx, const float* val,
+                                    const void* x_bf16, int64_t ldx, int64_t n_src_rows,
+                                    const float* bias, float* out, int64_t ldo, int64_t n_rows,
+                                    int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream) {
+  (void)nnz;
+  PG_CHECK_ARG(n_rows >= 0 && n_src_rows >= 0 && F > 0, PANGNN_E_BADARG, "pangnn_spmm_csr_bf16: negative size");
+  if (n_rows == 0) return 0;
+  PG_CHECK_ARG(rowptr && out && (x_bf16 || n_src_rows == 0) && ldx >= F && ldo >= F, PANGNN_E_BADARG,
+               "pangnn_spmm_csr_bf16: null pointer / leading dimension smaller than F");
+  PG_CHECK_ARG((reinterpret_cast<uintptr_t>(x_bf16) & 7u) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
+                   ldx % 4 == 0 && ldo % 4 == 0,
+               PANGNN_E_ALIGN, "pangnn_spmm_csr_bf16: x must be 8-byte aligned, out / bias 16-byte, ld multiples of 4");
+  PG_CHECK_ARG((n_rows + kWavesPerBlock - 1) / kWavesPerBlock < 2147483647LL, PANGNN_E_TOOLARGE,
+               "pangnn_spmm_csr_bf16: too many rows for one launch");
+  hipStream_t s = (hipStream_t)stream;
+  switch (F) {
+    case 32:  return launch_spmm_bf16<32, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+    case 64:  return launch_spmm_bf16<64, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+    case 128: return launch_spmm_bf16<128, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+    case 256: return launch_spmm_bf16<256, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
+    default: break;
+  }
+  set_error("pangnn_spmm_csr_bf16: F must be 32, 64, 128 or 256 (got %d)", (int)F);
+  return PANGNN_E_BADARG;
 }

@@ -48,11 +48,19 @@ def _timer_stop(tag, ev0):
 def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int,
              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
              accumulate: bool = False, tag: Optional[str] = None) -> torch.Tensor:
-    """out[r] (+)= bias + sum_e val[e] * x[other[e]]  — pangnn_spmm_csr_f32."""
+    """out[r] (+)= bias + sum_e val[e] * x[other[e]]  — pangnn_spmm_csr_f32, or pangnn_spmm_csr_bf16 when the
+    gathered rows are stored as bfloat16 (fp32 weights / accumulation / result either way)."""
     lib = _lib.load()
     _lib.require_device(x, csr.rowptr, val, bias)
-    x = _f32c(x)
     f = x.shape[1]
+    bf16 = x.dtype == torch.bfloat16 and f in (32, 64, 128, 256)
+    if bf16:
+        if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 8:
+            x = x.contiguous()
+        fn, name = lib.pangnn_spmm_csr_bf16, "pangnn_spmm_csr_bf16"
+    else:
+        x = _f32c(x)
+        fn, name = lib.pangnn_spmm_csr_f32, "pangnn_spmm_csr_f32"
     if out is None:
         out = torch.empty(n_rows, f, dtype=torch.float32, device=x.device)
         accumulate = False
@@ -61,10 +69,10 @@ def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _lib.check(lib.pangnn_spmm_csr_f32(csr.rowptr.data_ptr(), _lib.ptr(csr.other), _lib.ptr(val),
-                                           x.data_ptr(), x.stride(0), x.shape[0], _lib.ptr(bias),
-                                           out.data_ptr(), out.stride(0), n_rows, int(csr.other.shape[0]), f,
-                                           int(accumulate), _lib.stream_ptr()), "pangnn_spmm_csr_f32")
+        _lib.check(fn(csr.rowptr.data_ptr(), _lib.ptr(csr.other), _lib.ptr(val),
+                      x.data_ptr(), x.stride(0), x.shape[0], _lib.ptr(bias),
+                      out.data_ptr(), out.stride(0), n_rows, int(csr.other.shape[0]), f,
+                      int(accumulate), _lib.stream_ptr()), name)
         if timed:
             ev1.record()
             KERNEL_TIMER[tag].append((ev0, ev1))
@@ -97,6 +105,7 @@ class _Propagate(torch.autograd.Function):
     def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
         ctx.st, ctx.norm, ctx.tag = st, norm, tag
         ctx.has_bias = bias is not None
+        ctx.x_dtype = x.dtype            # bfloat16 rows are gathered as stored (half the bytes); result fp32
         return spmm_csr(st.by_dst, norm.by_dst, x, st.num_nodes, bias=None if bias is None else _f32c(bias),
                         tag=None if tag is None else tag + ".fwd")
 
@@ -107,6 +116,8 @@ class _Propagate(torch.autograd.Function):
         gx = spmm_csr(st.by_src, norm.by_src, g, st.num_src,
                       tag=None if ctx.tag is None else ctx.tag + ".bwd") if ctx.needs_input_grad[0] else None
         gb = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        if gx is not None and gx.dtype != ctx.x_dtype:
+            gx = gx.to(ctx.x_dtype)
         return gx, gb, None, None, None
 
 

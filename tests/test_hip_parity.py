@@ -918,3 +918,31 @@ def test_folded_activation_model_equals_layerwise_model():
         for k, gk in res[1][2].items():
             scale = float(gk.abs().max()) + 1e-12
             assert close(res[0][2][k], gk, atol=1e-4 * scale + 1e-9, rtol=1e-3), (flags, k)
+
+
+# ---------------------------------------------------------------- propagate over bfloat16-stored rows
+@pytest.mark.parametrize("F", [32, 64, 128, 256])
+@pytest.mark.parametrize("n,e,hub", [(1, 5, None), (513, 7000, 3000), (2000, 30000, None)])
+def test_spmm_bf16_rows_match_oracle_on_rounded_inputs(F, n, e, hub):
+    """bf16 storage of the gathered rows, fp32 weights / accumulation / result: equal (to fp32 rounding) to the
+    oracle run on the bf16-rounded features; the gradient w.r.t. the rows comes back in bf16"""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    ei, w = random_graph(n, e, seed=F + n, hub=hub)
+    torch.manual_seed(F)
+    x = torch.randn(n, F)
+    xb = x.to(torch.bfloat16)
+    b = torch.randn(F)
+    norm_ref = go.gcn_norm(ei, w.double(), n, dtype=torch.float64)
+    ref = go.propagate_add(xb.double(), ei, norm_ref) + b.double()
+    st = EdgeStructure(ei.to(dev()), n)
+    norm = st.gcn_norm(w.to(dev()))
+    xd = xb.to(dev()).requires_grad_(True)
+    out = PF.propagate(xd, b.to(dev()), st, norm)
+    assert out.dtype == torch.float32
+    assert close(out, ref, atol=1e-4, rtol=1e-4)
+    g = torch.randn(n, F)
+    out.backward(g.to(dev()))
+    assert xd.grad.dtype == torch.bfloat16
+    gref = go.propagate_add(g.double(), ei.flip(0), norm_ref)             # transposed propagate
+    assert close(xd.grad.float(), gref, atol=2e-2 * (float(gref.abs().max()) + 1e-12), rtol=2e-2)
