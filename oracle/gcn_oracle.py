@@ -55,7 +55,7 @@ def propagate_add(x: torch.Tensor, edge_index: torch.Tensor, norm: torch.Tensor)
     issued exactly as PyG's edge_index mode does: index_select -> mul -> index_add_."""
     x_j = x.index_select(0, edge_index[0])           # gather SOURCE rows   [E,F]
     msg = norm.view(-1, 1) * x_j                     #                      [E,F]
-    out = torch.zeros_like(x)
+    out = torch.zeros(x.shape, dtype=msg.dtype, device=x.device)   # PyG scatter: src.new_zeros (dtype of the messages)
     out.index_add_(0, edge_index[1], msg)            # scatter-add at TARGET
     return out
 

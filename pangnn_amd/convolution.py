@@ -132,15 +132,19 @@ class GCNConv(MessagePassing):
             raise ValueError(f"edge_weight has {edge_weight.shape[0]} entries for {st.num_edges} edges")
         norm = st.gcn_norm(edge_weight)
         x = x.float()
+        # Under bf16 autocast (`accelerate` mixed precision) PyG's propagate gathers bf16 rows — the
+        # output of its autocast Linear — and multiplies / accumulates in fp32: the rows this layer propagates are
+        # stored in bfloat16 (half the gather bytes, pangnn_spmm_csr_bf16); the dense part itself stays fp32.
+        rows_bf16 = x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
         if in_elu and self.in_channels < self.out_channels:
             x, in_elu = torch.nn.functional.elu(x), False       # propagate comes first: nothing to fold into
         if self.in_channels < self.out_channels:
             # A_hat (x W^T) == (A_hat x) W^T: propagate on the narrower side (half the gather bytes for
             # 64 -> 128), then the dense layer with the bias fused
-            agg = PF.propagate(x, None, st, norm, tag=name or None)
+            agg = PF.propagate(x.to(torch.bfloat16) if rows_bf16 else x, None, st, norm, tag=name or None)
             return PF.linear(agg, self.lin.weight, self.bias)
         xw = self.lin(x, 1 if in_elu else 0)
-        return PF.propagate(xw, self.bias, st, norm, tag=name or None)
+        return PF.propagate(xw.to(torch.bfloat16) if rows_bf16 else xw, self.bias, st, norm, tag=name or None)
 
     def message(self, x_j, edge_weight):            # kept for API parity; forward() is fused
         return edge_weight.view(-1, 1) * x_j

@@ -946,3 +946,29 @@ def test_spmm_bf16_rows_match_oracle_on_rounded_inputs(F, n, e, hub):
     assert xd.grad.dtype == torch.bfloat16
     gref = go.propagate_add(g.double(), ei.flip(0), norm_ref)             # transposed propagate
     assert close(xd.grad.float(), gref, atol=2e-2 * (float(gref.abs().max()) + 1e-12), rtol=2e-2)
+
+
+def test_gcnconv_under_bf16_autocast_propagates_bf16_rows():
+    """`accelerate` bf16 mixed precision: the reference's GCNConv then runs its Linear in bf16 and the propagate on
+    bf16 rows with fp32 accumulation; here the rows are stored in bf16 (the dense part stays fp32, i.e. more
+    accurate than the reference), so the result agrees with the oracle under CPU autocast to bf16 resolution"""
+    import pangnn_amd
+    g = whole_graph_from_golden("cfg2_sim_1000x5")
+    n = g.x.shape[0]
+    torch.manual_seed(4)
+    x = torch.randn(n, 128)
+    conv_o = go.GCNConvOracle(128, 64)
+    with torch.no_grad():
+        conv_o.bias.uniform_(-0.5, 0.5)
+    conv = pangnn_amd.GCNConv(128, 64).to(dev())
+    conv.load_state_dict(conv_o.state_dict())
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref = conv_o(x, g.edge_index, g.edge_attr).float()
+    exact = conv_o(x, g.edge_index, g.edge_attr)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = conv(x.to(dev()), g.edge_index.to(dev()), g.edge_attr.to(dev()))
+    assert out.dtype == torch.float32
+    scale = float(exact.abs().max())
+    assert float((out.cpu() - ref).abs().max()) < 3e-2 * scale            # bf16 resolution vs the autocast oracle
+    assert float((out.cpu() - exact).abs().max()) < 1e-2 * scale          # only the stored rows are rounded
+    assert float((out.cpu() - exact).abs().max()) > 1e-6 * scale          # ... and they are
