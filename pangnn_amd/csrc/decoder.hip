@@ -504,9 +504,31 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
           rs.part[pidx * DD + r] = s0;
           rs.part[pidx * DD + 32 + r] = s1;
         }
+      } else if (__builtin_popcount(m) == 2) {
+        // two runs: both column sums from the registers, rows selected by their position relative to the boundary
+        const int bnd = __builtin_ctz(m);            // last edge of the first run
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool first = jr(i, hh) <= bnd;
+          a0 += first ? acc2[0][i] : 0.f;
+          b0 += first ? 0.f : acc2[0][i];
+          a1 += first ? acc2[1][i] : 0.f;
+          b1 += first ? 0.f : acc2[1][i];
+        }
+        a0 += __shfl_xor(a0, 32);
+        a1 += __shfl_xor(a1, 32);
+        b0 += __shfl_xor(b0, 32);
+        b1 += __shfl_xor(b1, 32);
+        if (hh == 0) {
+          rs.part[pidx * DD + r] = a0;
+          rs.part[pidx * DD + 32 + r] = a1;
+          rs.part[(pidx + 1) * DD + r] = b0;
+          rs.part[(pidx + 1) * DD + 32 + r] = b1;
+        }
       } else {
-        // several runs: dL/dh1 tile -> LDS (the h1 image is no longer needed); every lane owns one of the 64
-        // columns and walks the 32 rows
+        // three or more runs: dL/dh1 tile -> LDS (the h1 image is no longer needed); every lane owns one of the
+        // 64 columns and walks the 32 rows
         wave_lds_sync();
 #pragma unroll
         for (int bp = 0; bp < 2; ++bp)
@@ -944,9 +966,32 @@ __global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
           rs.part[pidx * DD + r] = s0;
           rs.part[pidx * DD + 32 + r] = s1;
         }
+      } else if (__builtin_popcount(m) == 2) {
+        // two runs (a source boundary inside the tile: 32/75 of the tiles at cfg 4): both column sums from the
+        // registers, rows selected by their position relative to the boundary — no trip through LDS
+        const int bnd = __builtin_ctz(m);            // last edge of the first run
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool first = jr(i, hh) <= bnd;
+          a0 += first ? acc2[0][i] : 0.f;
+          b0 += first ? 0.f : acc2[0][i];
+          a1 += first ? acc2[1][i] : 0.f;
+          b1 += first ? 0.f : acc2[1][i];
+        }
+        a0 += __shfl_xor(a0, 32);
+        a1 += __shfl_xor(a1, 32);
+        b0 += __shfl_xor(b0, 32);
+        b1 += __shfl_xor(b1, 32);
+        if (hh == 0) {
+          rs.part[pidx * DD + r] = a0;
+          rs.part[pidx * DD + 32 + r] = a1;
+          rs.part[(pidx + 1) * DD + r] = b0;
+          rs.part[(pidx + 1) * DD + 32 + r] = b1;
+        }
       } else {
-        // several runs: dL/dh1 tile -> LDS (the h1 image is no longer needed); every lane owns one of the 64
-        // columns and walks the 32 rows
+        // three or more runs: dL/dh1 tile -> LDS (the h1 image is no longer needed); every lane owns one of the
+        // 64 columns and walks the 32 rows
         wave_lds_sync();
 #pragma unroll
         for (int bp = 0; bp < 2; ++bp)
