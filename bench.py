@@ -132,11 +132,29 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal hooks (tests/test_bench_ranks.py): several ranks on ONE GPU over gloo — RCCL refuses two ranks on a
+    # device — to run this file's N > 1 branch end to end; the product run is one rank per GPU over RCCL
+    backend = os.environ.get("PANGNN_BENCH_BACKEND", "nccl")
+    if os.environ.get("PANGNN_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce_(t, op):
+        """small control-plane reductions; staged through the host on gloo"""
+        if backend == "nccl":
+            torch.distributed.all_reduce(t, op=op)
+        else:
+            c = t.cpu()
+            torch.distributed.all_reduce(c, op=op)
+            t.copy_(c)
+        return t
 
     import pangnn_amd
     from pangnn_amd import functional as PF
@@ -167,8 +185,8 @@ def main():
         chk = torch.stack([g.edge_index.sum(), g.edge_index[0].max(), torch.tensor(e_sim, device=dev),
                            (g.edge_attr.double().sum() * 1e3).long()]).long()
         lo_, hi_ = chk.clone(), chk.clone()
-        torch.distributed.all_reduce(lo_, op=torch.distributed.ReduceOp.MIN)
-        torch.distributed.all_reduce(hi_, op=torch.distributed.ReduceOp.MAX)
+        all_reduce_(lo_, torch.distributed.ReduceOp.MIN)
+        all_reduce_(hi_, torch.distributed.ReduceOp.MAX)
         if not torch.equal(lo_, hi_):
             raise RuntimeError("ranks generated different graphs from the same seed")
         part = pdist.partition_graph(g, rank, world)
@@ -204,8 +222,10 @@ def main():
     timer, PF.KERNEL_TIMER = PF.KERNEL_TIMER, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        all_reduce_(t, torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        # a rank's loss is its share of the global mean (local sum / global edge count): report the whole job's
+        loss = all_reduce_(loss.detach().clone().reshape(1), torch.distributed.ReduceOp.SUM)[0]
 
     k_fwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["sim.fwd"]]
     k_bwd = [a.elapsed_time(b) * 1e-3 for a, b in timer["sim.bwd"]]

@@ -1,0 +1,42 @@
+"""bench.py's N > 1 branch end to end (graph agreement check, partition, per-rank timers, max-over-ranks, ONE JSON
+line from rank 0) — rehearsed with several ranks on the single GPU of the test box over gloo (rehearsal hooks in
+bench.py: PANGNN_BENCH_BACKEND / PANGNN_BENCH_ONE_GPU); the scaling run proper is one rank per GPU over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _run(cmd, env_extra):
+    env = dict(os.environ, **env_extra)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                    # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_line(world):
+    common = ["--workload", "cfg2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    one = _run([sys.executable, "bench.py"] + common, {})
+    many = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                 "--master-addr", "127.0.0.1", "--master-port", str(29640 + world), "bench.py", "--gpus", str(world)]
+                + common, {"PANGNN_BENCH_BACKEND": "gloo", "PANGNN_BENCH_ONE_GPU": "1"})
+    for d in (one, many):
+        assert all(k in d for k in REQUIRED), d.keys()
+        assert d["value"] > 0 and d["steps"] == 4 and d["warmup"] == 2
+    assert one["n_gpus"] == 1 and many["n_gpus"] == world
+    assert many["config"]["sim_edges"] == one["config"]["sim_edges"]          # the whole job's edges, not a shard's
+    assert "destination-partitioned" in many["config"]["partition"]
+    # same seed, same initial weights, same six steps: the partitioned job follows the single-GPU loss
+    assert abs(many["config"]["final_loss"] - one["config"]["final_loss"]) < 2e-3
+    assert many["roofline"]["avg_launch_ms"] > 0
