@@ -205,6 +205,50 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
                                 size_t workspace_bytes, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Two-wave-per-SIMD training decoder (csrc/decoder16.hip) — what `precision = 1` training uses.
+ * Replaces forward + criterion + backward of src/gnn.py:171-177 / pangnn.py:200-207 with TWO passes and
+ * no [E, D] tensor:
+ *
+ * pangnn_decoder_train_f32  ("S"): one pass over the edges in the caller's order.  Exactly one of
+ *   y        (fused loss: logits[E], loss[1] = mean BCEWithLogits(pos_weight) over `denom` edges are outputs and
+ *             dL/dlogit is produced in place), or
+ *   g_logits (given dL/dlogits[E]; logits nullable)
+ *   is set.  Outputs: the parameter gradients g_w2[D,D], g_w3[D], g_b3[1], g_cvec[D] (nullable) — dL/db2 comes
+ *   out of the dgrad pass (it needs only the records; keeping its per-lane partial sums out of this kernel is
+ *   what lets two waves share a SIMD without spilling),
+ *   rec[E][8] uint32 (nullable): per edge {4 dwords of relu masks, dL/dlogit_e, 3 unused} for the dgrad pass,
+ *   part_buf / part_off (both NULL or both set; edge list sorted by source): sums of dL/dh1 over every
+ *   (32-edge tile, source) run, as in pangnn_decoder_mlp_bwd_f32.
+ *   Arithmetic: every product on the bf16 matrix pipe with fp32 accumulation and fp32-exact operand handling —
+ *   W2 h1 with both operands split into three bf16 terms (6 partial products); dL/dh1 = m1 g_e (m2^T W2') and
+ *   dL/dW2 = diag(w3) m2 (g_e h1) with the relu mask m2 as the EXACT bf16 operand and the other operand split
+ *   three ways.  The last tile is padded by clamping edge ids (one tile body, no divergent matrix operands).
+ *   workspace: pangnn_decoder_train_workspace_bytes().
+ *
+ * pangnn_decoder_dgrad_f32  ("T"): dL/dh1 summed over runs of equal keys in a permuted edge order, from `rec`:
+ *   position k of the order is edge perm[k] (NULL = identity) with run key keys[k] (non-decreasing, e.g. the
+ *   target id in by-target CSR order); part_buf / part_off as above for THIS order.  dL/dQ[t] is then the sum
+ *   of the consecutive parts of target t (pangnn_spmm_csr_f32 with idx == NULL).  g_cvec (nullable, needs
+ *   `extra`) = sum_e extra_e dL/dh1[e];  g_b2[D] (nullable) = dL/db2 = w3[j] sum_e g_e [h2[j][e] > 0] — ask for it
+ *   in exactly one dgrad call per step.  part_buf / part_off / keys may all be NULL to get the parameter sums
+ *   alone.  workspace (with g_cvec or g_b2): pangnn_decoder_dgrad_workspace_bytes().
+ * Both are reproducible (fixed-order sums, no float atomics).
+ * ---------------------------------------------------------------------------------------- */
+size_t pangnn_decoder_train_workspace_bytes(void);
+int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
+                             const int64_t* edge_index, int64_t ld, int64_t num_edges, const float* extra,
+                             const float* cvec, const float* w2, const float* b2, const float* w3,
+                             const float* b3, int32_t D, const float* y, const float* pos_weight,
+                             int64_t denom, const float* g_logits, float* logits, float* loss, uint32_t* rec,
+                             float* part_buf, const int32_t* part_off, float* g_w2, float* g_w3, float* g_b3,
+                             float* g_cvec, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+size_t pangnn_decoder_dgrad_workspace_bytes(void);
+int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys, const float* extra,
+                             const float* w2, const float* w3, int64_t num_edges, float* part_buf,
+                             const int32_t* part_off, float* g_cvec, float* g_b2, void* workspace,
+                             size_t workspace_bytes, pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Node-level dense layers with a short inner dimension, K (in) and M (out) in {64, 128}
  * (GCNConv.lin = k4 of SURVEY.md §2.2, the decoder's node-level P|Q product, and their backward):
  *   fwd  : y[n, 0:M]  = x[n, 0:K] . w[M,K]^T (+ bias[M])          (dL/dx = g . w is fwd with w^T)

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpangnn_hip.so")
+LIB_PATH = os.environ.get("PANGNN_HIP_LIB") or os.path.join(_HERE, "libpangnn_hip.so")   # override: diagnostic builds (tools/)
 
 _i64, _i32, _p, _sz = C.c_int64, C.c_int32, C.c_void_p, C.c_size_t
 
@@ -57,6 +57,16 @@ SIGNATURES = {
                                               _p, _p, _i64,                            # y, pos_weight, denom
                                               _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,  # logits .. part_off
                                               _i32, _p, _sz, _p]),
+    # two-wave-per-SIMD training decoder (csrc/decoder16.hip): S kernel (+ by-source run sums, per-edge records)
+    "pangnn_decoder_train_workspace_bytes": (_sz, []),
+    "pangnn_decoder_train_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
+                                           _p, _p, _i64, _p,                        # y, pos_weight, denom, g_logits
+                                           _p, _p, _p, _p, _p,                      # logits, loss, rec, part_buf, part_off
+                                           _p, _p, _p, _p,                          # g_w2, g_w3, g_b3, g_cvec
+                                           _p, _sz, _p]),
+    # T kernel: dL/dh1 run sums in a permuted (CSR) edge order from the records
+    "pangnn_decoder_dgrad_workspace_bytes": (_sz, []),
+    "pangnn_decoder_dgrad_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

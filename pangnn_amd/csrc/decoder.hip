@@ -78,16 +78,9 @@ __device__ __forceinline__ void stage_weights(const DecParams& a, float* Wl, flo
 
 // ---- gather the tile's 32 h1 rows into the wave's LDS image.  Returns w_e / validity per lane e.
 // FULL: all 32 edges exist (every tile but the last): no bounds predicate on the id loads.
-// max(x, 0) as ONE instruction: fmaxf() makes the compiler put a canonicalising v_max(x, x) in front of it
-__device__ __forceinline__ float relu1(float x) {
-#ifdef PANGNN_NO_ASM_RELU
-  return fmaxf(x, 0.f);
-#else
-  float y;
-  asm("v_max_f32 %0, %1, 0" : "=v"(y) : "v"(x));
-  return y;
-#endif
-}
+// max(x, 0), compiler-visible (not inline asm: an asm statement that defines a VGPR is invisible to the MFMA hazard
+// recognizer and may overwrite a source register of an in-flight MFMA — see decoder16.hip)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 
 // 16-byte row piece at `table + byte_off`: uniform base pointer + 32-bit per-lane byte offset (node tables are
 // < 4 GiB, checked by the host wrapper) — `global_load_dwordx4 v, v_off, s[base]`, no 64-bit vector address
@@ -1187,11 +1180,20 @@ __global__ __launch_bounds__(kSumThreads) void decoder_reduce_kernel(const float
   const float s = ordered_parts_sum(slabs, n_slabs, SLAB, i, 4096 + 194);
   if (threadIdx.x >= kWave || i >= 4096 + 194) return;
   if (i < 4096) g_w2[i] = s;
-  else if (i < 4096 + 64) g_b2[i - 4096] = s;
+  else if (i < 4096 + 64) { if (g_b2) g_b2[i - 4096] = s; }
   else if (i < 4096 + 128) g_w3[i - 4096 - 64] = s;
   else if (i < 4096 + 192) { if (g_cvec) g_cvec[i - 4096 - 128] = s; }
   else if (i == 4096 + 192) g_b3[0] = s;
   else if (loss) loss[0] = s;
+}
+
+// for decoder16.hip: the same finishing reduction over its slabs (same layout)
+int launch_decoder_reduce(const float* slabs, int n_slabs, float* g_w2, float* g_b2, float* g_w3, float* g_cvec,
+                          float* g_b3, float* loss, hipStream_t s) {
+  hipLaunchKernelGGL(decoder_reduce_kernel, dim3((4096 + 194 + kWave - 1) / kWave), dim3(kSumThreads), 0, s, slabs,
+                     n_slabs, g_w2, g_b2, g_w3, g_cvec, g_b3, loss);
+  PG_CHECK_LAUNCH("decoder_reduce");
+  return 0;
 }
 
 static int grid_cus() {

@@ -1,0 +1,947 @@
+// Training form of the fused link decoder for D = 64 (src/gnn.py:110-116,171-177; pangnn.py:200-207), gfx950,
+// bf16 matrix pipe with fp32-exact operand splitting, TWO waves per SIMD.
+//
+//   h1[e]   = relu(P[src_e] + Q[dst_e] (+ w_e c))     P = z W1a^T, Q = z W1b^T + b1   (node level)
+//   h2[e]   = relu(W2 h1[e] + b2)
+//   logit_e = w3 . h2[e] + b3 ;  loss = mean BCEWithLogits(pos_weight)
+//
+// Two kernels replace the one-wave-per-SIMD kernel of round 1 (decoder_bwd_x3_kernel) and the 19 GB
+// dL/dh1 [E,64] round trip behind it:
+//
+//  S  decoder_train16_kernel   edges in the caller's order, 16-edge half tiles on v_mfma_f32_16x16x32_bf16:
+//       P1  C[j][e] = sum_k W2[j][k] h1[e][k]            (three-way split operands, 6 partial products)
+//       loss, g_e = dL/dlogit_e, m2[j][e] = [h2 > 0], m1[e][k] = [h1 > 0]
+//       P2  dL/dh1[e][k] = m1 g_e sum_j m2[j][e] W2'[j][k],   W2' = diag(w3) W2   (A = m2 is EXACT in bf16,
+//           B = W2' split three ways: 3 products, fp32-exact)          -> per-(tile, source) run sums
+//       P3  dL/dW2[j][k] = w3[j] sum_e m2[j][e] (g_e h1[e][k])        (A = m2 exact, B = g_e h1 split three
+//           ways: v_mfma_f32_32x32x16_bf16 with K = the 16 edges)
+//     and a 32-byte record per edge {m1 | m2 bit masks (16 B), g_e} for the target side.
+//  T  decoder_dgrad16_kernel   edges in by-target order (through the CSR permutation): rebuilds m2 / m1 / g_e
+//       from the records (no node-row gathers, no P1), runs P2 and sums dL/dh1 over target runs.
+//
+// Per wave and 16 edges: 48 + 24 MFMA(16x16x32) + 12 MFMA(32x32x16) in S, 24 in T; every product carries
+// fp32-level error (no two-term shortcuts).  No divergent control flow around matrix operands: the last tile is
+// padded by clamping edge ids to E-1 (dead lanes compute a duplicate whose dL/dlogit is forced to 0), so there is
+// ONE tile body, every lane is active in every MFMA / transposing LDS read, and only global stores are predicated.
+#include "common.h"
+
+namespace pangnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D16 = 64;
+constexpr int SLAB16 = 64 * 64 + 64 + 64 + 64 + 16;   // gW2 | gb2 | gw3 | gcvec | gb3, loss (+pad): layout of decoder.hip
+constexpr int S_WAVES = 8;                            // 512 threads, one workgroup per CU, two waves per SIMD
+constexpr int T_WAVES = 16;                           // dgrad kernel: light, latency bound
+
+// ---- LDS images.  Rows of 64 bf16 = 128 B = 8 chunks of 16 B, unpadded; chunk ch of row r sits at
+// physical chunk ch ^ f(r).  The swizzles make every access pattern below conflict-free (tools/lds_banks.py):
+//  weight images (rows j or k, read with ds_read_b128 as 16x16x32 A / B fragments): f(r) = r & 6
+//  per-wave tile images (rows e, read with ds_read_b64_tr_b16):                     f(r) = ((r&2)<<1) | ((r&4)>>1)
+__device__ __forceinline__ constexpr int wsw(int r) { return r & 6; }
+__device__ __forceinline__ constexpr int tsw(int r) { return ((r & 2) << 1) | ((r & 4) >> 1); }
+
+constexpr int W_IMG = 64 * 128;                       // bytes of one weight image
+constexpr int T_IMG = 16 * 128;                       // bytes of one tile image
+constexpr int LDS_W2 = 0;                             // W2 hi | mid | lo          (P1 A operand)
+constexpr int LDS_W2P = 3 * W_IMG;                    // W2'^T hi | mid | lo       (P2 B operand)
+constexpr int LDS_VEC = 6 * W_IMG;                    // b2 | w3 | cvec   (3 x 64 floats)
+constexpr int LDS_WAVE0 = LDS_VEC + 3 * 64 * 4;
+// per wave: Hg hi | mid | lo | m2 image | recl[16][4] | gl[16] | wl[16]
+constexpr int WV_HG = 0, WV_M2 = 3 * T_IMG, WV_REC = 4 * T_IMG, WV_GL = WV_REC + 256, WV_WL = WV_GL + 64;
+constexpr int WV_BYTES = WV_WL + 64;                  // 8576
+constexpr int S_LDS = LDS_WAVE0 + S_WAVES * WV_BYTES;
+
+struct Split3 { bf16x8 hi, mid, lo; };
+// x = hi + mid + lo EXACTLY: three bf16 terms by truncation (8 + 8 + 8 significand bits, all of the sign of x).
+// Per element: and, sub, and, sub; the three terms of two neighbours are packed by one v_perm_b32 each.
+__device__ __forceinline__ Split3 split8(const float (&f)[8]) {
+  u32x4 hi, mid, lo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, f[2 * q]), b = __builtin_bit_cast(uint32_t, f[2 * q + 1]);
+    hi[q] = __builtin_amdgcn_perm(b, a, 0x07060302u);                       // the two high halves
+    const float ra = f[2 * q] - __builtin_bit_cast(float, a & 0xffff0000u);
+    const float rb = f[2 * q + 1] - __builtin_bit_cast(float, b & 0xffff0000u);
+    const uint32_t ua = __builtin_bit_cast(uint32_t, ra), ub = __builtin_bit_cast(uint32_t, rb);
+    mid[q] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float sa = ra - __builtin_bit_cast(float, ua & 0xffff0000u);
+    const float sb = rb - __builtin_bit_cast(float, ub & 0xffff0000u);
+    lo[q] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x07060302u);
+  }
+  Split3 r;
+  r.hi = __builtin_bit_cast(bf16x8, hi);
+  r.mid = __builtin_bit_cast(bf16x8, mid);
+  r.lo = __builtin_bit_cast(bf16x8, lo);
+  return r;
+}
+
+// max(x, 0) as a compiler-visible instruction.  NOT inline asm: an asm statement that DEFINES a VGPR is invisible
+// to LLVM's MFMA hazard recognizer, so it can be scheduled right behind an MFMA that still reads that register as a
+// source operand (write-after-read on an in-flight matrix instruction) — the later passes of the MFMA then see the
+// new value.  That is what made the round-1 kernel's "AGPR form" build intermittently wrong and what zeroed rows
+// 12-15 of this kernel's second product in its first version (tools/find_asm_mfma_war.py).
+// Written as an integer max of the bit pattern (negative floats are negative integers): one v_max_i32, without the
+// canonicalising v_max_f32(x, x) hipcc puts in front of a float max.
+__device__ __forceinline__ float relu1(float x) {
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
+// x + x[lane ^ 16] and x + x[lane ^ 32] as one swap + one add each (gfx950 v_permlane{16,32}_swap; the
+// clang builtin folds the two results of a swap of a value with itself, so the instruction is written out;
+// the s_nop covers the VALU-write -> permlane-read wait states hipcc cannot see inside an asm statement).
+// Both registers are read-write operands whose initial values the compiler writes with its own (hazard-checked)
+// instructions, so — unlike a pure asm output — they cannot land on a register an in-flight MFMA still reads.
+__device__ __forceinline__ float xsum16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float xsum32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+// Sums of FOUR per-lane values over the four 16-lane rows with three swaps and three adds (no copies): a swap of
+// two DIFFERENT values hands each half (row pair) the other half's share of one of them.  Result: row 0 holds the
+// total of s0, row 1 of s2, row 2 of s1, row 3 of s3  (row g holds s[kRow4[g]]).
+__device__ __forceinline__ float red4(float s0, float s1, float s2, float s3) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s0), "+v"(s1));   // s0: [s0.lo, s1.lo]  s1: [s0.hi, s1.hi]
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s2), "+v"(s3));
+  float u = s0 + s1, w = s2 + s3;                  // rows 0,1: s0 (s2) summed over the halves; rows 2,3: s1 (s3)
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u), "+v"(w));     // u: [u.r0, w.r0, u.r2, w.r2]  w: [u.r1, w.r1, u.r3, w.r3]
+  return u + w;
+}
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef __attribute__((address_space(3))) short4v lds_s4;
+__device__ __forceinline__ short4v ld_tr4(const char* lds_base, int off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds_base + off));
+}
+__device__ __forceinline__ bf16x8 ld_tr8(const char* lds_base, int off_lo, int off_hi) {
+  struct P { short4v lo, hi; } p;
+  p.lo = ld_tr4(lds_base, off_lo);
+  p.hi = ld_tr4(lds_base, off_hi);
+  return __builtin_bit_cast(bf16x8, p);
+}
+__device__ __forceinline__ bf16x8 ld_b128(const char* lds_base, int off) {
+  return *reinterpret_cast<const bf16x8*>(lds_base + off);
+}
+
+#ifdef PANGNN_D16_DEBUG
+__device__ float* d16_dbg_v = nullptr;     // [E][64] dL/dh1pre as the S kernel sees it (diagnostic builds only)
+#endif
+
+struct D16Params {
+  const float* p; const float* q; uint32_t ldp_b; uint32_t ldq_b;   // row strides in bytes
+  const int64_t* ei; int64_t ld; int64_t E;
+  const float* extra; const float* cvec;
+  const float* w2; const float* b2; const float* w3; const float* b3;
+};
+struct D16Loss { const float* y; const float* pos_weight; float inv_denom; };
+struct D16Run { float* part; const int32_t* part_off; };
+
+__device__ __forceinline__ float4 ld_row16(const float* table, uint32_t byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table) + byte_off);
+}
+
+// ---- weights -> LDS images (once per workgroup).  which = 1: W2 (P1), 2: W2'^T (P2), 3: both.
+__device__ __forceinline__ void stage_weights16(const float* w2, const float* b2, const float* w3, const float* cvec,
+                                                char* lds, int nthreads, int which, int w2p_base, int vec_base) {
+  for (int i = threadIdx.x; i < 64 * 64; i += nthreads) {
+    const int j = i >> 6, k = i & 63;
+    const float w = w2[i];
+    if (which & 1) {
+      const __bf16 h = (__bf16)w;
+      const float r1 = w - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const __bf16 l = (__bf16)(r1 - (float)m);
+      const int off = LDS_W2 + j * 128 + (((k >> 3) ^ wsw(j)) << 4) + 2 * (k & 7);
+      *reinterpret_cast<__bf16*>(lds + off) = h;
+      *reinterpret_cast<__bf16*>(lds + off + W_IMG) = m;
+      *reinterpret_cast<__bf16*>(lds + off + 2 * W_IMG) = l;
+    }
+    if (which & 2) {
+      // row k; the 64 j of a row in the order P1's accumulator hands them to P2: K-step t = j >> 5, lane group
+      // g = (j >> 2) & 3, element s = 4 ((j >> 4) & 1) + (j & 3)   <->   chunk 4 t + g, element s
+      const float wp = w3[j] * w;
+      const __bf16 h = (__bf16)wp;
+      const float r1 = wp - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const __bf16 l = (__bf16)(r1 - (float)m);
+      const int t = j >> 5, g = (j >> 2) & 3, s = 4 * ((j >> 4) & 1) + (j & 3);
+      const int off = w2p_base + k * 128 + (((4 * t + g) ^ wsw(k)) << 4) + 2 * s;
+      *reinterpret_cast<__bf16*>(lds + off) = h;
+      *reinterpret_cast<__bf16*>(lds + off + W_IMG) = m;
+      *reinterpret_cast<__bf16*>(lds + off + 2 * W_IMG) = l;
+    }
+  }
+  float* vec = reinterpret_cast<float*>(lds + vec_base);
+  for (int i = threadIdx.x; i < 64; i += nthreads) {
+    vec[i] = b2 ? b2[i] : 0.f;
+    vec[64 + i] = w3[i];
+    vec[128 + i] = cvec ? cvec[i] : 0.f;
+  }
+}
+
+// ---- P2 + its epilogue + run sums, shared by S and T.  Lane (c = lane & 15, g = lane >> 4).
+//   a2[t]   mask m2 as bf16 0/1 A fragments: element s of K-step t is j = 32 t + 16 (s >> 2) + 4 g + (s & 3), edge c
+//   recl    [16][4] dwords in LDS: the m1 bits of edge e, lane group g' (bit 16 (s&1) + 7 - (4 ks + (s >> 1)) for
+//           k = 32 ks + 8 g' + s)
+//   gl      [16] floats in LDS: g_e
+// returns v[kb][i] = dL/dh1pre[e = 4 g + i][k = 16 kb + c]
+__device__ __forceinline__ void dgrad_tile(const char* lds, const char* recl, const char* gl, const bf16x8 (&a2)[2],
+                                           int c, int g, int w2p_off0, int w2p_off1, f32x4 (&v)[4]) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) v[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int off = (t ? w2p_off1 : w2p_off0) + kb * 2048;     // rows 16 kb + c
+      const bf16x8 b_hi = ld_b128(lds, off);
+      const bf16x8 b_mid = ld_b128(lds, off + W_IMG);
+      const bf16x8 b_lo = ld_b128(lds, off + 2 * W_IMG);
+      v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], b_lo, v[kb], 0, 0, 0);
+      v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], b_mid, v[kb], 0, 0, 0);
+      v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], b_hi, v[kb], 0, 0, 0);
+    }
+  // epilogue: times g_e, masked by m1
+  const f32x4 ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
+  const int bitpos = 16 * (c & 1) + 7 - ((c & 7) >> 1);
+  const char* rrow = recl + 64 * g + 4 * (c >> 3);      // edge 4 g + i at + 16 i; dwords (c >> 3) and 2 + (c >> 3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i);          // kb even
+    const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i + 8);      // kb odd
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const uint32_t d = (kb & 1) ? d1 : d0;
+      const int keep = __builtin_amdgcn_sbfe((int)d, bitpos - 4 * (kb >> 1), 1);     // 0 or -1
+      const float val = v[kb][i] * ge4[i];
+      v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
+    }
+  }
+}
+
+// Sums of the dL/dh1 rows of every run of equal keys (sources in S, targets in T) inside a 32-edge tile, written as
+// 256-byte "part" rows; the tile is processed as two 16-edge halves and a run that crosses the middle is carried
+// in ONE register per lane.  m16: bit e set = edge e of this half is the last of its run.  Layout of every summed
+// row: lane (c, g) holds column colp = 16 kRow4[g] + c (what red4 leaves in row g).
+__device__ __forceinline__ void run_sums(const f32x4 (&v)[4], unsigned m16, float& carry, float* part, int64_t& pidx,
+                                         char* wv, int lane, int c, int g, int colp) {
+  const unsigned inner = m16 & 0x7fffu;
+  if (inner == 0u) {
+    // no boundary before the last edge: one run (open or closing at edge 15)
+    float x[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) x[kb] = (v[kb][0] + v[kb][1]) + (v[kb][2] + v[kb][3]);
+    const float s = carry + red4(x[0], x[1], x[2], x[3]);
+    if (m16 & 0x8000u) {
+      part[pidx * D16 + colp] = s;
+      ++pidx;
+      carry = 0.f;
+    } else {
+      carry = s;
+    }
+  } else if ((inner & (inner - 1u)) == 0u) {
+    // one boundary inside: rows <= bnd close the first run, the rest is a second run (open or closing)
+    const int bnd = __builtin_ctz(inner);
+    float a[4], b[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      a[kb] = 0.f;
+      b[kb] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool first = 4 * g + i <= bnd;
+        a[kb] += first ? v[kb][i] : 0.f;
+        b[kb] += first ? 0.f : v[kb][i];
+      }
+    }
+    const float lo = carry + red4(a[0], a[1], a[2], a[3]);
+    const float hi = red4(b[0], b[1], b[2], b[3]);
+    part[pidx * D16 + colp] = lo;
+    ++pidx;
+    if (m16 & 0x8000u) {
+      part[pidx * D16 + colp] = hi;
+      ++pidx;
+      carry = 0.f;
+    } else {
+      carry = hi;
+    }
+  } else {
+    // three or more runs: the tile goes through LDS (the tile images are free at this point) as [16][64] floats,
+    // the carried sum as row 16; lane = column walks the rows
+    wave_sync();
+    float* tile = reinterpret_cast<float*>(wv);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tile[(4 * g + i) * 64 + 16 * kb + c] = v[kb][i];
+    tile[16 * 64 + colp] = carry;
+    wave_sync();
+    float sum = tile[16 * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      sum += tile[e * 64 + lane];
+      if ((m16 >> e) & 1u) {
+        part[pidx * D16 + lane] = sum;
+        sum = 0.f;
+        ++pidx;
+      }
+    }
+    wave_sync();
+    tile[lane] = sum;                  // the open remainder back into the carry layout
+    wave_sync();
+    carry = tile[colp];
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// S kernel
+// ------------------------------------------------------------------------------------------------------------------
+struct HalfIn { uint32_t poff, qoff; float aux, w_e; int key, key_nxt; };
+struct HalfRows { float4 p[4], q[4]; };
+
+// ids / label (or given gradient) / skip feature of the 16 edges of half `hx` of tile `tile`.  Addresses are a
+// wave-uniform tile base (scalar registers) plus a 32-bit lane offset; edges past the end of the list (the last
+// tile, and the prefetch of a tile the wave will not run) are clamped to the last edge.
+__device__ __forceinline__ HalfIn load_half(const D16Params& a, const float* aux, int64_t tile, int64_t n_tiles, int hx,
+                                            int c) {
+  HalfIn h;
+  const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
+  const int64_t e_tile = tc * 32;
+  const int64_t rest = a.E - 1 - e_tile;
+  const int lim = (int)(rest < 31 ? rest : 31);            // uniform: last valid position inside the tile
+  const int k = min(16 * hx + c, lim), kn = min(k + 1, lim);
+  const int64_t* ei = a.ei + e_tile;
+  const int64_t s = ei[k], d = ei[a.ld + k];
+  h.key = (int)s;
+  h.key_nxt = (int)ei[kn];
+  h.poff = (uint32_t)s * a.ldp_b;
+  h.qoff = (uint32_t)d * a.ldq_b;
+  h.aux = (aux + e_tile)[k];
+  h.w_e = a.extra ? (a.extra + e_tile)[k] : 0.f;
+  return h;
+}
+__device__ __forceinline__ void issue_half_rows(const D16Params& a, const HalfIn& in, int g, HalfRows& r) {
+  const uint32_t po = in.poff + 32u * g, qo = in.qoff + 32u * g;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {                          // x = 2 ks + half: k = 32 ks + 8 g + 4 half ..
+    r.p[x] = ld_row16(a.p, po + 128u * (x >> 1) + 16u * (x & 1));
+    r.q[x] = ld_row16(a.q, qo + 128u * (x >> 1) + 16u * (x & 1));
+  }
+}
+
+template <bool FUSED_LOSS, bool RUNSUM>
+__global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
+    D16Params a, const float* __restrict__ g_logits, D16Loss lp, float* __restrict__ logits, D16Run rs,
+    uint32_t* __restrict__ rec, float* __restrict__ slabs, int64_t n_tiles) {
+  __shared__ __attribute__((aligned(16))) char lds[S_LDS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  char* wv = lds + LDS_WAVE0 + wave * WV_BYTES;
+  stage_weights16(a.w2, a.b2, a.w3, a.cvec, lds, S_WAVES * 64, 3, LDS_W2P, LDS_VEC);
+  __syncthreads();
+  const float* b2l = reinterpret_cast<const float*>(lds + LDS_VEC);
+  const float* w3l = b2l + 64;
+  const float* cvl = w3l + 64;
+
+  // lane-constant LDS offsets
+  const int wfrag0 = c * 128 + ((g ^ wsw(c)) << 4);                    // weight images: row 16 x + c, chunk g (K-step 0)
+  const int wfrag1 = wfrag0 ^ 64;                                      //                               chunk 4 + g
+  const int hgw0 = c * 128 + ((g ^ tsw(c)) << 4);                      // tile images: row c, chunk g / 4 + g (16-B writes)
+  const int hgw1 = hgw0 ^ 64;
+  const int m2w = c * 128 + ((((g >> 1)) ^ tsw(c)) << 4) + 8 * (g & 1); // m2 image: row c, 8 B at column 4 g (+ 16 jb: ^ (jb << 5))
+  const int colp = 16 * (((g & 1) << 1) | (g >> 1)) + c;               // column a lane holds after red4: block {0, 2, 1, 3}[g]
+  // transposing reads of the 32x32x16 operands (P3): 16-lane group q4, block rows 8 (q4 >> 1) + (li >> 2) (+4),
+  // columns 32 blk + 16 (q4 & 1) + 4 (li & 3)
+  int tr3[2][2];
+  {
+    const int li = lane & 15, q4 = lane >> 4, p = li & 3;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = 8 * (q4 >> 1) + (li >> 2) + 4 * half;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const int ch = 4 * blk + 2 * (q4 & 1) + (p >> 1);
+        tr3[blk][half] = row * 128 + ((ch ^ tsw(row)) << 4) + 8 * (p & 1);
+      }
+    }
+  }
+
+  f32x16 acc3[2][2];                       // sum_e m2[j][e] g_e h1[e][k]:  j = 32 mb + jr(i, h), k = 32 nb + (lane & 31)
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc3[x][0][i] = 0.f; acc3[x][1][i] = 0.f; }
+  f32x4 gw3a[4];                           // per (j = 16 jb + 4 g + i, edge slot c) partial sums of g_e h2 over tiles
+#pragma unroll                             // (dL/db2 = w3[j] sum_e g_e m2[j][e] is left to the dgrad pass: it needs only the records)
+  for (int jb = 0; jb < 4; ++jb) gw3a[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gcv[4] = {0.f, 0.f, 0.f, 0.f};     // lane (c, g): partial of gcvec[16 kb + c] over its edges
+  float gb3p = 0.f, lossp = 0.f;
+  const float b3v = a.b3[0];
+  const float pw = (FUSED_LOSS && lp.pos_weight) ? lp.pos_weight[0] : 1.f;
+  const bool has_extra = a.extra != nullptr;
+  const float* auxp = FUSED_LOSS ? lp.y : g_logits;
+
+  const int64_t stride = (int64_t)gridDim.x * S_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * S_WAVES + wave;
+  HalfIn in_cur = load_half(a, auxp, tile, n_tiles, 0, c);
+  HalfRows rows;
+  issue_half_rows(a, in_cur, g, rows);
+  int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile] : 0;
+
+  for (; tile < n_tiles; tile += stride) {
+    float carry = 0.f;
+    int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
+    const int poff_nxt = (RUNSUM && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
+    const int live_lim = (int)min((int64_t)31, a.E - 1 - tile * 32);   // uniform: positions <= live_lim are real edges
+    uint32_t* rec_tile = rec ? rec + tile * 256 : nullptr;             // 8 dwords per edge
+    float* logit_tile = logits ? logits + tile * 32 : nullptr;
+#pragma unroll 1
+    for (int hx = 0; hx < 2; ++hx) {
+      // ids of the next half tile (this tile's second half, or the first half of the wave's next tile)
+      const HalfIn in_nxt = hx == 0 ? load_half(a, auxp, tile, n_tiles, 1, c) : load_half(a, auxp, tile + stride, n_tiles, 0, c);
+      const int pos = 16 * hx + c;
+      const bool live = pos <= live_lim;
+
+      // h1 fragments (B operand of P1): lane (c, g) holds h1[c][32 ks + 8 g + 0..7]
+      float h[2][8];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const float4 pv = rows.p[2 * ks + hf], qv = rows.q[2 * ks + hf];
+          h[ks][4 * hf + 0] = pv.x + qv.x;
+          h[ks][4 * hf + 1] = pv.y + qv.y;
+          h[ks][4 * hf + 2] = pv.z + qv.z;
+          h[ks][4 * hf + 3] = pv.w + qv.w;
+        }
+      if (has_extra) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int s = 0; s < 8; ++s) h[ks][s] = fmaf(in_cur.w_e, cvl[32 * ks + 8 * g + s], h[ks][s]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) h[ks][s] = relu1(h[ks][s]);
+
+      // ---- P1: C[j][e] = b2[j] + sum_k W2[j][k] h1[e][k]
+      f32x4 acc[4];
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) acc[jb] = *reinterpret_cast<const f32x4*>(b2l + 16 * jb + 4 * g);
+      uint32_t m1 = 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const Split3 hb = split8(h[ks]);
+        // m1 bits: element s = 2 qd + half of this K-step lands at bit 16 half + 7 - (4 ks + qd)   (h >= 0: bits != 0 <=> h > 0)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const uint32_t b0 = __builtin_bit_cast(uint32_t, h[ks][2 * qd]), b1 = __builtin_bit_cast(uint32_t, h[ks][2 * qd + 1]);
+          m1 = (m1 << 1) | min(b0, 1u) | (min(b1, 1u) << 16);
+        }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          const int off = LDS_W2 + (ks ? wfrag1 : wfrag0) + jb * 2048;
+          const bf16x8 w_hi = ld_b128(lds, off);
+          const bf16x8 w_mid = ld_b128(lds, off + W_IMG);
+          const bf16x8 w_lo = ld_b128(lds, off + 2 * W_IMG);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, hb.hi, acc[jb], 0, 0, 0);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb.mid, acc[jb], 0, 0, 0);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb.lo, acc[jb], 0, 0, 0);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb.hi, acc[jb], 0, 0, 0);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb.mid, acc[jb], 0, 0, 0);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb.hi, acc[jb], 0, 0, 0);
+        }
+      }
+      // the rows of the next half tile fly during the epilogue and the other two products
+      issue_half_rows(a, in_nxt, g, rows);
+
+      // ---- logits, loss, g_e
+      float part = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w3l + 16 * jb + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[jb][i] = relu1(acc[jb][i]);
+          part = fmaf(acc[jb][i], ww[i], part);
+        }
+      }
+      part = xsum32(xsum16(part));
+      const float xv = part + b3v;
+      float g_e;
+      if (FUSED_LOSS) {
+        const float y_e = in_cur.aux;
+        const float scale = live ? lp.inv_denom : 0.f;
+        const float lw = 1.f + (pw - 1.f) * y_e;
+        const float t = expf(-fabsf(xv));             // in (0, 1]
+        const float u = 1.f + t;
+        float ru = __builtin_amdgcn_rcpf(u);
+        ru = ru * (2.f - u * ru);                     // 1 / (1 + t): one Newton step on the hardware reciprocal
+        const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
+        g_e = ((1.f - y_e) - lw * sig_neg) * scale;
+        const float um1 = u - 1.f;                    // log1p(t) = log(u) t / (u - 1), = t when u == 1
+        float rm = __builtin_amdgcn_rcpf(um1);
+        rm = rm * (2.f - um1 * rm);
+        const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
+        lossp = fmaf((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f)), scale, lossp);
+      } else {
+        g_e = live ? in_cur.aux : 0.f;
+      }
+      gb3p += g_e;
+      if (logit_tile != nullptr && g == 0 && live) logit_tile[pos] = xv;
+
+      // ---- m2 = [h2 > 0] as bf16 0/1 (A operand of P2 and, transposed through LDS, of P3); gw3 partials
+      bf16x8 a2[2];
+      uint32_t m2 = 0;
+      {
+        u32x4 aw[2];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const float h2a = acc[jb][2 * pr], h2b = acc[jb][2 * pr + 1];
+            gw3a[jb][2 * pr] = fmaf(g_e, h2a, gw3a[jb][2 * pr]);
+            gw3a[jb][2 * pr + 1] = fmaf(g_e, h2b, gw3a[jb][2 * pr + 1]);
+            const uint32_t ta = min(__builtin_bit_cast(uint32_t, h2a), 1u), tb = min(__builtin_bit_cast(uint32_t, h2b), 1u);
+            const uint32_t t2 = ta | (tb << 16);                      // the pair as two 0/1 halves
+            m2 = (m2 << 1) | t2;
+            aw[jb >> 1][2 * (jb & 1) + pr] = t2 * 0x3f80u;             // bf16 1.0 / 0.0
+          }
+        a2[0] = __builtin_bit_cast(bf16x8, aw[0]);
+        a2[1] = __builtin_bit_cast(bf16x8, aw[1]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        struct P { short4v lo, hi; };
+        const P pk = __builtin_bit_cast(P, a2[t]);
+        *reinterpret_cast<short4v*>(wv + WV_M2 + (m2w ^ ((2 * t) << 5))) = pk.lo;        // columns 16 (2t) + 4 g ..
+        *reinterpret_cast<short4v*>(wv + WV_M2 + (m2w ^ ((2 * t + 1) << 5))) = pk.hi;    // columns 16 (2t+1) + 4 g ..
+      }
+      const uint32_t recw = (m1 & 0x00ff00ffu) | ((m2 & 0x00ff00ffu) << 8);
+      *reinterpret_cast<uint32_t*>(wv + WV_REC + 16 * c + 4 * g) = recw;
+      *reinterpret_cast<float*>(wv + WV_GL + 4 * c) = g_e;               // the four lane groups write the same value
+      if (has_extra) *reinterpret_cast<float*>(wv + WV_WL + 4 * c) = in_cur.w_e;
+      if (rec_tile != nullptr && live) {
+        uint32_t* r = rec_tile + pos * 8;
+        r[g] = recw;
+        if (g == 0) r[4] = __builtin_bit_cast(uint32_t, g_e);
+      }
+
+      // ---- Hg = g_e h1 split three ways -> tile images (B operand of P3)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float hg[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) hg[s] = g_e * h[ks][s];
+        const Split3 sb = split8(hg);
+        const int off = WV_HG + (ks ? hgw1 : hgw0);
+        *reinterpret_cast<bf16x8*>(wv + off) = sb.hi;
+        *reinterpret_cast<bf16x8*>(wv + off + T_IMG) = sb.mid;
+        *reinterpret_cast<bf16x8*>(wv + off + 2 * T_IMG) = sb.lo;
+      }
+      wave_sync();
+
+      // ---- P3: acc3[mb][nb] += m2^T (Hg_lo + Hg_mid + Hg_hi), K = the 16 edges
+      {
+        bf16x8 am[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) am[mb] = ld_tr8(wv + WV_M2, tr3[mb][0], tr3[mb][1]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int term = 2; term >= 0; --term) {
+            const bf16x8 bh = ld_tr8(wv + WV_HG + term * T_IMG, tr3[nb][0], tr3[nb][1]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+              acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mb], bh, acc3[mb][nb], 0, 0, 0);
+          }
+      }
+
+      // ---- P2 + run sums by source
+      if (RUNSUM || has_extra) {
+        f32x4 v[4];
+        dgrad_tile(lds, wv + WV_REC, wv + WV_GL, a2, c, g, LDS_W2P + wfrag0, LDS_W2P + wfrag1, v);
+#ifdef PANGNN_D16_DEBUG
+        if (d16_dbg_v != nullptr) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (tile * 32 + 16 * hx + 4 * g + i < a.E) d16_dbg_v[(tile * 32 + 16 * hx + 4 * g + i) * 64 + 16 * kb + c] = v[kb][i];
+        }
+#endif
+        if (has_extra) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + WV_WL + 16 * g);
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], v[kb][i], gcv[kb]);
+        }
+        if (RUNSUM) {
+          const bool closes = in_cur.key != in_cur.key_nxt || pos == 31;
+          const unsigned long long bal = __ballot(closes);
+          const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
+          run_sums(v, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
+        }
+      }
+      wave_sync();          // the next half tile overwrites the images / recl / gl
+      in_cur = in_nxt;
+    }
+    poff_cur = poff_nxt;
+  }
+
+  // ---- finish: per-lane partials -> per-wave rows -> workgroup slab (fixed order)
+  // gw3[j] = sum over the 16 edge slots c
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) gw3a[jb][i] += __shfl_xor(gw3a[jb][i], off);
+    }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) gcv[kb] = xsum32(xsum16(gcv[kb]));
+  if (g != 0) { gb3p = 0.f; lossp = 0.f; }                   // the four lane groups carried the same per-edge values
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    gb3p += __shfl_xor(gb3p, off);
+    lossp += __shfl_xor(lossp, off);
+  }
+  const int hh = lane >> 5, r = lane & 31;
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds + LDS_WAVE0);   // reuse the tile area: SLAB16 floats
+  for (int w = 0; w < S_WAVES; ++w) {
+    if (wave == w) {
+      const bool first = (w == 0);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int j = 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int idx = j * 64 + r + 32 * nb;
+            red[idx] = (first ? 0.f : red[idx]) + w3l[j] * acc3[mb][nb][i];
+          }
+      if (c == 0) {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int j = 16 * jb + 4 * g + i;
+            red[4096 + j] = 0.f;                                  // dL/db2: dgrad pass
+            red[4096 + 64 + j] = (first ? 0.f : red[4096 + 64 + j]) + gw3a[jb][i];
+          }
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          red[4096 + 128 + 16 * kb + c] = (first ? 0.f : red[4096 + 128 + 16 * kb + c]) + gcv[kb];
+      }
+      if (lane == 0) {
+        red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
+        red[4096 + 193] = (first ? 0.f : red[4096 + 193]) + lossp;
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * SLAB16;
+  for (int i = threadIdx.x; i < 4096 + 194; i += S_WAVES * 64) slab[i] = red[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// T kernel: dL/dh1 summed over runs of equal keys in a permuted edge order, from the records of S.
+//   perm[k] = edge id at sorted position k (NULL = identity); keys[k] = run key of position k (CSR row id).
+// ------------------------------------------------------------------------------------------------------------------
+struct TIn { uint32_t recw; float g_e, w_e; int key, key_nxt; };
+__device__ __forceinline__ TIn load_t(const uint32_t* rec, const int32_t* perm, const int32_t* keys, const float* extra,
+                                      int64_t E, int64_t tile, int64_t n_tiles, int hx, int c, int g) {
+  TIn t;
+  const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
+  const int64_t p_tile = tc * 32;
+  const int64_t rest = E - 1 - p_tile;
+  const int lim = (int)(rest < 31 ? rest : 31);
+  const int k = min(16 * hx + c, lim), kn = min(k + 1, lim);
+  const int32_t* kt = keys + p_tile;
+  t.key = kt[k];
+  t.key_nxt = kt[kn];
+  const uint32_t e = perm ? (uint32_t)(perm + p_tile)[k] : (uint32_t)(p_tile + k);
+  const uint32_t* r = rec + (uint64_t)e * 8;
+  t.recw = r[g];
+  t.g_e = __builtin_bit_cast(float, r[4]);
+  t.w_e = extra ? extra[e] : 0.f;
+  return t;
+}
+
+__global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
+    const uint32_t* __restrict__ rec, const int32_t* __restrict__ perm, const int32_t* __restrict__ keys,
+    const float* __restrict__ extra, const float* __restrict__ w2, const float* __restrict__ w3, int64_t E,
+    D16Run rs, float* __restrict__ gcv_slabs, float* __restrict__ gb2_slabs, int64_t n_tiles) {
+  // LDS: W2'^T hi | mid | lo, (b2 w3 cvec: unused here), per wave: run-sum tile [17][64] floats | recl | gl | wl
+  constexpr int TW_REC = 17 * 64 * 4, TW_GL = TW_REC + 256, TW_WL = TW_GL + 64, TW_BYTES = TW_WL + 64;
+  constexpr int T_VEC = 3 * W_IMG, T_WAVE0 = T_VEC + 3 * 64 * 4;
+  constexpr int T_LDS = T_WAVE0 + T_WAVES * TW_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[T_LDS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  char* wv = lds + T_WAVE0 + wave * TW_BYTES;
+  stage_weights16(w2, nullptr, w3, nullptr, lds, T_WAVES * 64, 2, 0, T_VEC);
+  __syncthreads();
+  const int wfrag0 = c * 128 + ((g ^ wsw(c)) << 4), wfrag1 = wfrag0 ^ 64;
+  const int colp = 16 * (((g & 1) << 1) | (g >> 1)) + c;
+  const bool has_extra = extra != nullptr;
+  const bool run = rs.part != nullptr;
+  float gcv[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gb2a[4];                           // per (j = 16 jb + 4 g + i, edge slot c): sum of g_e m2[j][e] over tiles
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) gb2a[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t stride = (int64_t)gridDim.x * T_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * T_WAVES + wave;
+  TIn cur = load_t(rec, perm, keys, extra, E, tile, n_tiles, 0, c, g);
+  int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile] : 0;
+  for (; tile < n_tiles; tile += stride) {
+    float carry = 0.f;
+    int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
+    const int poff_nxt = (run && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
+    const int live_lim = (int)min((int64_t)31, E - 1 - tile * 32);
+#pragma unroll 1
+    for (int hx = 0; hx < 2; ++hx) {
+      const TIn nxt = hx == 0 ? load_t(rec, perm, keys, extra, E, tile, n_tiles, 1, c, g)
+                              : load_t(rec, perm, keys, extra, E, tile + stride, n_tiles, 0, c, g);
+      const int pos = 16 * hx + c;
+      const float g_e = pos <= live_lim ? cur.g_e : 0.f;
+      *reinterpret_cast<uint32_t*>(wv + TW_REC + 16 * c + 4 * g) = cur.recw;
+      *reinterpret_cast<float*>(wv + TW_GL + 4 * c) = g_e;
+      if (has_extra) *reinterpret_cast<float*>(wv + TW_WL + 4 * c) = cur.w_e;
+      // m2 bits of lane (c, g): dword qd of K-step t holds elements (2 qd, 2 qd + 1) at bits 15 - n and 31 - n, n = 4 t + qd
+      bf16x8 a2[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        u32x4 w;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) w[qd] = ((cur.recw >> (15 - (4 * t + qd))) & 0x00010001u) * 0x3f80u;
+        a2[t] = __builtin_bit_cast(bf16x8, w);
+        if (gb2_slabs != nullptr) {
+          // the halves of w are bf16 1.0 / 0.0: as fp32 bit patterns they are the mask value itself
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int jb = 2 * t + (qd >> 1), i0 = 2 * (qd & 1);
+            gb2a[jb][i0] = fmaf(__builtin_bit_cast(float, w[qd] << 16), g_e, gb2a[jb][i0]);
+            gb2a[jb][i0 + 1] = fmaf(__builtin_bit_cast(float, w[qd] & 0xffff0000u), g_e, gb2a[jb][i0 + 1]);
+          }
+        }
+      }
+      wave_sync();
+      if (!run) {                                       // parameter sums only
+        wave_sync();
+        cur = nxt;
+        continue;
+      }
+      f32x4 v[4];
+      dgrad_tile(lds, wv + TW_REC, wv + TW_GL, a2, c, g, wfrag0, wfrag1, v);
+      if (has_extra && gcv_slabs != nullptr) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + TW_WL + 16 * g);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], v[kb][i], gcv[kb]);
+      }
+      const bool closes = cur.key != cur.key_nxt || pos == 31;
+      const unsigned long long bal = __ballot(closes);
+      const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
+      run_sums(v, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
+      wave_sync();
+      cur = nxt;
+    }
+    poff_cur = poff_nxt;
+  }
+  if (gcv_slabs != nullptr || gb2_slabs != nullptr) {
+    // parameter-gradient partials of the workgroup in fixed wave order: [gcvec 64 | gb2 64]
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) gcv[kb] = xsum32(xsum16(gcv[kb]));
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) gb2a[jb][i] += __shfl_xor(gb2a[jb][i], off);
+      }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds + T_WAVE0);
+    const float* w3v = reinterpret_cast<const float*>(lds + T_VEC) + 64;
+    for (int w = 0; w < T_WAVES; ++w) {
+      if (wave == w) {
+        if (g == 0) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) red[16 * kb + c] = (w == 0 ? 0.f : red[16 * kb + c]) + gcv[kb];
+        }
+        if (c == 0) {
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int j = 16 * jb + 4 * g + i;
+              red[64 + j] = (w == 0 ? 0.f : red[64 + j]) + w3v[j] * gb2a[jb][i];
+            }
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < 64 && gcv_slabs != nullptr) gcv_slabs[(int64_t)blockIdx.x * 64 + threadIdx.x] = red[threadIdx.x];
+    if (threadIdx.x < 64 && gb2_slabs != nullptr) gb2_slabs[(int64_t)blockIdx.x * 64 + threadIdx.x] = red[64 + threadIdx.x];
+  }
+}
+
+}  // namespace pangnn
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+namespace pangnn {
+// decoder.hip: sums the per-workgroup slabs (layout SLAB16) in index order
+int launch_decoder_reduce(const float* slabs, int n_slabs, float* g_w2, float* g_b2, float* g_w3, float* g_cvec,
+                          float* g_b3, float* loss, hipStream_t s);
+
+__global__ __launch_bounds__(kSumThreads) void gcv_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                             float* __restrict__ g_cvec) {
+  const int i = threadIdx.x & (kWave - 1);
+  const float s = ordered_parts_sum(slabs, n_slabs, 64, i, 64);
+  if (threadIdx.x < kWave) g_cvec[i] = s;
+}
+
+static int cu_count() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return cus;
+}
+}  // namespace pangnn
+
+using namespace pangnn;
+
+#ifdef PANGNN_D16_DEBUG
+extern "C" int pangnn_debug_set_v(float* ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(d16_dbg_v), &ptr, sizeof(ptr));
+}
+#endif
+
+extern "C" size_t pangnn_decoder_train_workspace_bytes(void) { return (size_t)cu_count() * SLAB16 * sizeof(float); }
+
+extern "C" int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
+                                        const int64_t* edge_index, int64_t ld, int64_t num_edges, const float* extra,
+                                        const float* cvec, const float* w2, const float* b2, const float* w3,
+                                        const float* b3, int32_t D, const float* y, const float* pos_weight,
+                                        int64_t denom, const float* g_logits, float* logits, float* loss,
+                                        uint32_t* rec, float* part_buf, const int32_t* part_off, float* g_w2,
+                                        float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                        size_t workspace_bytes, pangnn_stream_t stream) {
+  const char* who = "pangnn_decoder_train_f32";
+  PG_CHECK_ARG(D == D16, PANGNN_E_BADARG, "%s: built for node_dim 64, got %d", who, (int)D);
+  PG_CHECK_ARG(num_edges >= 0 && ld >= num_edges && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
+  PG_CHECK_ARG(ldp >= D16 && ldq >= D16 && ldp % 4 == 0 && ldq % 4 == 0, PANGNN_E_BADARG,
+               "%s: ldp / ldq must be multiples of 4 and >= 64", who);
+  PG_CHECK_ARG((double)num_nodes * (double)(ldp > ldq ? ldp : ldq) * 4.0 < 4294967296.0, PANGNN_E_TOOLARGE,
+               "%s: node tables must stay under 4 GiB (32-bit gather offsets)", who);
+  PG_CHECK_ARG(g_w2 && g_w3 && g_b3, PANGNN_E_BADARG, "%s: null gradient output", who);
+  PG_CHECK_ARG((y != nullptr) != (g_logits != nullptr) || num_edges == 0, PANGNN_E_BADARG,
+               "%s: exactly one of y (fused loss) and g_logits (given gradient) must be set", who);
+  PG_CHECK_ARG(!y || (denom > 0 && loss && logits), PANGNN_E_BADARG, "%s: fused loss needs denom > 0, loss, logits", who);
+  PG_CHECK_ARG((part_buf == nullptr) == (part_off == nullptr), PANGNN_E_BADARG, "%s: part_buf and part_off go together",
+               who);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = (num_edges + 31) / 32;
+  int64_t grid = (n_tiles + S_WAVES - 1) / S_WAVES;
+  const int cus = cu_count();
+  if (grid > cus) grid = cus;
+  if (grid < 1) grid = 1;
+  PG_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * SLAB16 * sizeof(float), PANGNN_E_WORKSPACE,
+               "%s: workspace too small", who);
+  float* ws = static_cast<float*>(workspace);
+  if (num_edges == 0) {
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)grid * SLAB16 * sizeof(float), s);
+    PG_CHECK_ARG(e == hipSuccess, (int)e, "%s: memset failed", who);
+  } else {
+    PG_CHECK_ARG(p && q && edge_index && w2 && b2 && w3 && b3 && (!extra || cvec), PANGNN_E_BADARG, "%s: null pointer",
+                 who);
+    PG_CHECK_ARG(aligned16(p) && aligned16(q) && aligned16(w2), PANGNN_E_ALIGN, "%s: p / q / w2 must be 16-byte aligned",
+                 who);
+    PG_CHECK_ARG(!rec || aligned16(rec), PANGNN_E_ALIGN, "%s: rec must be 16-byte aligned", who);
+    D16Params a{p, q, (uint32_t)(ldp * 4), (uint32_t)(ldq * 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+    const D16Loss lp{y, pos_weight, y ? 1.0f / (float)denom : 0.f};
+    const D16Run rs{part_buf, part_off};
+    const dim3 gd((unsigned)grid), bd(S_WAVES * 64);
+    if (y && part_buf)
+      hipLaunchKernelGGL((decoder_train16_kernel<true, true>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
+    else if (y)
+      hipLaunchKernelGGL((decoder_train16_kernel<true, false>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
+    else if (part_buf)
+      hipLaunchKernelGGL((decoder_train16_kernel<false, true>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
+    else
+      hipLaunchKernelGGL((decoder_train16_kernel<false, false>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
+    PG_CHECK_LAUNCH(who);
+  }
+  return launch_decoder_reduce(ws, (int)grid, g_w2, nullptr, g_w3, g_cvec, g_b3, loss, s);
+}
+
+extern "C" size_t pangnn_decoder_dgrad_workspace_bytes(void) { return (size_t)cu_count() * 128 * sizeof(float); }
+
+extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys,
+                                        const float* extra, const float* w2, const float* w3, int64_t num_edges,
+                                        float* part_buf, const int32_t* part_off, float* g_cvec, float* g_b2,
+                                        void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
+  const char* who = "pangnn_decoder_dgrad_f32";
+  PG_CHECK_ARG(num_edges >= 0, PANGNN_E_BADARG, "%s: bad size", who);
+  hipStream_t s = (hipStream_t)stream;
+  if (num_edges == 0) {
+    for (float* z : {g_cvec, g_b2})
+      if (z) {
+        hipError_t e = hipMemsetAsync(z, 0, 64 * sizeof(float), s);
+        PG_CHECK_ARG(e == hipSuccess, (int)e, "%s: memset failed", who);
+      }
+    return 0;
+  }
+  PG_CHECK_ARG(rec && w2 && w3 && (part_buf == nullptr) == (part_off == nullptr) && (!part_buf || keys),
+               PANGNN_E_BADARG, "%s: null pointer", who);
+  PG_CHECK_ARG(part_buf || g_b2 || g_cvec, PANGNN_E_BADARG, "%s: nothing to compute", who);
+  PG_CHECK_ARG(!g_cvec || (extra && part_buf), PANGNN_E_BADARG, "%s: g_cvec needs extra and the run-sum pass", who);
+  const int64_t n_tiles = (num_edges + 31) / 32;
+  int64_t grid = (n_tiles + T_WAVES - 1) / T_WAVES;
+  const int cus = cu_count();
+  if (grid > cus) grid = cus;
+  PG_CHECK_ARG(!(g_cvec || g_b2) || (workspace && workspace_bytes >= (size_t)grid * 128 * sizeof(float)),
+               PANGNN_E_WORKSPACE, "%s: workspace too small", who);
+  const D16Run rs{part_buf, part_off};
+  float* cv_slabs = g_cvec ? static_cast<float*>(workspace) : nullptr;
+  float* b2_slabs = g_b2 ? static_cast<float*>(workspace) + (size_t)grid * 64 : nullptr;
+  hipLaunchKernelGGL(decoder_dgrad16_kernel, dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, keys, extra, w2,
+                     w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles);
+  PG_CHECK_LAUNCH(who);
+  for (int x = 0; x < 2; ++x) {
+    float* out = x ? g_b2 : g_cvec;
+    if (out) {
+      hipLaunchKernelGGL(gcv_reduce_kernel, dim3(1), dim3(kSumThreads), 0, s, x ? b2_slabs : cv_slabs, (int)grid, out);
+      PG_CHECK_LAUNCH(who);
+    }
+  }
+  return 0;
+}

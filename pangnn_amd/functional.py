@@ -272,6 +272,85 @@ def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor) -> 
     return out
 
 
+def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 0, out=None, g_b2=None):
+    """dL/dh1 summed over the rows of CSR order `by` ("src" / "dst") from the per-edge records of the training
+    kernel: pangnn_decoder_dgrad_f32 (run parts) + the short contiguous part sum.  `g_b2`: also filled with dL/db2
+    (one call per step asks for it); by = None: the parameter sums alone."""
+    lib = _lib.load()
+    dev = rec.device
+    plan = st.csr_plan(by) if by else None
+    csr = None if not by else (st.by_dst if by == "dst" else st.by_src)
+    parts = None if plan is None else torch.empty(plan.n_parts, 64, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws_bytes = lib.pangnn_decoder_dgrad_workspace_bytes() if g_b2 is not None else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        ev = _timer_start("dec.dgrad")
+        _lib.check(lib.pangnn_decoder_dgrad_f32(rec.data_ptr(), None if csr is None else _lib.ptr(csr.perm),
+                                                None if plan is None else plan.keys.data_ptr(), None,
+                                                w2.data_ptr(), w3.data_ptr(), st.num_edges, _lib.ptr(parts),
+                                                None if plan is None else plan.part_off.data_ptr(), None,
+                                                _lib.ptr(g_b2), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                   "pangnn_decoder_dgrad_f32")
+        _timer_stop("dec.dgrad", ev)
+    if plan is None:
+        return None
+    return _sum_parts(plan, parts, n_rows, out if out is not None else torch.empty(n_rows, 64, device=dev))
+
+
+def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw=None, denom=0, g_logits=None,
+                     out_p=None, out_q=None, need_p=True, need_q=True):
+    """Two-wave-per-SIMD training decoder (csrc/decoder16.hip).  One pass over the edges in the caller's order (S):
+    logits, loss (y given) or the given dL/dlogits, every parameter gradient, per-source run sums when the list is
+    source-sorted, and a 32-byte record per edge; then dL/dQ (and dL/dP for unsorted lists) from the records in CSR
+    order (T).  No [E, 64] tensor exists.  Returns (loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3)."""
+    lib = _lib.load()
+    dev = p.device
+    e, d = st.num_edges, p.shape[1]
+    fused = y is not None
+    logits = torch.empty(e, dtype=torch.float32, device=dev) if fused else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev) if fused else None
+    g_w2 = torch.empty_like(w2)
+    g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
+    g_cv = None if cv is None else torch.empty_like(cv)
+    rec = torch.empty(max(e, 1), 8, dtype=torch.int32, device=dev)
+    plan = st.runsum_plan() if (need_p and e > 0) else None
+    parts = None if plan is None else torch.empty(plan.n_parts, d, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws_bytes = lib.pangnn_decoder_train_workspace_bytes()
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ev = _timer_start("dec.bwd")
+        _lib.check(lib.pangnn_decoder_train_f32(
+            p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), max(p.shape[0], q.shape[0]),
+            st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+            b3.data_ptr(), d, _lib.ptr(y), _lib.ptr(pw), int(denom), _lib.ptr(g_logits), _lib.ptr(logits),
+            _lib.ptr(loss), rec.data_ptr(), _lib.ptr(parts), None if plan is None else plan.part_off.data_ptr(),
+            g_w2.data_ptr(), g_w3.data_ptr(), g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(),
+            ws_bytes, _lib.stream_ptr()), "pangnn_decoder_train_f32")
+        _timer_stop("dec.bwd", ev)
+    gp = gq = None
+    b2_out = g_b2          # dL/db2 comes out of exactly one dgrad call
+    if need_p:
+        if e == 0:
+            gp = (out_p if out_p is not None else torch.empty(p.shape[0], d, device=dev)).zero_()
+        elif plan is not None:
+            gp = _sum_parts(plan, parts, p.shape[0], out_p if out_p is not None else torch.empty(p.shape[0], d, device=dev))
+        else:
+            gp = _dgrad_sum(rec, st, "src", w2, w3, p.shape[0], out_p, g_b2=b2_out)
+            b2_out = None
+    if need_q:
+        if e == 0:
+            gq = (out_q if out_q is not None else torch.empty(q.shape[0], d, device=dev)).zero_()
+        else:
+            gq = _dgrad_sum(rec, st, "dst", w2, w3, q.shape[0], out_q, g_b2=b2_out)
+            b2_out = None
+    if b2_out is not None:
+        if e == 0:
+            g_b2.zero_()
+        else:
+            _dgrad_sum(rec, st, None, w2, w3, g_b2=b2_out)
+    return loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
+
+
 def _rows_f32(t: torch.Tensor) -> torch.Tensor:
     """fp32 with unit column stride and a 16-byte friendly row stride; column windows of a wider
     row-major matrix pass through without a copy"""
@@ -326,6 +405,16 @@ class _DecoderMLP(torch.autograd.Function):
         g = _f32c(g)
         e, d = st.num_edges, p.shape[1]
         dev = p.device
+        if DECODER_PRECISION == 1:
+            if ctx.joint:
+                g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
+                _, _, _, _, g_cv, g_w2, g_b2, g_w3, g_b3 = _decoder_train16(
+                    p, q, st, ex, cv, w2, b2, w3, b3, g_logits=g, out_p=g_pq[:, :d], out_q=g_pq[:, d:])
+                return g_pq, None, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None
+            _, _, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = _decoder_train16(
+                p, q, st, ex, cv, w2, b2, w3, b3, g_logits=g, need_p=ctx.needs_input_grad[0],
+                need_q=ctx.needs_input_grad[1])
+            return gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None
         g_h1 = torch.empty(e, d, dtype=torch.float32, device=dev)
         g_w2 = torch.empty_like(w2)
         g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
@@ -413,6 +502,20 @@ class _DecoderLoss(torch.autograd.Function):
         pw = None if pos_weight is None else _f32c(pos_weight).reshape(-1)
         e, d = st.num_edges, p.shape[1]
         dev = p.device
+        if DECODER_PRECISION == 1:
+            if pq_joint:
+                g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
+                loss, logits, _, _, g_cv, g_w2, g_b2, g_w3, g_b3 = _decoder_train16(
+                    p, q, st, ex, cv, w2, b2, w3, b3, y=y, pw=pw, denom=denom, out_p=g_pq[:, :d], out_q=g_pq[:, d:])
+                gp, gq = g_pq, None
+            else:
+                loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = _decoder_train16(
+                    p, q, st, ex, cv, w2, b2, w3, b3, y=y, pw=pw, denom=denom)
+            ctx.has_cv, ctx.has_q = g_cv is not None, gq is not None
+            ctx.save_for_backward(gp, gq if gq is not None else gp.new_empty(0),
+                                  g_cv if g_cv is not None else gp.new_empty(0), g_w2, g_b2, g_w3, g_b3)
+            ctx.mark_non_differentiable(logits)
+            return loss.view(()), logits
         logits = torch.empty(e, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         g_h1 = torch.empty(e, d, dtype=torch.float32, device=dev)

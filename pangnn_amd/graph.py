@@ -90,6 +90,33 @@ class EdgeStructure:
             self._by_src = build_csr(self.edge_index, nmax, 0, validate=False, num_rows=self.num_src)
         return self._by_src
 
+    @staticmethod
+    def _plan_of_sorted_keys(keys: torch.Tensor, n_rows: int):
+        """Layout of the per-(32-edge tile, key) partial rows for an edge order whose `keys` are non-decreasing:
+          part_off[t]    index of tile t's first part
+          part_rowptr[r] parts of row r are [part_rowptr[r], part_rowptr[r+1])   (consecutive: sorted)
+          keys           int32 copy handed to the kernel"""
+        from types import SimpleNamespace
+        e = keys.shape[0]
+        flags = (torch.arange(e, device=keys.device) % 32) == 0
+        flags[1:] |= keys[1:] != keys[:-1]
+        part_id = torch.cumsum(flags, 0) - 1
+        n_parts = int(part_id[-1]) + 1
+        part_rowptr = torch.searchsorted(keys[flags].contiguous(), torch.arange(n_rows + 1, device=keys.device))
+        return SimpleNamespace(n_parts=n_parts, part_off=part_id[::32].to(torch.int32).contiguous(),
+                               part_rowptr=part_rowptr.contiguous(), keys=keys.to(torch.int32).contiguous())
+
+    def csr_plan(self, by: str):
+        """run-sum plan of the CSR order `by` in {"dst", "src"} (pangnn_decoder_dgrad_f32: perm = that CSR's perm)"""
+        cache = self.__dict__.setdefault("_csr_plans", {})
+        if by not in cache:
+            csr = self.by_dst if by == "dst" else self.by_src
+            n_rows = self.num_nodes if by == "dst" else self.num_src
+            keys = self.edge_index[1 if by == "dst" else 0][csr.perm.long()] if self.num_edges else \
+                self.edge_index.new_empty(0)
+            cache[by] = self._plan_of_sorted_keys(keys, n_rows) if self.num_edges else None
+        return cache[by]
+
     def runsum_plan(self):
         """If the caller's edge order is sorted by source: the layout of the per-(32-edge tile, source) partial
         rows the decoder backward kernel can emit (include/pangnn_hip.h, `part_buf` / `part_off`), else None.
@@ -100,15 +127,7 @@ class EdgeStructure:
             if e == 0 or not bool((src[1:] >= src[:-1]).all()):
                 self._runsum = False
             else:
-                flags = (torch.arange(e, device=src.device) % 32) == 0
-                flags[1:] |= src[1:] != src[:-1]
-                part_id = torch.cumsum(flags, 0) - 1
-                n_parts = int(part_id[-1]) + 1
-                part_rowptr = torch.searchsorted(src[flags].contiguous(),
-                                                 torch.arange(self.num_src + 1, device=src.device))
-                from types import SimpleNamespace
-                self._runsum = SimpleNamespace(n_parts=n_parts, part_off=part_id[::32].to(torch.int32).contiguous(),
-                                               part_rowptr=part_rowptr.contiguous())
+                self._runsum = self._plan_of_sorted_keys(src, self.num_src)
         return self._runsum or None
 
     def gcn_norm(self, edge_weight: Optional[torch.Tensor], gather_dis=None) -> "GcnNorm":
