@@ -204,18 +204,23 @@ __device__ __forceinline__ void dgrad_tile(const char* lds, const char* recl, co
                                            int c, int g, int w2p_off0, int w2p_off1, f32x4 (&v)[4]) {
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) v[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the three W2' terms of step (t, kb) are read one step ahead of their MFMAs (an LDS round trip is ~100 cycles,
+  // the three MFMAs of a step 48)
+  bf16x8 bq[2][3];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int x = 0; x < 3; ++x) bq[0][x] = ld_b128(lds, w2p_off0 + x * W_IMG);
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int off = (t ? w2p_off1 : w2p_off0) + kb * 2048;     // rows 16 kb + c
-      const bf16x8 b_hi = ld_b128(lds, off);
-      const bf16x8 b_mid = ld_b128(lds, off + W_IMG);
-      const bf16x8 b_lo = ld_b128(lds, off + 2 * W_IMG);
-      v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], b_lo, v[kb], 0, 0, 0);
-      v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], b_mid, v[kb], 0, 0, 0);
-      v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], b_hi, v[kb], 0, 0, 0);
+  for (int st = 0; st < 8; ++st) {
+    const int t = st >> 2, kb = st & 3;
+    if (st < 7) {
+      const int off = (((st + 1) >> 2) ? w2p_off1 : w2p_off0) + ((st + 1) & 3) * 2048;     // rows 16 kb + c
+#pragma unroll
+      for (int x = 0; x < 3; ++x) bq[(st + 1) & 1][x] = ld_b128(lds, off + x * W_IMG);
     }
+    v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], bq[st & 1][2], v[kb], 0, 0, 0);     // lo, mid, hi
+    v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], bq[st & 1][1], v[kb], 0, 0, 0);
+    v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], bq[st & 1][0], v[kb], 0, 0, 0);
+  }
   // epilogue: times g_e, masked by m1
   const f32x4 ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
   const int bitpos = 16 * (c & 1) + 7 - ((c & 7) >> 1);
@@ -446,28 +451,36 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb) acc[jb] = *reinterpret_cast<const f32x4*>(b2l + 16 * jb + 4 * g);
       uint32_t m1 = 0;
+      // W2 terms of step (ks, jb) are read one step ahead of their six MFMAs
+      bf16x8 aq[2][3];
+#pragma unroll
+      for (int x = 0; x < 3; ++x) aq[0][x] = ld_b128(lds, LDS_W2 + wfrag0 + x * W_IMG);
+      Split3 hb[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const Split3 hb = split8(h[ks]);
+        hb[ks] = split8(h[ks]);
         // m1 bits: element s = 2 qd + half of this K-step lands at bit 16 half + 7 - (4 ks + qd)   (h >= 0: bits != 0 <=> h > 0)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const uint32_t b0 = __builtin_bit_cast(uint32_t, h[ks][2 * qd]), b1 = __builtin_bit_cast(uint32_t, h[ks][2 * qd + 1]);
           m1 = (m1 << 1) | min(b0, 1u) | (min(b1, 1u) << 16);
         }
+      }
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-          const int off = LDS_W2 + (ks ? wfrag1 : wfrag0) + jb * 2048;
-          const bf16x8 w_hi = ld_b128(lds, off);
-          const bf16x8 w_mid = ld_b128(lds, off + W_IMG);
-          const bf16x8 w_lo = ld_b128(lds, off + 2 * W_IMG);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, hb.hi, acc[jb], 0, 0, 0);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb.mid, acc[jb], 0, 0, 0);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb.lo, acc[jb], 0, 0, 0);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb.hi, acc[jb], 0, 0, 0);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb.mid, acc[jb], 0, 0, 0);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb.hi, acc[jb], 0, 0, 0);
+      for (int st = 0; st < 8; ++st) {
+        const int ks = st >> 2, jb = st & 3;
+        if (st < 7) {
+          const int off = LDS_W2 + (((st + 1) >> 2) ? wfrag1 : wfrag0) + ((st + 1) & 3) * 2048;
+#pragma unroll
+          for (int x = 0; x < 3; ++x) aq[(st + 1) & 1][x] = ld_b128(lds, off + x * W_IMG);
         }
+        const bf16x8 w_hi = aq[st & 1][0], w_mid = aq[st & 1][1], w_lo = aq[st & 1][2];
+        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, hb[ks].hi, acc[jb], 0, 0, 0);
+        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb[ks].mid, acc[jb], 0, 0, 0);
+        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb[ks].lo, acc[jb], 0, 0, 0);
+        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb[ks].hi, acc[jb], 0, 0, 0);
+        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb[ks].mid, acc[jb], 0, 0, 0);
+        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb[ks].hi, acc[jb], 0, 0, 0);
       }
       // the rows of the next half tile fly during the epilogue and the other two products
       issue_half_rows(a, in_nxt, g, rows);
