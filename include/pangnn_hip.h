@@ -161,21 +161,18 @@ int pangnn_segment_max_bwd_f32(const float* g, const int32_t* arg, const int64_t
  *   sums the g_h1 rows of every (32-edge tile, source) run into part_buf[part, 0:D]; part_off[tile] is the
  *   index of the tile's first part, i.e. the number of k < 32*tile with k % 32 == 0 or src_k != src_{k-1}.
  *   g_p[s] is then the sum of the consecutive parts of source s (pangnn_spmm_csr_f32 with idx == NULL).
- *   precision: 0 = every product on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains);
- *              1 = every product on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) with the fp32 operands
- *                  split into bf16 terms and fp32 accumulation: the logit product and dL/dh1 with hi + mid + lo
- *                  (24 significand bits; the six largest partial products, five where W2 is split two-way),
- *                  dL/dW2 with hi + mid of both operands.  fp32-level error (logits within 2e-5 of fp64 in the
- *                  tests), not bit-identical to mode 0; 0.78x its time, because the f32 MFMA occupies the
- *                  SIMD's vector lanes while the bf16 one leaves them to the epilogues.
+ *   precision: must be 0 here = every product on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains): the strict-fp32
+ *              mode.  The bf16 matrix-pipe mode (fp32-level error, the default of the Python layer) is the
+ *              pangnn_decoder_train_f32 + pangnn_decoder_dgrad_f32 pair below; it produces no [E, D] tensor.
  * ---------------------------------------------------------------------------------------- */
 int pangnn_decoder_mlp_fwd_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                const float* extra, const float* cvec, const float* w2, const float* b2,
                                const float* w3, const float* b3, int32_t D, float* logits,
                                pangnn_stream_t stream);
-/* the same forward with the matrix-pipe mode of the training kernel (`precision`, see above): 0 = f32 MFMA,
- * 1 = bf16 matrix pipe with three-way split operands (fp32-level error, about half the time) */
+/* the same forward with the matrix-pipe mode of the training kernels (`precision`): 0 = f32 MFMA (bit-identical to
+ * the logits of pangnn_decoder_mlp_loss_f32), 1 = bf16 matrix pipe with three-way split operands (fp32-level
+ * error; bit-identical to the logits of pangnn_decoder_train_f32, about half the time of mode 0) */
 int pangnn_decoder_mlp_infer_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                                  const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                  const float* extra, const float* cvec, const float* w2, const float* b2,

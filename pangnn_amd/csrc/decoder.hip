@@ -593,581 +593,6 @@ __global__ __launch_bounds__(BWD_WAVES * 64) void decoder_bwd_kernel(
   for (int i = threadIdx.x; i < 4096 + 194; i += BWD_WAVES * 64) slab[i] = red[i];
 }
 
-// ------------------------------------------------------------------------------------------------------
-// bf16x3 variant of the backward / training kernel.  v_mfma_f32_32x32x2_f32 executes on the FP32 vector
-// lanes, so in the kernel above matrix and vector instructions serialise.  Here the first two
-// products run on the real matrix pipe as v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three
-// bf16 terms (hi + mid + lo carries 24 mantissa bits; the six largest partial products are accumulated in
-// fp32, smallest first), which keeps fp32-level accuracy while the vector lanes do the splits, epilogues and
-// the third (f32) product.  One wave per SIMD (4 per workgroup) so that a wave owns 512 registers: the W2
-// fragments of the first product live in registers, the gather is software-pipelined.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct Split3 { bf16x8 hi, mid, lo; };
-
-__device__ __forceinline__ Split3 split8(const float (&f)[8]) {
-  Split3 s;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = (__bf16)f[i];
-    const float r1 = f[i] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    s.hi[i] = h;
-    s.mid[i] = m;
-    s.lo[i] = (__bf16)(r1 - (float)m);
-  }
-  return s;
-}
-
-typedef short short4v __attribute__((ext_vector_type(4)));
-constexpr int IRS = 68;       // row stride (16-bit elements) of the per-tile bf16 images: 136 B, 8-byte aligned rows
-
-// 8 bf16 -> two 8-byte LDS stores (rows are only 8-byte aligned)
-__device__ __forceinline__ void st_img8(short* dst, const bf16x8& v) {
-  struct P { short4v lo, hi; };
-  const P p = __builtin_bit_cast(P, v);
-  *reinterpret_cast<short4v*>(dst) = p.lo;
-  *reinterpret_cast<short4v*>(dst + 4) = p.hi;
-}
-// elements 0..3 at dst, elements 4..7 eight columns further
-__device__ __forceinline__ void st_img4x2(short* dst, const bf16x8& v) {
-  struct P { short4v lo, hi; };
-  const P p = __builtin_bit_cast(P, v);
-  *reinterpret_cast<short4v*>(dst) = p.lo;
-  *reinterpret_cast<short4v*>(dst + 8) = p.hi;
-}
-// 8-deep MFMA fragment from a rows-are-K image: two transposing reads, 4 rows apart
-__device__ __forceinline__ bf16x8 ld_tr8(const short* src) {
-  typedef __attribute__((address_space(3))) short4v lds_s4;
-  struct P { short4v lo, hi; };
-  P p;
-  p.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(src));
-  p.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(src + 4 * IRS));
-  return __builtin_bit_cast(bf16x8, p);
-}
-
-constexpr int X3_WAVES = 4;   // 256 threads, 1 workgroup / CU, 1 wave / SIMD
-constexpr int WTS = 72;       // bf16 row stride of the W2^T images: 144 B, conflict-free ds_read_b128 down rows
-
-template <bool FUSED_LOSS, bool RUNSUM>
-__global__ __launch_bounds__(X3_WAVES * 64) void decoder_bwd_x3_kernel(
-    DecParams a, const float* __restrict__ g_logits, LossParams lp, RunSumParams rs, float* __restrict__ g_h1,
-    float* __restrict__ slabs, int64_t n_tiles) {
-  constexpr int IMG = TE * IRS / 2;                  // one bf16 image [32 edges][64] of the tile, in floats
-  constexpr int PER_WAVE = TE * RS + 64 + 4 * IMG;   // Ht | w_e | (pad) | G hi,mid | h1 hi,mid
-  constexpr int WT_FLOATS = 2 * 64 * WTS / 2;        // two bf16 images [64][WTS] of W2^T (hi, mid)
-  __shared__ __attribute__((aligned(16))) float lds[WT_FLOATS + 3 * 64 + X3_WAVES * PER_WAVE];
-  unsigned short* Wt = reinterpret_cast<unsigned short*>(lds);
-  float* b2l = lds + WT_FLOATS;
-  float* w3l = b2l + 64;
-  float* cvl = w3l + 64;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR: tile index and its addresses stay scalar
-  float* Ht = cvl + 64 + wave * PER_WAVE;
-  float* wl = Ht + TE * RS;
-  short* GIh = reinterpret_cast<short*>(wl + 64);   // G[j][e] as rows e, columns j (bf16 hi / mid): A operand of
-  short* GIm = GIh + TE * IRS;                      //   the third product through transposing reads
-  short* HIh = GIm + TE * IRS;                      // h1[e][k] as rows e, columns k (bf16 hi / mid): its B operand
-  short* HIm = HIh + TE * IRS;
-  const int hh = lane >> 5, r = lane & 31;
-  // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and
-  // lane i receives column i of the 4 rows.  Group g covers columns 16(g&1).., rows 8(g>>1)..; +4 rows for the
-  // second half of an 8-deep fragment, +16 rows for the second k-step, +32 columns for the second block.
-  const int tr_base = (8 * hh + ((lane >> 2) & 3)) * IRS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  // W2^T images for the second product: row k, and inside a row the 64 j in the order the first product's
-  // accumulator hands them over: slot ((b*2+u)*2+half)*8 + jj  <->  j = 32b + (jj&3) + 8(2u + (jj>>2)) + 4 half
-  for (int i = threadIdx.x; i < 64 * 64; i += X3_WAVES * 64) {
-    const int j = i >> 6, kk = i & 63;
-    const float w = a.w2[i];
-    const __bf16 whi = (__bf16)w;
-    const __bf16 wmid = (__bf16)(w - (float)whi);
-    const int j5 = j & 31, t3 = j5 >> 3;
-    const int slot = ((((j >> 5) * 2 + (t3 >> 1)) * 2 + ((j5 >> 2) & 1)) * 8) + (j5 & 3) + 4 * (t3 & 1);
-    Wt[kk * WTS + slot] = __builtin_bit_cast(unsigned short, whi);
-    Wt[64 * WTS + kk * WTS + slot] = __builtin_bit_cast(unsigned short, wmid);
-  }
-  for (int i = threadIdx.x; i < 64; i += X3_WAVES * 64) {
-    b2l[i] = a.b2[i];
-    w3l[i] = a.w3[i];
-    cvl[i] = a.cvec ? a.cvec[i] : 0.f;
-  }
-  // W2 fragments of the first product stay in registers for the whole kernel (one wave per SIMD: 512 VGPRs):
-  // lane (j = r + 32b, half h) holds W2[j][16s + 8h .. + 7], split three ways
-  Split3 Wa[2][4];
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const float4 lo4 = reinterpret_cast<const float4*>(a.w2 + (r + 32 * b) * 64 + 16 * s4 + 8 * hh)[0];
-      const float4 hi4 = reinterpret_cast<const float4*>(a.w2 + (r + 32 * b) * 64 + 16 * s4 + 8 * hh)[1];
-      const float f[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-      Wa[b][s4] = split8(f);
-    }
-  __syncthreads();
-
-  f32x16 acc3[2][2];   // gW2[j = jr(i,hh)+32bj][k = r+32bk]
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc3[x][0][i] = 0.f; acc3[x][1][i] = 0.f; }
-  }
-  // b2 / w3 in the accumulator layout (register i of block b is j = 32b + jr(i, hh)): constants of the whole kernel.
-  // gw3 / gb2 partials live in the same layout, one per register and lane (= per (j, edge slot)); they are summed
-  // over tiles here and over the 32 edge slots once, after the last tile — no h2 image, no per-tile reduction.
-  float gw3a[2][16], gb2a[2][16];
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      gw3a[b][i] = 0.f;
-      gb2a[b][i] = 0.f;
-    }
-  // b2 / w3 of register i of block b (j = 32b + jr(i, hh)): 16-byte LDS reads, 4 registers at a time
-  auto ld4 = [&](const float* v, int b, int qd, float (&o)[4]) {
-    const float4 t = *reinterpret_cast<const float4*>(v + 32 * b + 8 * qd + 4 * hh);
-    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
-  };
-  float gcv[2] = {0.f, 0.f};    // lane (k = r+32bp, hh): partial of gcvec[k]
-  float gb3p = 0.f;
-  float lossp = 0.f;            // FUSED_LOSS: lanes < 32, partial of the (already 1/denom-scaled) loss
-  const float b3v = a.b3[0];
-  const float pw = (FUSED_LOSS && lp.pos_weight) ? lp.pos_weight[0] : 1.f;
-
-  // software-pipelined gather: ids / labels of the next tile at the top of a tile, its node rows after the
-  // second product's epilogue (they land while the third product runs)
-  const int64_t stride = (int64_t)gridDim.x * X3_WAVES;
-  int64_t tile = (int64_t)blockIdx.x * X3_WAVES + wave;
-  TileIds ids_cur = load_ids(a, tile, n_tiles, lane);
-  float aux_cur = 0.f;      // y_e (fused loss) or upstream dL/dlogit_e of this lane's edge
-  if (tile < n_tiles && tile * TE + r < a.E) aux_cur = FUSED_LOSS ? lp.y[tile * TE + r] : g_logits[tile * TE + r];
-  // index of the tile's first run part: fetched one tile ahead like the ids (a wave has nothing else to hide a
-  // load-and-use behind: fetched where it is used it cost 1.2 ms of the kernel)
-  int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile] : 0;
-  TileRows rw;
-  issue_rows(a, ids_cur, lane, rw);
-  auto tile_body = [&](auto full_c) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_c)::value;     // all 32 edges of the tile exist: no bounds predicates
-    const int64_t ebase = tile * TE;
-    commit_rows(a, rw, lane, cvl, Ht);
-    const float w_e = ids_cur.w_e;
-    const int id = ids_cur.id;
-    const TileIds ids_nxt = load_ids(a, tile + stride, n_tiles, lane);
-    const int poff_nxt = (RUNSUM && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
-    float aux_nxt = 0.f;
-    if (tile + stride < n_tiles && (tile + stride) * TE + r < a.E)
-      aux_nxt = FUSED_LOSS ? lp.y[(tile + stride) * TE + r] : g_logits[(tile + stride) * TE + r];
-    float g_e = 0.f;
-    float y_e = 0.f;
-    const bool live = FULL || ebase + r < a.E;
-    if (FUSED_LOSS) {
-      y_e = aux_cur;
-      if (lane < 32) wl[lane] = w_e;
-    } else {
-      g_e = aux_cur;
-      if (lane < 32) { wl[lane] = w_e; gb3p += g_e; }
-    }
-    wave_lds_sync();
-
-    // C[j][e] = sum_k W2[j][k] h1[e][k] on the bf16 matrix pipe, every operand split three ways
-    // (x = hi + mid + lo, 8 + 8 + 8 mantissa bits): the six products with the largest weights are kept,
-    // smallest first, so the result carries fp32-level error
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const float4 lo4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh));
-      const float4 hi4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh + 1));
-      const float f[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-      const Split3 hb = split8(f);
-      st_img8(HIh + r * IRS + 16 * s4 + 8 * hh, hb.hi);
-      st_img8(HIm + r * IRS + 16 * s4 + 8 * hh, hb.mid);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].lo, hb.hi, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].mid, hb.mid, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].hi, hb.lo, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].mid, hb.hi, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].hi, hb.mid, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wa[b][s4].hi, hb.hi, acc[b], 0, 0, 0);
-      }
-    }
-
-    if (FUSED_LOSS) {
-      // h2 = relu(C + b2) in place; the tile's logits; then loss and dL/dlogit per edge
-      float part = 0.f;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          float bbv[4], wwv[4];
-          ld4(b2l, b, qd, bbv);
-          ld4(w3l, b, qd, wwv);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float h2 = relu1(acc[b][4 * qd + c] + bbv[c]);
-            acc[b][4 * qd + c] = h2;
-            part = fmaf(h2, wwv[c], part);
-          }
-        }
-      part += __shfl_xor(part, 32);                 // both halves of the wave now hold edge r's logit
-      const float xv = part + b3v;
-      const float lw = 1.f + (pw - 1.f) * y_e;
-      const float t = expf(-fabsf(xv));             // in (0, 1]
-      const float u = 1.f + t;
-      float ru = __builtin_amdgcn_rcpf(u);
-      ru = ru * (2.f - u * ru);                     // 1 / (1 + t), one Newton step on the hardware reciprocal
-      const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
-      g_e = live ? ((1.f - y_e) - lw * sig_neg) * lp.inv_denom : 0.f;
-      const float um1 = u - 1.f;                    // log1p(t) = log(u) t / (u - 1), = t when u == 1
-      float rm = __builtin_amdgcn_rcpf(um1);
-      rm = rm * (2.f - um1 * rm);
-      const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
-      gb3p += g_e;                                   // per-half partials; lane 0's half is the one read out
-      lossp += live ? ((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f))) * lp.inv_denom : 0.f;   // select, not a branch
-      if (hh == 0 && live) lp.logits[ebase + r] = xv;
-    } else {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          float bbv[4];
-          ld4(b2l, b, qd, bbv);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[b][4 * qd + c] = relu1(acc[b][4 * qd + c] + bbv[c]);
-        }
-    }
-    // gw3[j] += g_e h2[j][e];  gb2[j] += G[j][e] / w3[j];  G[j][e] = g_e w3[j] [h2 > 0] (A operand of the next product)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        float wwv[4];
-        ld4(w3l, b, qd, wwv);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int i = 4 * qd + c;
-          const float h2 = acc[b][i];
-          gw3a[b][i] = fmaf(g_e, h2, gw3a[b][i]);
-          const float tg = h2 > 0.f ? g_e : 0.f;
-          gb2a[b][i] += tg;
-          acc[b][i] = tg * wwv[c];
-        }
-      }
-    wave_lds_sync();
-
-    // gH1[e][k] = sum_j G[j][e] W2[j][k]  : A = G from the accumulator registers, B = W2 rows
-    f32x16 acc2[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc2[0][i] = 0.f; acc2[1][i] = 0.f; }
-    // bf16 matrix pipe again: the A fragment of step (b, u) is the accumulator registers 8u .. 8u+7 of
-    // block b, split three ways in registers; B is the matching 8-j slice of row k of the W2^T images
-    // (two-way split: this product only feeds gradients)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float f[8] = {acc[b][8 * u + 0], acc[b][8 * u + 1], acc[b][8 * u + 2], acc[b][8 * u + 3],
-                            acc[b][8 * u + 4], acc[b][8 * u + 5], acc[b][8 * u + 6], acc[b][8 * u + 7]};
-        const Split3 ga = split8(f);
-        // registers 8u .. 8u+3 are j = 32b + 16u + 4hh + (0..3), 8u+4 .. 8u+7 the same + 8
-        st_img4x2(GIh + r * IRS + 32 * b + 16 * u + 4 * hh, ga.hi);
-        st_img4x2(GIm + r * IRS + 32 * b + 16 * u + 4 * hh, ga.mid);
-#pragma unroll
-        for (int bp = 0; bp < 2; ++bp) {
-          const unsigned short* row = Wt + (r + 32 * bp) * WTS + (((b * 2 + u) * 2 + hh) * 8);
-          const bf16x8 w_hi = *reinterpret_cast<const bf16x8*>(row);
-          const bf16x8 w_mid = *reinterpret_cast<const bf16x8*>(row + 64 * WTS);
-          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.lo, w_hi, acc2[bp], 0, 0, 0);
-          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.mid, w_mid, acc2[bp], 0, 0, 0);
-          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.hi, w_mid, acc2[bp], 0, 0, 0);
-          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.mid, w_hi, acc2[bp], 0, 0, 0);
-          acc2[bp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga.hi, w_hi, acc2[bp], 0, 0, 0);
-        }
-      }
-    if (tile + stride < n_tiles) issue_rows(a, ids_nxt, lane, rw);   // flies during the third product
-
-    // gW2[j][k] += sum_e G[j][e] h1[e][k] on the bf16 matrix pipe too: K = the tile's 32 edges (two k-steps),
-    // A = G and B = h1 come from the bf16 images written above (rows = edges) through transposing reads;
-    // two-way split operands, the three largest partial products (this product only feeds a gradient)
-    wave_lds_sync();
-#ifndef PANGNN_X3_ABL_P3
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[2], am[2], bh[2], bm[2];
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const int off = tr_base + 16 * ks * IRS + 32 * x;
-        ah[x] = ld_tr8(GIh + off);
-        am[x] = ld_tr8(GIm + off);
-        bh[x] = ld_tr8(HIh + off);
-        bm[x] = ld_tr8(HIm + off);
-      }
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mb], bh[nb], acc3[mb][nb], 0, 0, 0);
-          acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bm[nb], acc3[mb][nb], 0, 0, 0);
-          acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc3[mb][nb], 0, 0, 0);
-        }
-    }
-#endif
-    // (the third product sits BEFORE the bounds-predicated stores below: its transposing reads need every lane
-    // active, and in the partial tile the compiler may otherwise schedule them into a predicated region)
-    // mask by h1 > 0, write dL/dh1pre (kept in acc2 for the run sums), accumulate gcvec.  Full tiles store
-    // through one lane base pointer + compile-time offsets: no per-element bounds test or address arithmetic.
-    {
-      float* gout = g_h1 + (ebase + 4 * hh) * DD + r;
-      const bool full = FULL || ebase + TE <= a.E;
-#pragma unroll
-      for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int e = jr(i, hh);
-          const int k = r + 32 * bp;
-          const float hval = Ht[swz(e, k)];
-          const float v = hval > 0.f ? acc2[bp][i] : 0.f;
-#ifndef PANGNN_X3_ABL_STORE
-          if (full || ebase + e < a.E) __builtin_nontemporal_store(v, &gout[jr(i, 0) * DD + 32 * bp]);   // 19 GB written once
-#endif
-          acc2[bp][i] = v;
-        }
-      if (a.extra) {                                 // uniform; only with skip connections
-#pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) gcv[bp] = fmaf(wl[jr(i, hh)], acc2[bp][i], gcv[bp]);
-      }
-    }
-
-#ifndef PANGNN_X3_ABL_RUNSUM
-    if (RUNSUM) {
-      // close a part at the last edge of every source run of the tile
-      const int id_nxt = __shfl(id, (lane + 1) & 63);
-      const bool ok = lane < 32 && (FULL || ebase + lane < a.E);
-      const bool ok_nxt = lane < 31 && (FULL || ebase + lane + 1 < a.E);
-      const unsigned long long mask = __ballot(ok && (!ok_nxt || id != id_nxt));
-      const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask & 0xffffffffull));
-      int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
-      if ((m & (m - 1u)) == 0u) {
-        // one run covers the tile (the common case at degree >> 32): column sums straight from registers
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s0 += acc2[0][i]; s1 += acc2[1][i]; }
-        s0 += __shfl_xor(s0, 32);
-        s1 += __shfl_xor(s1, 32);
-        if (hh == 0) {
-          rs.part[pidx * DD + r] = s0;
-          rs.part[pidx * DD + 32 + r] = s1;
-        }
-      } else if (__builtin_popcount(m) == 2) {
-        // two runs (a source boundary inside the tile: 32/75 of the tiles at cfg 4): both column sums from the
-        // registers, rows selected by their position relative to the boundary — no trip through LDS
-        const int bnd = __builtin_ctz(m);            // last edge of the first run
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const bool first = jr(i, hh) <= bnd;
-          a0 += first ? acc2[0][i] : 0.f;
-          b0 += first ? 0.f : acc2[0][i];
-          a1 += first ? acc2[1][i] : 0.f;
-          b1 += first ? 0.f : acc2[1][i];
-        }
-        a0 += __shfl_xor(a0, 32);
-        a1 += __shfl_xor(a1, 32);
-        b0 += __shfl_xor(b0, 32);
-        b1 += __shfl_xor(b1, 32);
-        if (hh == 0) {
-          rs.part[pidx * DD + r] = a0;
-          rs.part[pidx * DD + 32 + r] = a1;
-          rs.part[(pidx + 1) * DD + r] = b0;
-          rs.part[(pidx + 1) * DD + 32 + r] = b1;
-        }
-      } else {
-        // three or more runs: dL/dh1 tile -> LDS (the h1 image is no longer needed); every lane owns one of the
-        // 64 columns and walks the 32 rows
-        wave_lds_sync();
-#pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) Ht[swz(jr(i, hh), r + 32 * bp)] = acc2[bp][i];
-        wave_lds_sync();
-        float sum = 0.f;
-#pragma unroll
-        for (int e = 0; e < TE; ++e) {
-          sum += Ht[swz(e, lane)];
-          if ((m >> e) & 1u) {
-            rs.part[pidx * DD + lane] = sum;
-            sum = 0.f;
-            ++pidx;
-          }
-        }
-      }
-    }
-#endif
-    wave_lds_sync();   // next tile overwrites Ht / wl / the images
-    ids_cur = ids_nxt;
-    aux_cur = aux_nxt;
-    poff_cur = poff_nxt;
-  };
-  const int64_t n_full = a.E / TE;
-#ifdef PANGNN_X3_NOFULL
-  (void)n_full;
-  for (; tile < n_tiles; tile += stride) tile_body(std::false_type{});
-#else
-  for (; tile < n_full; tile += stride) tile_body(std::true_type{});
-  if (tile < n_tiles) tile_body(std::false_type{});     // the partial tile, when it is this wave's turn
-#endif
-
-  // ---- fold the per-lane partials, then reduce the workgroup's waves in wave order
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      gb2a[b][i] *= w3l[32 * b + jr(i, hh)];
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) {      // over the 32 edge slots of this half (fixed tree)
-        gw3a[b][i] += __shfl_xor(gw3a[b][i], off);
-        gb2a[b][i] += __shfl_xor(gb2a[b][i], off);
-      }
-    }
-  gcv[0] += __shfl_xor(gcv[0], 32);
-  gcv[1] += __shfl_xor(gcv[1], 32);
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) {
-    gb3p += __shfl_xor(gb3p, off);
-    lossp += __shfl_xor(lossp, off);
-  }
-
-  __syncthreads();
-  float* red = cvl + 64;   // reuse the tile area: SLAB floats
-  for (int w = 0; w < X3_WAVES; ++w) {
-    if (wave == w) {
-      const bool first = (w == 0);
-#pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-        for (int bk = 0; bk < 2; ++bk)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int idx = (32 * bj + jr(i, hh)) * 64 + r + 32 * bk;
-            red[idx] = (first ? 0.f : red[idx]) + acc3[bj][bk][i];
-          }
-      if (r == 0) {                                    // lane 0 / 32: the j's of its half, summed over edges
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int j = 32 * b + jr(i, hh);
-            red[4096 + j] = (first ? 0.f : red[4096 + j]) + gb2a[b][i];
-            red[4096 + 64 + j] = (first ? 0.f : red[4096 + 64 + j]) + gw3a[b][i];
-          }
-      }
-      if (hh == 0) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-          red[4096 + 128 + r + 32 * x] = (first ? 0.f : red[4096 + 128 + r + 32 * x]) + gcv[x];
-      }
-      if (lane == 0) {
-        red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
-        red[4096 + 193] = (first ? 0.f : red[4096 + 193]) + lossp;
-      }
-    }
-    __syncthreads();
-  }
-  float* slab = slabs + (int64_t)blockIdx.x * SLAB;
-  for (int i = threadIdx.x; i < 4096 + 194; i += X3_WAVES * 64) slab[i] = red[i];
-}
-
-// Inference form of the bf16 matrix-pipe mode: logits only.  Same first product as the training kernel (six
-// partial products of three-way split operands), then bias + relu + the w3 dot in the accumulator layout.
-// 8 waves per CU (two per SIMD): the W2 terms are LDS images shared by the workgroup (in the training kernel they
-// are registers of its single wave per SIMD), which leaves room for the software-pipelined gather — edge ids two
-// tiles ahead, node rows one tile ahead — of the f32 forward kernel.
-constexpr int FWD_X3_WAVES = 8;
-__global__ __launch_bounds__(FWD_X3_WAVES * 64) void decoder_fwd_x3_kernel(DecParams a, float* __restrict__ logits,
-                                                                            int64_t n_tiles) {
-  constexpr int WIMG = 64 * WTS / 2;      // one bf16 image [64][WTS] of W2, in floats
-  __shared__ __attribute__((aligned(16))) float lds[3 * WIMG + 3 * 64 + FWD_X3_WAVES * TE * RS];
-  unsigned short* Wi = reinterpret_cast<unsigned short*>(lds);      // hi | mid | lo
-  float* b2l = lds + 3 * WIMG;
-  float* w3l = b2l + 64;
-  float* cvl = w3l + 64;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float* Ht = cvl + 64 + wave * (TE * RS);
-  const int hh = lane >> 5, r = lane & 31;
-  for (int i = threadIdx.x; i < 64 * 64; i += FWD_X3_WAVES * 64) {
-    const int j = i >> 6, kk = i & 63;
-    const float w = a.w2[i];
-    const __bf16 whi = (__bf16)w;
-    const float r1 = w - (float)whi;
-    const __bf16 wmid = (__bf16)r1;
-    const __bf16 wlo = (__bf16)(r1 - (float)wmid);
-    Wi[j * WTS + kk] = __builtin_bit_cast(unsigned short, whi);
-    Wi[64 * WTS + j * WTS + kk] = __builtin_bit_cast(unsigned short, wmid);
-    Wi[128 * WTS + j * WTS + kk] = __builtin_bit_cast(unsigned short, wlo);
-  }
-  for (int i = threadIdx.x; i < 64; i += FWD_X3_WAVES * 64) {
-    b2l[i] = a.b2[i];
-    w3l[i] = a.w3[i];
-    cvl[i] = a.cvec ? a.cvec[i] : 0.f;
-  }
-  __syncthreads();
-  const float b3 = a.b3[0];
-  const int64_t stride = (int64_t)gridDim.x * FWD_X3_WAVES;
-  int64_t tile = (int64_t)blockIdx.x * FWD_X3_WAVES + wave;
-  TileIds cur = load_ids(a, tile, n_tiles, lane);
-  TileIds nxt = load_ids(a, tile + stride, n_tiles, lane);
-  TileRows rw;
-  issue_rows(a, cur, lane, rw);
-  for (; tile < n_tiles; tile += stride) {
-    const int64_t ebase = tile * TE;
-    commit_rows(a, rw, lane, cvl, Ht);
-    const TileIds nn = load_ids(a, tile + 2 * stride, n_tiles, lane);
-    issue_rows(a, nxt, lane, rw);                            // next tile's rows fly during the MFMAs
-    nxt = nn;
-    wave_lds_sync();
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const float4 lo4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh));
-      const float4 hi4 = *reinterpret_cast<const float4*>(Ht + swz4(r, 4 * s4 + 2 * hh + 1));
-      const float f[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-      const Split3 hb = split8(f);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const unsigned short* wrow = Wi + (r + 32 * b) * WTS + 16 * s4 + 8 * hh;     // W2[j][16s + 8hh .. + 7]
-        const bf16x8 w_hi = *reinterpret_cast<const bf16x8*>(wrow);
-        const bf16x8 w_mid = *reinterpret_cast<const bf16x8*>(wrow + 64 * WTS);
-        const bf16x8 w_lo = *reinterpret_cast<const bf16x8*>(wrow + 128 * WTS);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo, hb.hi, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid, hb.mid, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, hb.lo, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid, hb.hi, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, hb.mid, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, hb.hi, acc[b], 0, 0, 0);
-      }
-    }
-    float part = 0.f;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int j0 = 32 * b + 8 * qd + 4 * hh;
-        const float4 bb = *reinterpret_cast<const float4*>(b2l + j0);
-        const float4 ww = *reinterpret_cast<const float4*>(w3l + j0);
-        part = fmaf(relu1(acc[b][4 * qd + 0] + bb.x), ww.x, part);
-        part = fmaf(relu1(acc[b][4 * qd + 1] + bb.y), ww.y, part);
-        part = fmaf(relu1(acc[b][4 * qd + 2] + bb.z), ww.z, part);
-        part = fmaf(relu1(acc[b][4 * qd + 3] + bb.w), ww.w, part);
-      }
-    part += __shfl_xor(part, 32);
-    if (lane < 32 && ebase + lane < a.E) logits[ebase + lane] = part + b3;
-    wave_lds_sync();   // the next commit overwrites Ht
-  }
-}
-
 // out[i] = sum over workgroup slabs in index order (fixed => reproducible)
 __global__ __launch_bounds__(kSumThreads) void decoder_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
                                                                 float* __restrict__ g_w2,
@@ -1186,6 +611,11 @@ __global__ __launch_bounds__(kSumThreads) void decoder_reduce_kernel(const float
   else if (i == 4096 + 192) g_b3[0] = s;
   else if (loss) loss[0] = s;
 }
+
+// decoder16.hip: inference form of the bf16 matrix-pipe mode
+int launch_decoder_infer16(const float* p, int64_t ldp, const float* q, int64_t ldq, const int64_t* edge_index, int64_t ld,
+                           int64_t num_edges, const float* extra, const float* cvec, const float* w2, const float* b2,
+                           const float* w3, const float* b3, float* logits, hipStream_t s);
 
 // for decoder16.hip: the same finishing reduction over its slabs (same layout)
 int launch_decoder_reduce(const float* slabs, int n_slabs, float* g_w2, float* g_b2, float* g_w3, float* g_cvec,
@@ -1239,18 +669,16 @@ extern "C" int pangnn_decoder_mlp_infer_f32(const float* p, int64_t ldp, const f
   PG_CHECK_ARG(precision == 0 || precision == 1, PANGNN_E_BADARG, "pangnn_decoder_mlp_infer_f32: precision must be 0 or 1");
   if (num_edges == 0) return 0;
   PG_CHECK_ARG(logits, PANGNN_E_BADARG, "pangnn_decoder_mlp_fwd_f32: null logits");
+  if (precision)   // bf16 matrix pipe, split operands: decoder16.hip (the first product of the training kernel)
+    return launch_decoder_infer16(p, ldp, q, ldq, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3, logits,
+                                  (hipStream_t)stream);
   const int64_t n_tiles = (num_edges + TE - 1) / TE;
-  const int waves = precision ? FWD_X3_WAVES : FWD_WAVES;
-  int64_t grid = (n_tiles + waves - 1) / waves;
+  int64_t grid = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
   const int cus = grid_cus();
   if (grid > cus) grid = cus;
   DecParams a{p, q, (uint32_t)(ldp / 4), (uint32_t)(ldq / 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
-  if (precision)
-    hipLaunchKernelGGL(decoder_fwd_x3_kernel, dim3((unsigned)grid), dim3(FWD_X3_WAVES * 64), 0,
-                       (hipStream_t)stream, a, logits, n_tiles);
-  else
-    hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0,
-                       (hipStream_t)stream, a, logits, n_tiles);
+  hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)grid), dim3(FWD_WAVES * 64), 0, (hipStream_t)stream, a, logits,
+                     n_tiles);
   PG_CHECK_LAUNCH("pangnn_decoder_mlp_fwd_f32");
   return 0;
 }
@@ -1274,8 +702,10 @@ static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, in
                       float* g_cvec, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s) {
   PG_CHECK_ARG(g_w2 && g_b2 && g_w3 && g_b3, PANGNN_E_BADARG, "%s: null gradient output", who);
   const int64_t num_edges = a.E;
-  PG_CHECK_ARG(precision == 0 || precision == 1, PANGNN_E_BADARG, "%s: precision must be 0 (f32 MFMA) or 1 (bf16x3)", who);
-  const int waves = precision ? X3_WAVES : BWD_WAVES;
+  PG_CHECK_ARG(precision == 0, PANGNN_E_BADARG,
+               "%s: only precision 0 (f32 MFMA) here; the bf16 matrix-pipe mode is pangnn_decoder_train_f32 + "
+               "pangnn_decoder_dgrad_f32", who);
+  const int waves = BWD_WAVES;
   const int64_t n_tiles = (num_edges + TE - 1) / TE;
   int64_t grid = (n_tiles + waves - 1) / waves;
   const int cus = grid_cus();
@@ -1295,12 +725,7 @@ static int launch_bwd(const char* who, const DecParams& a, int64_t num_nodes, in
     const RunSumParams rs{part_buf, part_off};
     const dim3 g((unsigned)grid), b(waves * 64);
     float* ws = static_cast<float*>(workspace);
-    if (precision) {
-      if (lp && part_buf) hipLaunchKernelGGL((decoder_bwd_x3_kernel<true, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
-      else if (lp) hipLaunchKernelGGL((decoder_bwd_x3_kernel<true, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
-      else if (part_buf) hipLaunchKernelGGL((decoder_bwd_x3_kernel<false, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
-      else hipLaunchKernelGGL((decoder_bwd_x3_kernel<false, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
-    } else if (lp && part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<true, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
+    if (lp && part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<true, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     else if (lp) hipLaunchKernelGGL((decoder_bwd_kernel<true, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     else if (part_buf) hipLaunchKernelGGL((decoder_bwd_kernel<false, true>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);
     else hipLaunchKernelGGL((decoder_bwd_kernel<false, false>), g, b, 0, s, a, g_logits, l, rs, g_h1, ws, n_tiles);

@@ -36,7 +36,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int D16 = 64;
 constexpr int SLAB16 = 64 * 64 + 64 + 64 + 64 + 16;   // gW2 | gb2 | gw3 | gcvec | gb3, loss (+pad): layout of decoder.hip
 constexpr int S_WAVES = 8;                            // 512 threads, one workgroup per CU, two waves per SIMD
-constexpr int T_WAVES = 16;                           // dgrad kernel: light, latency bound
+constexpr int T_WAVES = 12;                           // dgrad kernel: three waves per SIMD (168 registers each)
 
 // ---- LDS images.  Rows of 64 bf16 = 128 B = 8 chunks of 16 B, unpadded; chunk ch of row r sits at
 // physical chunk ch ^ f(r).  The swizzles make every access pattern below conflict-free (tools/lds_banks.py):
@@ -200,6 +200,7 @@ __device__ __forceinline__ void stage_weights16(const float* w2, const float* b2
 //           k = 32 ks + 8 g' + s)
 //   gl      [16] floats in LDS: g_e
 // returns v[kb][i] = dL/dh1pre[e = 4 g + i][k = 16 kb + c]
+template <bool PIPE>
 __device__ __forceinline__ void dgrad_tile(const char* lds, const char* recl, const char* gl, const bf16x8 (&a2)[2],
                                            int c, int g, int w2p_off0, int w2p_off1, f32x4 (&v)[4]) {
 #pragma unroll
@@ -207,15 +208,23 @@ __device__ __forceinline__ void dgrad_tile(const char* lds, const char* recl, co
   // the three W2' terms of step (t, kb) are read one step ahead of their MFMAs (an LDS round trip is ~100 cycles,
   // the three MFMAs of a step 48)
   bf16x8 bq[2][3];
+  if (PIPE) {
 #pragma unroll
-  for (int x = 0; x < 3; ++x) bq[0][x] = ld_b128(lds, w2p_off0 + x * W_IMG);
+    for (int x = 0; x < 3; ++x) bq[0][x] = ld_b128(lds, w2p_off0 + x * W_IMG);
+  }
 #pragma unroll
   for (int st = 0; st < 8; ++st) {
     const int t = st >> 2, kb = st & 3;
-    if (st < 7) {
-      const int off = (((st + 1) >> 2) ? w2p_off1 : w2p_off0) + ((st + 1) & 3) * 2048;     // rows 16 kb + c
+    if (PIPE) {
+      if (st < 7) {
+        const int off = (((st + 1) >> 2) ? w2p_off1 : w2p_off0) + ((st + 1) & 3) * 2048;     // rows 16 kb + c
 #pragma unroll
-      for (int x = 0; x < 3; ++x) bq[(st + 1) & 1][x] = ld_b128(lds, off + x * W_IMG);
+        for (int x = 0; x < 3; ++x) bq[(st + 1) & 1][x] = ld_b128(lds, off + x * W_IMG);
+      }
+    } else {
+      const int off = (t ? w2p_off1 : w2p_off0) + kb * 2048;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) bq[st & 1][x] = ld_b128(lds, off + x * W_IMG);
     }
     v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], bq[st & 1][2], v[kb], 0, 0, 0);     // lo, mid, hi
     v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], bq[st & 1][1], v[kb], 0, 0, 0);
@@ -350,6 +359,85 @@ __device__ __forceinline__ void issue_half_rows(const D16Params& a, const HalfIn
   }
 }
 
+// ---- first product + logit, shared by the training (S) and inference kernels so that both give bit-identical
+// logits: h1 fragments of lane (c, g) -> split -> C[j][e] = b2[j] + sum_k W2[j][k] h1[e][k] (six partial products,
+// smallest first) -> h2 = relu(C) left in acc (j = 16 jb + 4 g + i), logit of edge c in every lane group.
+// PIPE: the W2 terms of step (ks, jb) are read one step ahead of their MFMAs (12 more registers: the inference
+// kernel has them, the training kernel at 256 registers does not and lets its SIMD partner cover the LDS latency;
+// the MFMA order, hence the result, is the same).
+template <bool PIPE>
+__device__ __forceinline__ float p1_logit(const char* lds, const float (&h)[2][8], int wfrag0, int wfrag1, int g,
+                                          float b3v, f32x4 (&acc)[4]) {
+  const float* b2l = reinterpret_cast<const float*>(lds + LDS_VEC);
+  const float* w3l = b2l + 64;
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) acc[jb] = *reinterpret_cast<const f32x4*>(b2l + 16 * jb + 4 * g);
+  bf16x8 aq[2][3];
+  if (PIPE) {
+#pragma unroll
+    for (int x = 0; x < 3; ++x) aq[0][x] = ld_b128(lds, LDS_W2 + wfrag0 + x * W_IMG);
+  }
+  Split3 hbk;                                       // the terms of one K-step at a time (12 registers)
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int ks = st >> 2, jb = st & 3;
+    if (jb == 0) hbk = split8(h[ks]);
+    if (PIPE) {
+      if (st < 7) {
+        const int off = LDS_W2 + (((st + 1) >> 2) ? wfrag1 : wfrag0) + ((st + 1) & 3) * 2048;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) aq[(st + 1) & 1][x] = ld_b128(lds, off + x * W_IMG);
+      }
+    } else {
+      const int off = LDS_W2 + (ks ? wfrag1 : wfrag0) + jb * 2048;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) aq[st & 1][x] = ld_b128(lds, off + x * W_IMG);
+    }
+    const bf16x8 w_hi = aq[st & 1][0], w_mid = aq[st & 1][1], w_lo = aq[st & 1][2];
+    acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, hbk.hi, acc[jb], 0, 0, 0);
+    acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hbk.mid, acc[jb], 0, 0, 0);
+    acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hbk.lo, acc[jb], 0, 0, 0);
+    acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hbk.hi, acc[jb], 0, 0, 0);
+    acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hbk.mid, acc[jb], 0, 0, 0);
+    acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hbk.hi, acc[jb], 0, 0, 0);
+  }
+  float part = 0.f;
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w3l + 16 * jb + 4 * g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[jb][i] = relu1(acc[jb][i]);
+      part = fmaf(acc[jb][i], ww[i], part);
+    }
+  }
+  return xsum32(xsum16(part)) + b3v;
+}
+// h1 fragments from the gathered row pieces: h = relu(p + q (+ w_e c))
+__device__ __forceinline__ void h1_frags(const HalfRows& rows, bool has_extra, float w_e, const float* cvl, int g,
+                                         float (&h)[2][8]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const float4 pv = rows.p[2 * ks + hf], qv = rows.q[2 * ks + hf];
+      h[ks][4 * hf + 0] = pv.x + qv.x;
+      h[ks][4 * hf + 1] = pv.y + qv.y;
+      h[ks][4 * hf + 2] = pv.z + qv.z;
+      h[ks][4 * hf + 3] = pv.w + qv.w;
+    }
+  if (has_extra) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) h[ks][s] = fmaf(w_e, cvl[32 * ks + 8 * g + s], h[ks][s]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) h[ks][s] = relu1(h[ks][s]);
+}
+
 template <bool FUSED_LOSS, bool RUNSUM>
 __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     D16Params a, const float* __restrict__ g_logits, D16Loss lp, float* __restrict__ logits, D16Run rs,
@@ -360,8 +448,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   char* wv = lds + LDS_WAVE0 + wave * WV_BYTES;
   stage_weights16(a.w2, a.b2, a.w3, a.cvec, lds, S_WAVES * 64, 3, LDS_W2P, LDS_VEC);
   __syncthreads();
-  const float* b2l = reinterpret_cast<const float*>(lds + LDS_VEC);
-  const float* w3l = b2l + 64;
+  const float* w3l = reinterpret_cast<const float*>(lds + LDS_VEC) + 64;
   const float* cvl = w3l + 64;
 
   // lane-constant LDS offsets
@@ -373,17 +460,14 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   const int colp = 16 * (((g & 1) << 1) | (g >> 1)) + c;               // column a lane holds after red4: block {0, 2, 1, 3}[g]
   // transposing reads of the 32x32x16 operands (P3): 16-lane group q4, block rows 8 (q4 >> 1) + (li >> 2) (+4),
   // columns 32 blk + 16 (q4 & 1) + 4 (li & 3)
-  int tr3[2][2];
+  int tr3h[2];                             // column block 0; block 1 is the same offset ^ 64 (chunk bit 2)
   {
     const int li = lane & 15, q4 = lane >> 4, p = li & 3;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int row = 8 * (q4 >> 1) + (li >> 2) + 4 * half;
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const int ch = 4 * blk + 2 * (q4 & 1) + (p >> 1);
-        tr3[blk][half] = row * 128 + ((ch ^ tsw(row)) << 4) + 8 * (p & 1);
-      }
+      const int ch = 2 * (q4 & 1) + (p >> 1);
+      tr3h[half] = row * 128 + ((ch ^ tsw(row)) << 4) + 8 * (p & 1);
     }
   }
 
@@ -425,79 +509,15 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 
       // h1 fragments (B operand of P1): lane (c, g) holds h1[c][32 ks + 8 g + 0..7]
       float h[2][8];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const float4 pv = rows.p[2 * ks + hf], qv = rows.q[2 * ks + hf];
-          h[ks][4 * hf + 0] = pv.x + qv.x;
-          h[ks][4 * hf + 1] = pv.y + qv.y;
-          h[ks][4 * hf + 2] = pv.z + qv.z;
-          h[ks][4 * hf + 3] = pv.w + qv.w;
-        }
-      if (has_extra) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int s = 0; s < 8; ++s) h[ks][s] = fmaf(in_cur.w_e, cvl[32 * ks + 8 * g + s], h[ks][s]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) h[ks][s] = relu1(h[ks][s]);
+      h1_frags(rows, has_extra, in_cur.w_e, cvl, g, h);
 
       // ---- P1: C[j][e] = b2[j] + sum_k W2[j][k] h1[e][k]
       f32x4 acc[4];
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) acc[jb] = *reinterpret_cast<const f32x4*>(b2l + 16 * jb + 4 * g);
-      uint32_t m1 = 0;
-      // W2 terms of step (ks, jb) are read one step ahead of their six MFMAs
-      bf16x8 aq[2][3];
-#pragma unroll
-      for (int x = 0; x < 3; ++x) aq[0][x] = ld_b128(lds, LDS_W2 + wfrag0 + x * W_IMG);
-      Split3 hb[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        hb[ks] = split8(h[ks]);
-        // m1 bits: element s = 2 qd + half of this K-step lands at bit 16 half + 7 - (4 ks + qd)   (h >= 0: bits != 0 <=> h > 0)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const uint32_t b0 = __builtin_bit_cast(uint32_t, h[ks][2 * qd]), b1 = __builtin_bit_cast(uint32_t, h[ks][2 * qd + 1]);
-          m1 = (m1 << 1) | min(b0, 1u) | (min(b1, 1u) << 16);
-        }
-      }
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        const int ks = st >> 2, jb = st & 3;
-        if (st < 7) {
-          const int off = LDS_W2 + (((st + 1) >> 2) ? wfrag1 : wfrag0) + ((st + 1) & 3) * 2048;
-#pragma unroll
-          for (int x = 0; x < 3; ++x) aq[(st + 1) & 1][x] = ld_b128(lds, off + x * W_IMG);
-        }
-        const bf16x8 w_hi = aq[st & 1][0], w_mid = aq[st & 1][1], w_lo = aq[st & 1][2];
-        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, hb[ks].hi, acc[jb], 0, 0, 0);
-        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb[ks].mid, acc[jb], 0, 0, 0);
-        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb[ks].lo, acc[jb], 0, 0, 0);
-        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, hb[ks].hi, acc[jb], 0, 0, 0);
-        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb[ks].mid, acc[jb], 0, 0, 0);
-        acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, hb[ks].hi, acc[jb], 0, 0, 0);
-      }
+      const float xv = p1_logit<false>(lds, h, wfrag0, wfrag1, g, b3v, acc);
       // the rows of the next half tile fly during the epilogue and the other two products
       issue_half_rows(a, in_nxt, g, rows);
 
-      // ---- logits, loss, g_e
-      float part = 0.f;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const f32x4 ww = *reinterpret_cast<const f32x4*>(w3l + 16 * jb + 4 * g);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[jb][i] = relu1(acc[jb][i]);
-          part = fmaf(acc[jb][i], ww[i], part);
-        }
-      }
-      part = xsum32(xsum16(part));
-      const float xv = part + b3v;
+      // ---- loss, g_e
       float g_e;
       if (FUSED_LOSS) {
         const float y_e = in_cur.aux;
@@ -547,6 +567,15 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
         *reinterpret_cast<short4v*>(wv + WV_M2 + (m2w ^ ((2 * t) << 5))) = pk.lo;        // columns 16 (2t) + 4 g ..
         *reinterpret_cast<short4v*>(wv + WV_M2 + (m2w ^ ((2 * t + 1) << 5))) = pk.hi;    // columns 16 (2t+1) + 4 g ..
       }
+      // relu mask bits of h1: element s = 2 qd + half of K-step ks lands at bit 16 half + 7 - (4 ks + qd)   (h >= 0: bits != 0 <=> h > 0)
+      uint32_t m1 = 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const uint32_t b0 = __builtin_bit_cast(uint32_t, h[ks][2 * qd]), b1 = __builtin_bit_cast(uint32_t, h[ks][2 * qd + 1]);
+          m1 = (m1 << 1) | min(b0, 1u) | (min(b1, 1u) << 16);
+        }
       const uint32_t recw = (m1 & 0x00ff00ffu) | ((m2 & 0x00ff00ffu) << 8);
       *reinterpret_cast<uint32_t*>(wv + WV_REC + 16 * c + 4 * g) = recw;
       *reinterpret_cast<float*>(wv + WV_GL + 4 * c) = g_e;               // the four lane groups write the same value
@@ -575,12 +604,12 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       {
         bf16x8 am[2];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) am[mb] = ld_tr8(wv + WV_M2, tr3[mb][0], tr3[mb][1]);
+        for (int mb = 0; mb < 2; ++mb) am[mb] = ld_tr8(wv + WV_M2, tr3h[0] ^ (mb << 6), tr3h[1] ^ (mb << 6));
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
           for (int term = 2; term >= 0; --term) {
-            const bf16x8 bh = ld_tr8(wv + WV_HG + term * T_IMG, tr3[nb][0], tr3[nb][1]);
+            const bf16x8 bh = ld_tr8(wv + WV_HG + term * T_IMG, tr3h[0] ^ (nb << 6), tr3h[1] ^ (nb << 6));
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
               acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mb], bh, acc3[mb][nb], 0, 0, 0);
@@ -590,7 +619,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       // ---- P2 + run sums by source
       if (RUNSUM || has_extra) {
         f32x4 v[4];
-        dgrad_tile(lds, wv + WV_REC, wv + WV_GL, a2, c, g, LDS_W2P + wfrag0, LDS_W2P + wfrag1, v);
+        dgrad_tile<false>(lds, wv + WV_REC, wv + WV_GL, a2, c, g, LDS_W2P + wfrag0, LDS_W2P + wfrag1, v);
 #ifdef PANGNN_D16_DEBUG
         if (d16_dbg_v != nullptr) {
 #pragma unroll
@@ -769,7 +798,7 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
         continue;
       }
       f32x4 v[4];
-      dgrad_tile(lds, wv + TW_REC, wv + TW_GL, a2, c, g, wfrag0, wfrag1, v);
+      dgrad_tile<true>(lds, wv + TW_REC, wv + TW_GL, a2, c, g, wfrag0, wfrag1, v);
       if (has_extra && gcv_slabs != nullptr) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + TW_WL + 16 * g);
 #pragma unroll
@@ -823,6 +852,60 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Inference: logits only.  Same first product (p1_logit) as the training kernel => bit-identical logits.
+// 16-edge tiles, 16 waves per CU (the kernel holds no gradient accumulators), rows of the next tile prefetched.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int I_WAVES = 16;
+__device__ __forceinline__ HalfIn load_tile16(const D16Params& a, int64_t tile, int64_t n_tiles, int c) {
+  HalfIn h;
+  const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
+  const int64_t e_tile = tc * 16;
+  const int64_t rest = a.E - 1 - e_tile;
+  const int lim = (int)(rest < 15 ? rest : 15);
+  const int k = min(c, lim);
+  const int64_t* ei = a.ei + e_tile;
+  const int64_t s = ei[k], d = ei[a.ld + k];
+  h.key = h.key_nxt = 0;
+  h.poff = (uint32_t)s * a.ldp_b;
+  h.qoff = (uint32_t)d * a.ldq_b;
+  h.aux = 0.f;
+  h.w_e = a.extra ? (a.extra + e_tile)[k] : 0.f;
+  return h;
+}
+__global__ __launch_bounds__(I_WAVES * 64) void decoder_infer16_kernel(D16Params a, float* __restrict__ logits,
+                                                                      int64_t n_tiles) {
+  // LDS: W2 hi | mid | lo at LDS_W2 (the W2' slot stays unused), vectors at LDS_VEC
+  __shared__ __attribute__((aligned(16))) char lds[LDS_WAVE0];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  stage_weights16(a.w2, a.b2, a.w3, a.cvec, lds, I_WAVES * 64, 1, LDS_W2P, LDS_VEC);
+  __syncthreads();
+  const float* cvl = reinterpret_cast<const float*>(lds + LDS_VEC) + 128;
+  const int wfrag0 = c * 128 + ((g ^ wsw(c)) << 4), wfrag1 = wfrag0 ^ 64;
+  const float b3v = a.b3[0];
+  const bool has_extra = a.extra != nullptr;
+  const int64_t stride = (int64_t)gridDim.x * I_WAVES;
+  int64_t tile = (int64_t)blockIdx.x * I_WAVES + wave;
+  HalfIn cur = load_tile16(a, tile, n_tiles, c);
+  HalfIn nxt = load_tile16(a, tile + stride, n_tiles, c);
+  HalfRows rows;
+  issue_half_rows(a, cur, g, rows);
+  for (; tile < n_tiles; tile += stride) {
+    float h[2][8];
+    h1_frags(rows, has_extra, cur.w_e, cvl, g, h);
+    const HalfIn nn = load_tile16(a, tile + 2 * stride, n_tiles, c);
+    issue_half_rows(a, nxt, g, rows);                       // next tile's rows fly during the product
+    f32x4 acc[4];
+    const float xv = p1_logit<true>(lds, h, wfrag0, wfrag1, g, b3v, acc);
+    const int64_t e = tile * 16 + c;
+    if (g == 0 && e < a.E) logits[e] = xv;
+    cur = nxt;
+    nxt = nn;
+  }
+}
+
 }  // namespace pangnn
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -847,6 +930,22 @@ static int cu_count() {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
   return cus;
+}
+}  // namespace pangnn
+
+namespace pangnn {
+// decoder.hip (pangnn_decoder_mlp_infer_f32, precision = 1) -> the 16-edge-tile inference kernel of this file
+int launch_decoder_infer16(const float* p, int64_t ldp, const float* q, int64_t ldq, const int64_t* edge_index, int64_t ld,
+                           int64_t num_edges, const float* extra, const float* cvec, const float* w2, const float* b2,
+                           const float* w3, const float* b3, float* logits, hipStream_t s) {
+  const int64_t n_tiles = (num_edges + 15) / 16;
+  int64_t grid = (n_tiles + I_WAVES - 1) / I_WAVES;
+  const int cus = cu_count();
+  if (grid > cus) grid = cus;
+  D16Params a{p, q, (uint32_t)(ldp * 4), (uint32_t)(ldq * 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  hipLaunchKernelGGL(decoder_infer16_kernel, dim3((unsigned)grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles);
+  PG_CHECK_LAUNCH("pangnn_decoder_mlp_infer_f32");
+  return 0;
 }
 }  // namespace pangnn
 

@@ -1,4 +1,4 @@
-"""Diagnostic for csrc/decoder16.hip: per-part errors of the S kernel's by-source run sums and relu-mask flips of
+"""Diagnostic for csrc/decoder16.hip (build it with -DPANGNN_D16_DEBUG to get the dL/dh1 dump): per-part errors of the S kernel's by-source run sums and relu-mask flips of
 the records against torch.  python tools/debug_d16.py"""
 import os, sys
 import torch
@@ -50,7 +50,7 @@ def run(e, srt, skip, n=97, seed=None):
                                             _lib.ptr(ex_), _lib.ptr(cv_), w2_.data_ptr(), b2_.data_ptr(), w3_.data_ptr(),
                                             b3_.data_ptr(), 64, None, None, 0, g_.data_ptr(), None, None, rec.data_ptr(),
                                             _lib.ptr(parts), None if plan is None else plan.part_off.data_ptr(),
-                                            gw2.data_ptr(), gb2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(), _lib.ptr(gcv),
+                                            gw2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(), _lib.ptr(gcv),
                                             ws.data_ptr(), wsb, _lib.stream_ptr()), "train")
     torch.cuda.synchronize()
     msg = f"E={e} sorted={srt} skip={skip}:"
