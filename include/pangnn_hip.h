@@ -309,6 +309,16 @@ int    pangnn_bce_logits_f32(const float* logits, const float* y, const float* p
                              int64_t denom, float* loss, float* g_logits, void* workspace,
                              size_t workspace_bytes, pangnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * normalize_sim_scores (src/preprocessing.py:454-548) over a relation sorted by (source gene, candidate genome):
+ * segment k = items [rowptr[k], rowptr[k+1]).  Per segment p = softmax(score / t) (one candidate: p = 1),
+ * q = -10 log10(clip(1 - p, epsilon, 1 - epsilon)) + pseudo_count, float64 as in the reference.  One wavefront
+ * per segment, fixed reduction order.  
+ * ---------------------------------------------------------------------------------------- */
+int    pangnn_softmax_qscore_f64(const int64_t* rowptr, const double* score, int64_t num_segments,
+                                 int64_t num_items, double t, double epsilon, double pseudo_count, double* q,
+                                 pangnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

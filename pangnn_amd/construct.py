@@ -1,4 +1,5 @@
-"""Graph construction on integer COO arrays (runs on whatever device the tensors live on).
+"""Graph construction on integer COO arrays (runs on the device of its inputs: sort / unique / searchsorted programs
+plus, on the GPU, the segmented softmax -> Q-score HIP kernel of csrc/edge_ops.hip).
 
 Restates the host pipeline the reference runs as nested Python dict loops
 (/root/reference/src/preprocessing.py:73-156,264-325,370-385,454-548; src/dataset.py:325-384) as
@@ -46,6 +47,22 @@ def normalize_sim_scores(src, dst, score, genome_of, t: float = 0.8, epsilon: fl
     src, dst, score = src[ns], dst[ns], score[ns]
     g = int(genome_of.max().item()) + 1 if genome_of.numel() else 1
     key = src * g + genome_of[dst].to(src.dtype)
+    if src.is_cuda:
+        # device tensors: one segmented HIP pass over the key-sorted relation (pangnn_softmax_qscore_f64)
+        from . import _lib
+        lib = _lib.load()
+        order = torch.argsort(key, stable=True)
+        src, dst, key = src[order], dst[order], key[order]
+        sc = score[order].to(torch.float64).contiguous()
+        _, cnt = torch.unique_consecutive(key, return_counts=True)
+        rowptr = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=src.device)
+        torch.cumsum(cnt, 0, out=rowptr[1:])
+        q = torch.empty_like(sc)
+        with torch.cuda.device(src.device):
+            _lib.check(lib.pangnn_softmax_qscore_f64(rowptr.data_ptr(), sc.data_ptr(), int(cnt.numel()), int(sc.numel()),
+                                                     float(t), float(epsilon), float(pseudo_count), q.data_ptr(),
+                                                     _lib.stream_ptr()), "pangnn_softmax_qscore_f64")
+        return src, dst, q
     inv, cnt = _segments(key)
     x = score.to(torch.float64) / t
     nseg = cnt.numel()

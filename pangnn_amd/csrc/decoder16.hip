@@ -36,7 +36,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int D16 = 64;
 constexpr int SLAB16 = 64 * 64 + 64 + 64 + 64 + 16;   // gW2 | gb2 | gw3 | gcvec | gb3, loss (+pad): layout of decoder.hip
 constexpr int S_WAVES = 8;                            // 512 threads, one workgroup per CU, two waves per SIMD
-constexpr int T_WAVES = 12;                           // dgrad kernel: three waves per SIMD (168 registers each)
+constexpr int T_WAVES = 16;                           // dgrad kernel: four waves per SIMD (128 registers each): its record gathers are latency bound
 
 // ---- LDS images.  Rows of 64 bf16 = 128 B = 8 chunks of 16 B, unpadded; chunk ch of row r sits at
 // physical chunk ch ^ f(r).  The swizzles make every access pattern below conflict-free (tools/lds_banks.py):
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
         continue;
       }
       f32x4 v[4];
-      dgrad_tile<true>(lds, wv + TW_REC, wv + TW_GL, a2, c, g, wfrag0, wfrag1, v);
+      dgrad_tile<false>(lds, wv + TW_REC, wv + TW_GL, a2, c, g, wfrag0, wfrag1, v);
       if (has_extra && gcv_slabs != nullptr) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + TW_WL + 16 * g);
 #pragma unroll

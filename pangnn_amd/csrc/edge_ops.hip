@@ -289,6 +289,43 @@ static inline unsigned grid_for(int64_t total) {
   return (unsigned)b;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// normalize_sim_scores (src/preprocessing.py:454-548) as ONE segmented pass over the (source, candidate genome)-sorted
+// relation: per segment  p = softmax(score / t)  (a single candidate: p = 1),  q = -10 log10(clip(1 - p, eps, 1 - eps))
+// + pseudo_count, in float64 like the reference's numpy.  One wavefront per segment (segments hold ~2 .. 500
+// candidates): lanes stride over the segment for the maximum, then for sum exp(x - max) with a fixed xor-shuffle
+// tree (deterministic), then write q.  Replaces four float64 ATen scatter / gather passes.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void softmax_qscore_kernel(const int64_t* __restrict__ rowptr,
+                                                               const double* __restrict__ score, int64_t nseg, double t,
+                                                               double eps, double pseudo, double* __restrict__ q) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t seg = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (seg >= nseg) return;                       // wave-uniform: whole waves leave
+  const int64_t beg = rowptr[seg], end = rowptr[seg + 1];
+  const double q_one = -10.0 * log10(eps) + pseudo;                     // p = 1: clip(0, eps, 1 - eps) = eps
+  if (end - beg == 1) {
+    if (lane == 0) q[beg] = q_one;
+    return;
+  }
+  double mx = -INFINITY;
+  for (int64_t i = beg + lane; i < end; i += kWave) mx = fmax(mx, score[i] / t);     // divide like the reference (t = 0.8 is not a binary fraction)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+  double sm = 0.0;
+  for (int64_t i = beg + lane; i < end; i += kWave) sm += exp(score[i] / t - mx);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off);
+  const double lse = log(sm) + mx;                                      // scipy.special.logsumexp
+  for (int64_t i = beg + lane; i < end; i += kWave) {
+    const double p = exp(score[i] / t - lse);
+    double c = 1.0 - p;
+    c = c < eps ? eps : (c > 1.0 - eps ? 1.0 - eps : c);
+    const double v = -10.0 * log10(c);
+    q[i] = (p != p ? -10.0 * log10(1.0 - eps) : v) + pseudo;            // NaN p: the reference's nan_to_num branch
+  }
+}
+
 }  // namespace pangnn
 
 using namespace pangnn;
@@ -501,5 +538,20 @@ extern "C" int pangnn_confusion_update_f32(const float* scores, const float* lab
   hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, scores, labels, n,
                      threshold, apply_sigmoid, reinterpret_cast<unsigned long long*>(counts));
   PG_CHECK_LAUNCH("pangnn_confusion_update_f32");
+  return 0;
+}
+
+extern "C" int pangnn_softmax_qscore_f64(const int64_t* rowptr, const double* score, int64_t num_segments,
+                                         int64_t num_items, double t, double epsilon, double pseudo_count, double* q,
+                                         pangnn_stream_t stream) {
+  PG_CHECK_ARG(num_segments >= 0 && num_items >= 0 && t > 0.0 && epsilon > 0.0, PANGNN_E_BADARG,
+               "pangnn_softmax_qscore_f64: bad size / temperature / epsilon");
+  if (num_segments == 0 || num_items == 0) return 0;
+  PG_CHECK_ARG(rowptr && score && q, PANGNN_E_BADARG, "pangnn_softmax_qscore_f64: null pointer");
+  const int64_t blocks = (num_segments + kWavesPerBlock - 1) / kWavesPerBlock;
+  PG_CHECK_ARG(blocks < 2147483647LL, PANGNN_E_TOOLARGE, "pangnn_softmax_qscore_f64: too many segments");
+  hipLaunchKernelGGL(softmax_qscore_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, rowptr, score,
+                     num_segments, t, epsilon, pseudo_count, q);
+  PG_CHECK_LAUNCH("pangnn_softmax_qscore_f64");
   return 0;
 }

@@ -265,6 +265,12 @@ class HipOps:
     def decoder_loss(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
         return PF.decoder_loss(p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
 
+    def linear(self, x, w, b, in_act: int = 0):
+        return PF.linear(x, w, b, in_act)
+
+    def bce_sum_over(self, logits, labels, pos_weight, denom):
+        """sum_i BCEWithLogits_i / denom (this rank's share of the global mean)"""
+        return PF.bce_with_logits(logits, labels, pos_weight, denom=denom)
 
 
 class DistAlternateGCN(AlternateGCN):
@@ -312,17 +318,19 @@ class DistAlternateGCN(AlternateGCN):
         return AllGatherRows.apply(x_local, self.group)
 
     def _norm(self, shard, name, weight, wkey):
+        """normalisation of (graph `name`, weight tensor): cached on the shard, keyed on the weight tensor's identity
+        and version; the entry keeps the tensor alive so that its address cannot be handed to another one"""
         cache = shard.__dict__.setdefault("_dist_norms", {})
         key = (name, wkey, self.exchange)
-        if key not in cache:
+        ident = None if weight is None else (weight.data_ptr(), weight._version, tuple(weight.shape))
+        hit = cache.get(key)
+        if hit is None or hit[0] != ident:
             gather = lambda d: self._table(d.view(-1, 1), shard, name).view(-1).contiguous()   # noqa: E731
-            cache[key] = self.ops.norm(self._st(shard, name), weight, gather)
-        return cache[key]
+            hit = cache[key] = (ident, self.ops.norm(self._st(shard, name), weight, gather), weight)
+        return hit[1]
 
     def _linear(self, x, w, b, in_act: int = 0):
-        if x.is_cuda:
-            return PF.linear(x, w, b, in_act)
-        return F.linear(F.elu(x) if in_act else x, w, b)                   # CPU only in the gloo tests
+        return self.ops.linear(x, w, b, in_act)
 
     def _conv(self, conv, h_local, shard, name, weight, wkey, tag, in_elu: bool = False):
         """`in_elu`: h_local is the pre-activation of the deferred ELU (see AlternateGCN._encode_pre)"""
@@ -408,10 +416,7 @@ class DistAlternateGCN(AlternateGCN):
                                          self.mlp[2].bias, self.mlp[4].weight.view(-1), self.mlp[4].bias, labels,
                                          pos_weight, shard.e_sim_total)
         out = self.decode_mlp(self.activation_fct(z) if fold else z, shard)
-        if out.is_cuda:
-            return PF.bce_with_logits(out, labels, pos_weight, denom=shard.e_sim_total), out.detach()
-        return F.binary_cross_entropy_with_logits(out, labels, pos_weight=pos_weight,
-                                                  reduction="sum") / shard.e_sim_total, out.detach()
+        return self.ops.bce_sum_over(out, labels, pos_weight, shard.e_sim_total), out.detach()
 
     def sync_gradients(self):
         """one flat all-reduce (sum) of every parameter gradient: 216 KB at default dims"""
@@ -432,7 +437,7 @@ def train_step(model: DistAlternateGCN, optimizer, shard, labels, pos_weight):
     by the global edge count and the gradient all-reduce is a plain sum."""
     optimizer.zero_grad(set_to_none=True)
     loss, out = model.loss_and_logits(shard, labels, pos_weight)
-    loss.backward(PF.unit_grad(loss.device) if loss.is_cuda else None)
+    loss.backward(PF.unit_grad(loss.device))
     model.sync_gradients()
     optimizer.step()
     return loss.detach(), out.detach()

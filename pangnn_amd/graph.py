@@ -65,13 +65,14 @@ class EdgeStructure:
         """`num_nodes` = number of TARGET rows (= all nodes for a whole graph).  `num_src` (default
         the same) = number of SOURCE rows: a destination-partitioned shard keeps local target ids
         and global source ids (pangnn_amd/dist.py)."""
+        self._key_tensor = edge_index        # the caches are keyed on THIS tensor's address: keep it alive
         self.edge_index = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
         self.num_nodes = int(num_nodes)
         self.num_src = int(num_nodes if num_src is None else num_src)
         self.num_edges = int(edge_index.shape[1])
         self._by_dst: Optional[CSR] = None
         self._by_src: Optional[CSR] = None
-        self._norm: Dict[Tuple, "GcnNorm"] = {}
+        self._norm: Dict[Tuple, Tuple["GcnNorm", Optional[torch.Tensor]]] = {}
         self._runsum = None
 
     @property
@@ -138,11 +139,13 @@ class EdgeStructure:
                                                 tuple(edge_weight.shape))
         hit = self._norm.get(key)
         if hit is None:
-            hit = GcnNorm(self, edge_weight, gather_dis)
+            # the entry keeps `edge_weight` alive: a freed tensor's address can be handed to a new same-shape
+            # tensor (fresh tensors all have _version 0), which would then match this key
+            hit = (GcnNorm(self, edge_weight, gather_dis), edge_weight)
             if len(self._norm) >= 4:
                 self._norm.pop(next(iter(self._norm)))
             self._norm[key] = hit
-        return hit
+        return hit[0]
 
 
 class GcnNorm:

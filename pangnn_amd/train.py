@@ -4,17 +4,14 @@ gather/scatter inside `model` runs in libpangnn_hip.so."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import functional as PF
 
 
 def criterion(logits, labels, pos_weight):
     """torch.nn.BCEWithLogitsLoss(pos_weight=class_balance) (pangnn.py:98) — loss and dL/dlogits from one
-    HIP pass on the GPU"""
-    if logits.is_cuda:
-        return PF.bce_with_logits(logits, labels, pos_weight)
-    return F.binary_cross_entropy_with_logits(logits, labels, pos_weight=pos_weight)
+    HIP pass (device tensors only: there is no CPU path)"""
+    return PF.bce_with_logits(logits, labels, pos_weight)
 
 
 def make_optimizer(model, lr: float = 1e-3, capturable: bool = False):
@@ -29,7 +26,7 @@ def train_step(model, optimizer, graph, labels, pos_weight):
     else:
         out = model(graph)
         loss = criterion(out, labels, pos_weight)                                   # pangnn.py:98,203
-    loss.backward(PF.unit_grad(loss.device) if loss.is_cuda else None)              # = loss.backward(), see unit_grad
+    loss.backward(PF.unit_grad(loss.device))                                        # = loss.backward(), see unit_grad
     optimizer.step()
     return loss.detach(), out.detach()
 

@@ -1,5 +1,10 @@
-"""CPU suite: the product's tensor-program graph construction (pangnn_amd/construct.py, subgraphs.py,
-simulate.py) against fixtures built by the reference's own code (tests/golden/*.npz)."""
+"""The product's graph construction (pangnn_amd/construct.py, subgraphs.py, simulate.py) against fixtures built by
+the reference's own code (tests/golden/*.npz), on BOTH devices: the `cpu` legs run in the CPU suite, the `cuda`
+legs carry the gpu mark and run the same programs where bench.py and the product run them (device sort / unique /
+searchsorted and the segmented softmax -> Q-score HIP kernel).  Ids and labels: bit-exact on both.  fp32 weights:
+bit-exact on the CPU; on the device the float64 exp / log / log10 of the GPU math library may differ from the host
+libm in the last place, which can move a value across an fp32 rounding boundary: at most 1 fp32 ulp, on at most
+0.1 % of the edges (asserted below; in practice 0)."""
 import numpy as np
 import pytest
 import torch
@@ -8,23 +13,65 @@ from conftest import load_golden
 from pangnn_amd import construct, simulate, subgraphs
 
 FIXTURES = ["sim_200x4", "cfg1_2genomes", "cfg2_sim_1000x5", "cfg3_5genomes"]
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
 
 
-def T(f, k):
-    return torch.from_numpy(f[k])
+def T(f, k, device="cpu"):
+    return torch.from_numpy(f[k]).to(device)
 
 
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_weights(got, want, device):
+    """fp32 edge weights: identical on the CPU; within 1 ulp on <= 0.1 % of the entries on the device"""
+    got, want = np.asarray(got, dtype=np.float32), np.asarray(want, dtype=np.float32)
+    if device == "cpu":
+        assert np.array_equal(got, want)
+        return
+    bad = got != want
+    if bad.any():
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1 and bad.mean() <= 1e-3, (int(ulp.max()), float(bad.mean()))
+
+
+@pytest.mark.parametrize("device", DEVICES)
 @pytest.mark.parametrize("name", FIXTURES)
-def test_whole_graph_construction_is_bit_exact(name):
+def test_whole_graph_construction_is_bit_exact(name, device):
     f = load_golden(name)
-    g = construct.build_from_raw(int(f["num_nodes"]), T(f, "raw_src"), T(f, "raw_dst"), T(f, "raw_score"),
-                                 T(f, "genome_of").long(), pair_src=T(f, "grp_src"), pair_dst=T(f, "grp_dst"))
+    g = construct.build_from_raw(int(f["num_nodes"]), T(f, "raw_src", device), T(f, "raw_dst", device),
+                                 T(f, "raw_score", device), T(f, "genome_of", device).long(),
+                                 pair_src=T(f, "grp_src", device), pair_dst=T(f, "grp_dst", device))
+    assert g.edge_index.device.type == device
     o = np.lexsort((f["whole_edge_index"][1], f["whole_edge_index"][0]))
-    assert np.array_equal(g.edge_index.numpy(), f["whole_edge_index"][:, o])          # bit-exact edge_index
-    assert np.array_equal(g.neighbour_edge_index.numpy(), f["whole_neighbour_edge_index"])
-    assert np.array_equal(g.y.numpy(), f["whole_y"][o])
-    assert np.array_equal(g.edge_attr.numpy(), f["whole_edge_attr"][o])               # fp32 weights identical on CPU
-    assert np.array_equal(g.x.numpy(), f["whole_x"])
+    assert np.array_equal(N(g.edge_index), f["whole_edge_index"][:, o])               # bit-exact edge_index
+    assert np.array_equal(N(g.neighbour_edge_index), f["whole_neighbour_edge_index"])
+    assert np.array_equal(N(g.y), f["whole_y"][o])
+    assert_weights(N(g.edge_attr), f["whole_edge_attr"][o], device)
+    assert np.array_equal(N(g.x), f["whole_x"])
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("name", FIXTURES)
+def test_normalized_relation_matches_reference_float64(name, device):
+    """normalize_sim_scores alone, in float64 (the fixture holds the reference's float64 weights): the CPU torch
+    program and the device kernel (pangnn_softmax_qscore_f64: one wavefront per (source, genome) segment)"""
+    f = load_golden(name)
+    s, d, w = construct.normalize_sim_scores(T(f, "flt_src", device), T(f, "flt_dst", device), T(f, "flt_score", device),
+                                             T(f, "genome_of", device).long())
+    n = int(f["num_nodes"])
+    o1 = np.argsort(N(s) * n + N(d), kind="stable")
+    o2 = np.argsort(f["nrm_src"] * n + f["nrm_dst"], kind="stable")
+    assert np.array_equal(N(s)[o1], f["nrm_src"][o2]) and np.array_equal(N(d)[o1], f["nrm_dst"][o2])
+    got, want = N(w)[o1], f["nrm_weight"][o2]
+    assert got.dtype == np.float64
+    # float64.  CPU: the same libm, identical up to summation order.  Device: exp / log of the GPU math library are a
+    # few ulp from libm, and q = -10 log10(1 - p) amplifies a relative error d of p by p / (1 - p) <= 1e8 (the clip at
+    # epsilon = 1e-8): |dq| <= 4.35 * 1e8 * d ~ 1e-7 for d ~ 2 ulp.  The fp32 weights the graph carries have an ulp
+    # of 7.6e-6 at 81, so they still come out identical (test above).
+    tol = 1e-13 if device == "cpu" else 5e-7
+    assert np.allclose(got, want, rtol=tol, atol=tol)
 
 
 def _groups_from_pairs(f):
@@ -42,20 +89,23 @@ def _groups_from_pairs(f):
     return torch.from_numpy(gid.astype(np.int64)), torch.from_numpy(genes.astype(np.int64))
 
 
+@pytest.mark.parametrize("device", DEVICES)
 @pytest.mark.parametrize("name,subset", [("sim_200x4", False), ("cfg1_2genomes", True), ("cfg3_5genomes", True),
                                          ("cfg2_sim_1000x5", False)])
-def test_subgraphs_equal_the_reference_sets(name, subset):
+def test_subgraphs_equal_the_reference_sets(name, subset, device):
     """node set, similarity edges (+ weight, label) and neighbour edges of every reference sub-graph, in
     GLOBAL ids (the reference's local numbering is CPython set order)"""
     f = load_golden(name)
     n = int(f["num_nodes"])
     gid, mem = _groups_from_pairs(f)
-    ds = subgraphs.build_subgraphs(n, T(f, "nrm_src"), T(f, "nrm_dst"), T(f, "nrm_weight"), gid, mem, neighbours=1,
-                                   pair_src=T(f, "grp_src"), pair_dst=T(f, "grp_dst"),
+    ds = subgraphs.build_subgraphs(n, T(f, "nrm_src", device), T(f, "nrm_dst", device), T(f, "nrm_weight", device),
+                                   gid.to(device), mem.to(device), neighbours=1,
+                                   pair_src=T(f, "grp_src", device), pair_dst=T(f, "grp_dst", device),
                                    require_edges_ge_members=subset)
+    assert ds.node_global.device.type == device
     mine = {}          # node set -> candidate sub-graphs (two groups can span the same node set)
     for i in range(len(ds)):
-        nodes = ds.node_global[int(ds.node_off[i]):int(ds.node_off[i + 1])].numpy()
+        nodes = N(ds.node_global[int(ds.node_off[i]):int(ds.node_off[i + 1])])
         mine.setdefault(tuple(sorted(nodes.tolist())), []).append(i)
     no, eo, bo = f["sub_node_off"], f["sub_edge_off"], f["sub_nb_off"]
     total = int(f["n_train"]) + int(f["n_val"])
@@ -72,26 +122,28 @@ def test_subgraphs_equal_the_reference_sets(name, subset):
         match = None
         for i in mine[key]:            # same node set: the neighbour edges tell the groups apart
             b = ds.graph(i)
-            mg = ds.node_global[int(ds.node_off[i]):int(ds.node_off[i + 1])].numpy()
-            my_nb = mg[b.neighbour_edge_index.numpy()]
+            mg = N(ds.node_global[int(ds.node_off[i]):int(ds.node_off[i + 1])])
+            my_nb = mg[N(b.neighbour_edge_index)]
             if my_nb.shape == ref_nb.shape and set(map(tuple, my_nb.T.tolist())) == ref_nb_set:
                 match = i
                 break
         assert match is not None, f"no sub-graph with the neighbour edges of reference sub-graph {k}"
         mine[key].remove(match)        # one-to-one
         ref_e = glob[f["sub_edge_index"][:, eo[k]:eo[k + 1]]]
-        my_e = mg[b.edge_index.numpy()]
+        my_e = mg[N(b.edge_index)]
         ro, mo = np.lexsort((ref_e[1], ref_e[0])), np.lexsort((my_e[1], my_e[0]))
         assert np.array_equal(ref_e[:, ro], my_e[:, mo])
-        assert np.array_equal(f["sub_edge_attr"][eo[k]:eo[k + 1]][ro], b.edge_attr.numpy()[mo])
-        assert np.array_equal(f["sub_y"][eo[k]:eo[k + 1]][ro], b.y.numpy()[mo])
+        assert np.array_equal(f["sub_edge_attr"][eo[k]:eo[k + 1]][ro], N(b.edge_attr)[mo])
+        assert np.array_equal(f["sub_y"][eo[k]:eo[k + 1]][ro], N(b.y)[mo])
 
 
-def test_subgraph_batches_are_disjoint_unions():
+@pytest.mark.parametrize("device", DEVICES)
+def test_subgraph_batches_are_disjoint_unions(device):
     f = load_golden("cfg1_2genomes")
     gid, mem = _groups_from_pairs(f)
-    ds = subgraphs.build_subgraphs(int(f["num_nodes"]), T(f, "nrm_src"), T(f, "nrm_dst"), T(f, "nrm_weight"), gid,
-                                   mem, pair_src=T(f, "grp_src"), pair_dst=T(f, "grp_dst"),
+    ds = subgraphs.build_subgraphs(int(f["num_nodes"]), T(f, "nrm_src", device), T(f, "nrm_dst", device),
+                                   T(f, "nrm_weight", device), gid.to(device), mem.to(device),
+                                   pair_src=T(f, "grp_src", device), pair_dst=T(f, "grp_dst", device),
                                    require_edges_ge_members=True)
     b = ds.batch(3, 35)
     assert b.num_graphs == 32 and b.x.shape[0] == int(b.ptr[-1])
@@ -107,17 +159,19 @@ def test_subgraph_batches_are_disjoint_unions():
 
 
 # ---------------------------------------------------------------- simulator: distributional parity
-def test_simulator_matches_reference_statistics():
+@pytest.mark.parametrize("device", DEVICES)
+def test_simulator_matches_reference_statistics(device):
     """the reference never seeds its RNG, so compare laws, not samples (cfg 2: 1000 x 5, frac 0.3)"""
     f = load_golden("cfg2_sim_1000x5")
-    g = simulate.simulate_graph(1000, 5, 0.3, 10, 2, seed=3)
+    g = simulate.simulate_graph(1000, 5, 0.3, 10, 2, seed=3, device=device)
+    assert g.edge_index.device.type == device
     assert g.num_nodes == 5000 and g.neighbour_edge_index.shape[1] == 14998
     e_ref = f["whole_edge_index"].shape[1]
     assert abs(g.edge_index.shape[1] - e_ref) / e_ref < 0.05
     assert abs(float(g.y.mean()) - float(f["whole_y"].mean())) < 0.01
     assert abs(float(g.edge_attr.mean()) - float(f["whole_edge_attr"].mean())) / float(f["whole_edge_attr"].mean()) < 0.05
     assert float(g.edge_attr.min()) >= 1.0 and float(g.edge_attr.max()) <= 81.0001
-    deg = torch.bincount(g.edge_index[1], minlength=5000).float()
+    deg = torch.bincount(g.edge_index[1], minlength=5000).float().cpu()
     dref = np.bincount(f["whole_edge_index"][1], minlength=5000)
     assert abs(float(deg.median()) - np.median(dref)) <= 1
     assert 0.6 < float(deg.quantile(0.99)) / np.quantile(dref, 0.99) < 1.6
@@ -126,16 +180,17 @@ def test_simulator_matches_reference_statistics():
     s, d = g.edge_index
     assert not bool((s == d).any())
     assert int(((s // 1000) - (d // 1000)).abs().max()) == 1
-    raw = simulate.simulate_raw(1000, 5, 0.3, 10, 2, seed=3)
+    raw = simulate.simulate_raw(1000, 5, 0.3, 10, 2, seed=3, device=device)
     fwd = torch.stack([raw.src * 5000 + raw.dst, raw.score.long()], 1)
     bwd = torch.stack([raw.dst * 5000 + raw.src, raw.score.long()], 1)
     assert torch.equal(fwd[torch.argsort(fwd[:, 0])], bwd[torch.argsort(bwd[:, 0])])
     assert torch.unique(fwd[:, 0]).numel() == fwd.shape[0]             # a dict: one score per ordered pair
 
 
-def test_simulator_is_seeded():
-    a = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=7)
-    b = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=7)
-    c = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=8)
+@pytest.mark.parametrize("device", DEVICES)
+def test_simulator_is_seeded(device):
+    a = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=7, device=device)
+    b = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=7, device=device)
+    c = simulate.simulate_graph(300, 4, 0.3, 10, 2, seed=8, device=device)
     assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.edge_attr, b.edge_attr)
     assert a.edge_index.shape != c.edge_index.shape or not torch.equal(a.edge_index, c.edge_index)

@@ -53,6 +53,13 @@ class TorchOps:
             h = h + extra.view(-1, 1) * cvec
         return torch.relu(torch.relu(h) @ w2.t() + b2) @ w3 + b3
 
+    def linear(self, x, w, b, in_act=0):
+        return torch.nn.functional.linear(torch.nn.functional.elu(x) if in_act else x, w, b)
+
+    def bce_sum_over(self, logits, labels, pos_weight, denom):
+        return torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, pos_weight=pos_weight,
+                                                                    reduction="sum") / denom
+
 
 def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
     sys.path.insert(0, ROOT)

@@ -187,14 +187,34 @@ def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
     lr.backward()
     lo.backward()
     po = dict(oracle.named_parameters())
+    # fp64 evaluation of the same oracle (referee for the gradient comparison below)
+    import copy
+    o64 = copy.deepcopy(oracle).double()
+    o64.zero_grad()
+    g64_ = copy.copy(g)
+    g64_.x = g.x.double() if g.x.is_floating_point() else g.x
+    g64_.edge_attr = g.edge_attr.double()
+    torch.nn.functional.binary_cross_entropy_with_logits(o64(g64_), g.y.double(), pos_weight=pw.double()).backward()
+    p64 = dict(o64.named_parameters())
     for k, p in model.named_parameters():
         if po[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        # parameter gradients are fp32 sums over up to E edge terms taken in a different
-        # association order than the oracle's: bound the error by 1e-3 of the tensor's scale
+        # parameter gradients are fp32 sums over up to E edge terms taken in a different association order than the
+        # oracle's.  Two fp32 evaluations cannot be held to 1e-4 of the tensor's scale against EACH OTHER: the fp32
+        # oracle itself is up to 8e-4 away from an fp64 evaluation on these graphs (cfg3 union weights; 1.8e-4 on
+        # cfg2 default) — activation-boundary flips and cancellation.  So (i) the direct bound stays at 1e-3, and
+        # (ii) both are adjudicated against the fp64 oracle: where no activation flips, the HIP gradient is as close
+        # to fp64 as the fp32 oracle is (x4 for the different association order, + 2e-5 of the scale); a flip on
+        # either side moves a gradient by up to ~5e-4 of its scale (seen on the oracle: 8e-4, on the HIP side: 1e-4
+        # for embedding.weight of sim_200x4 with skip connections, where fma(w, c, p + q) and (p + q) + w c round
+        # differently), so that is the floor of the bound.
         scale = float(po[k].grad.abs().max()) + 1e-12
         assert close(p.grad, po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), k
+        g64 = p64[k].grad
+        e_hip = float((p.grad.detach().cpu().double() - g64).abs().max()) / scale
+        e_o32 = float((po[k].grad.double() - g64).abs().max()) / scale
+        assert e_hip <= max(4.0 * e_o32 + 2e-5, 5e-4), (k, e_hip, e_o32)
 
 
 @pytest.mark.parametrize("skip", [False, True])
@@ -972,3 +992,29 @@ def test_gcnconv_under_bf16_autocast_propagates_bf16_rows():
     assert float((out.cpu() - ref).abs().max()) < 3e-2 * scale            # bf16 resolution vs the autocast oracle
     assert float((out.cpu() - exact).abs().max()) < 1e-2 * scale          # only the stored rows are rounded
     assert float((out.cpu() - exact).abs().max()) > 1e-6 * scale          # ... and they are
+
+
+def test_gcn_norm_cache_survives_address_reuse():
+    """The per-structure norm cache is keyed on the weight tensor's address / version / shape.  A weight tensor
+    that is freed and whose address the caching allocator hands to a NEW same-shape tensor must not return the old
+    normalisation (round-1 ADVICE: the cache entry now keeps the keyed tensor alive)."""
+    from pangnn_amd.graph import EdgeStructure
+    n, e = 300, 5000
+    ei, w = random_graph(n, e, seed=5)
+    st = EdgeStructure(ei.to(dev()), n)
+    seen = set()
+    for k in range(6):
+        wk = (w * (k + 1)).to(dev())                 # fresh tensor each round; the previous one is dropped
+        seen.add(wk.data_ptr())
+        got = st.gcn_norm(wk).orig.cpu()
+        want = go.gcn_norm(ei, w * (k + 1), n)
+        assert close(got, want, atol=1e-6, rtol=1e-5), k
+        del wk
+    # and through the identity-keyed structure cache with a non-contiguous edge_index
+    from pangnn_amd.graph import structure_of, clear_cache
+    clear_cache()
+    big = torch.stack([ei[0], ei[0], ei[1]]).to(dev())
+    view = big[::2]                                  # rows 0 and 2: non-contiguous [2, E]
+    st2 = structure_of(view, n)
+    assert torch.equal(st2.edge_index.cpu(), ei)
+    clear_cache()
