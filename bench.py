@@ -167,35 +167,54 @@ def main():
         genes = args.genes
     if args.workload == "cfg2mb":
         return minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd)
-    t_gen = time.perf_counter()
-    g = simulate.simulate_graph(genes, G, frac, frags, shuf, seed=args.seed, device=dev)
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
-    n, e_sim, e_nb = g.num_nodes, g.edge_index.shape[1], g.neighbour_edge_index.shape[1]
-
-    torch.manual_seed(0)
     force_dist = os.environ.get("PANGNN_FORCE_DIST") == "1"      # exercise the partitioned path at world = 1
     if force_dist and world == 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    if world > 1 or force_dist:
+    partitioned = world > 1 or force_dist
+    replicated = os.environ.get("PANGNN_BENCH_REPLICATED") == "1"    # round-1 way: every rank builds the whole graph
+    t_gen = time.perf_counter()
+    g = None
+    if partitioned and not replicated:
+        # rank-local generation: a rank draws only the genome pairs around its node range (simulate.simulate_shard,
+        # bit-identical to partitioning the whole graph: tests/test_construct.py) — what lets config 5 exist at all
+        part = simulate.simulate_shard(genes, G, frac, frags, shuf, seed=args.seed, device=dev, rank=rank, world=world)
+        cnt = torch.tensor([part.e_sim_local, part.n_pos_local, part.neighbour_edge_index.shape[1]], dtype=torch.int64,
+                           device=dev)
+        if world > 1:
+            all_reduce_(cnt, torch.distributed.ReduceOp.SUM)
+        e_sim, n_pos, e_nb = (int(v) for v in cnt.tolist())
+        part.e_sim_total = e_sim
+        n = part.n_global
+        class_balance = torch.tensor((e_sim - n_pos) / max(n_pos, 1), dtype=torch.float32, device=dev)   # dataset.py:346
+    else:
+        g = simulate.simulate_graph(genes, G, frac, frags, shuf, seed=args.seed, device=dev)
+        n, e_sim, e_nb = g.num_nodes, g.edge_index.shape[1], g.neighbour_edge_index.shape[1]
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+
+    torch.manual_seed(0)
+    if partitioned:
         from pangnn_amd import dist as pdist
-        # every rank generated the graph itself from the same seed: verify they agree before slicing it
-        chk = torch.stack([g.edge_index.sum(), g.edge_index[0].max(), torch.tensor(e_sim, device=dev),
-                           (g.edge_attr.double().sum() * 1e3).long()]).long()
-        lo_, hi_ = chk.clone(), chk.clone()
-        all_reduce_(lo_, torch.distributed.ReduceOp.MIN)
-        all_reduce_(hi_, torch.distributed.ReduceOp.MAX)
-        if not torch.equal(lo_, hi_):
-            raise RuntimeError("ranks generated different graphs from the same seed")
-        part = pdist.partition_graph(g, rank, world)
+        if g is not None:
+            # every rank generated the graph itself from the same seed: verify they agree before slicing it
+            chk = torch.stack([g.edge_index.sum(), g.edge_index[0].max(), torch.tensor(e_sim, device=dev),
+                               (g.edge_attr.double().sum() * 1e3).long()]).long()
+            lo_, hi_ = chk.clone(), chk.clone()
+            if world > 1:
+                all_reduce_(lo_, torch.distributed.ReduceOp.MIN)
+                all_reduce_(hi_, torch.distributed.ReduceOp.MAX)
+            if not torch.equal(lo_, hi_):
+                raise RuntimeError("ranks generated different graphs from the same seed")
+            part = pdist.partition_graph(g, rank, world)
+            class_balance = g.class_balance
+            del g
         model = pdist.DistAlternateGCN(dev, dims=[d, h], part=part)
         graph, labels = part, part.y
-        pos_weight = g.class_balance
+        pos_weight = class_balance
         step_fn = lambda: pdist.train_step(model, opt, graph, labels, pos_weight)   # noqa: E731
-        del g
     else:
         model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h],
                                         fold_activation=os.environ.get("PANGNN_FOLD_ACT", "1") == "1")   # A/B switch
@@ -291,7 +310,7 @@ def main():
             "config": {"workload": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf}, whole graph as one batch, "
                                    f"node_dim={d} hidden_dim={h}, AlternateGCN default topology, mlp decoder",
                        "nodes": n, "sim_edges": e_sim, "neighbour_edges": e_nb,
-                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, halo rows by all-to-all-v (conv_in needs no exchange)",
+                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, rank-local generation, halo rows by all-to-all-v (conv_in needs no exchange)",
                        "arithmetic": "fp32 storage and accumulation everywhere; the three per-edge decoder products run on the bf16 "
                                      "matrix pipe with fp32-exact operand handling (W2 h1: both operands split into three bf16 terms, "
                                      "six partial products; dL/dh1 and dL/dW2: the relu mask is the exact bf16 operand, the other "

@@ -1,0 +1,190 @@
+// torch dispatcher registration of the hot-path operators: TORCH_LIBRARY(pangnn, ...) schemas with
+// HIP ("CUDA" dispatch key on ROCm builds of torch) implementations that call the C ABI of libpangnn_hip.so on
+// torch's current stream.  No arithmetic lives here: each implementation checks its operands (TORCH_CHECK ->
+// Python RuntimeError), allocates the outputs with at::empty on the input's device and forwards raw pointers.
+// Autograd formulas, fake (meta) kernels and the autocast policy are registered on these ops from Python
+// (pangnn_amd/torch_ops.py: torch.library.register_autograd / register_fake), so `accelerate`'s autocast and
+// torch.compile see ordinary dispatcher ops.  Built by csrc/Makefile into pangnn_amd/libpangnn_torch.so (g++ against
+// the torch headers; contains no device code).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "../../include/pangnn_hip.h"
+
+namespace {
+
+void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_rc(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (rc=", rc, "): ", pangnn_last_error()); }
+
+const at::Tensor& on_gpu(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), "pangnn: ", name, " must be a GPU tensor (there is no CPU path), got ", t.device());
+  return t;
+}
+
+template <typename T>
+const T* opt_ptr(const c10::optional<at::Tensor>& t) {
+  return (t.has_value() && t->defined()) ? t->data_ptr<T>() : nullptr;
+}
+
+// csr_from_coo(edge_index i64[2,E], num_nodes, group_by) -> (rowptr i64[N+1], other i32[E], perm i32[E])
+std::tuple<at::Tensor, at::Tensor, at::Tensor> csr_from_coo(const at::Tensor& edge_index, int64_t num_nodes,
+                                                           int64_t group_by) {
+  on_gpu(edge_index, "edge_index");
+  TORCH_CHECK(edge_index.scalar_type() == at::kLong && edge_index.dim() == 2 && edge_index.size(0) == 2,
+              "pangnn::csr_from_coo: edge_index must be int64 [2, E]");
+  const at::Tensor ei = edge_index.contiguous();
+  const int64_t e = ei.size(1);
+  auto rowptr = at::empty({num_nodes + 1}, ei.options());
+  auto other = at::empty({e}, ei.options().dtype(at::kInt));
+  auto perm = at::empty({e}, ei.options().dtype(at::kInt));
+  const size_t wsb = pangnn_csr_build_workspace_bytes(e, num_nodes);
+  TORCH_CHECK(wsb > 0, "pangnn::csr_from_coo: workspace query failed: ", pangnn_last_error());
+  auto ws = at::empty({(int64_t)wsb}, ei.options().dtype(at::kByte));
+  check_rc(pangnn_csr_build(ei.data_ptr<int64_t>(), e, e, num_nodes, (int)group_by, rowptr.data_ptr<int64_t>(),
+                            other.data_ptr<int32_t>(), perm.data_ptr<int32_t>(), ws.data_ptr(), wsb, stream_of(ei)),
+           "pangnn_csr_build");
+  return {rowptr, other, perm};
+}
+
+// gcn_norm(rowptr, other, perm, w?) -> (deg^-1/2 [N], norm in CSR order [E], norm in the caller's edge order [E])
+std::tuple<at::Tensor, at::Tensor, at::Tensor> gcn_norm(const at::Tensor& rowptr, const at::Tensor& other,
+                                                       const at::Tensor& perm, const c10::optional<at::Tensor>& w) {
+  on_gpu(rowptr, "rowptr");
+  const int64_t n = rowptr.size(0) - 1, e = other.size(0);
+  c10::optional<at::Tensor> wc;
+  if (w.has_value() && w->defined()) {
+    TORCH_CHECK(w->dim() == 1 && w->size(0) >= e, "pangnn::gcn_norm: edge_weight must be [E]");
+    wc = w->to(at::kFloat).contiguous();
+  }
+  auto dis = at::empty({n}, rowptr.options().dtype(at::kFloat));
+  auto ns = at::empty({e}, dis.options());
+  auto no = at::empty({e}, dis.options());
+  check_rc(pangnn_gcn_norm_f32(rowptr.data_ptr<int64_t>(), other.data_ptr<int32_t>(), perm.data_ptr<int32_t>(),
+                               opt_ptr<float>(wc), n, e, dis.data_ptr<float>(), ns.data_ptr<float>(),
+                               no.data_ptr<float>(), stream_of(rowptr)),
+           "pangnn_gcn_norm_f32");
+  return {dis, ns, no};
+}
+
+// spmm(rowptr, other, val?, x f32|bf16 [n_src, F], bias?, n_rows) -> f32 [n_rows, F]
+//   out[r] = bias + sum_{k in row r} val[k] x[other[k]]      forward propagate (by-target CSR) and, with the by-source
+//   CSR, its transpose (spmm_bwd of SURVEY.md §8b is this op on the other CSR)
+at::Tensor spmm(const at::Tensor& rowptr, const at::Tensor& other, const c10::optional<at::Tensor>& val,
+                const at::Tensor& x, const c10::optional<at::Tensor>& bias, int64_t n_rows) {
+  on_gpu(x, "x");
+  TORCH_CHECK(x.dim() == 2, "pangnn::spmm: x must be [n_src, F]");
+  TORCH_CHECK(rowptr.size(0) >= n_rows + 1, "pangnn::spmm: rowptr shorter than n_rows + 1");
+  const int64_t f = x.size(1);
+  const bool bf16 = x.scalar_type() == at::kBFloat16 && (f == 32 || f == 64 || f == 128 || f == 256);
+  at::Tensor xc = bf16 ? x.contiguous() : x.to(at::kFloat).contiguous();
+  c10::optional<at::Tensor> vc, bc;
+  if (val.has_value() && val->defined()) vc = val->to(at::kFloat).contiguous();
+  if (bias.has_value() && bias->defined()) bc = bias->to(at::kFloat).contiguous();
+  auto out = at::empty({n_rows, f}, x.options().dtype(at::kFloat));
+  const int rc = bf16 ? pangnn_spmm_csr_bf16(rowptr.data_ptr<int64_t>(), other.data_ptr<int32_t>(), opt_ptr<float>(vc),
+                                             xc.data_ptr(), xc.stride(0), xc.size(0), opt_ptr<float>(bc),
+                                             out.data_ptr<float>(), out.stride(0), n_rows, other.size(0), (int32_t)f, 0,
+                                             stream_of(x))
+                      : pangnn_spmm_csr_f32(rowptr.data_ptr<int64_t>(), other.data_ptr<int32_t>(), opt_ptr<float>(vc),
+                                            xc.data_ptr<float>(), xc.stride(0), xc.size(0), opt_ptr<float>(bc),
+                                            out.data_ptr<float>(), out.stride(0), n_rows, other.size(0), (int32_t)f, 0,
+                                            stream_of(x));
+  check_rc(rc, "pangnn_spmm_csr");
+  return out;
+}
+
+// propagate(rowptr, other, val, rowptr_t, other_t, val_t, x, bias?) -> f32 [N, F]: GCNConv's message passing
+// (PyG MessagePassing.propagate + GCNConv.message, gnn.py:158,165 call sites).  Forward = spmm over the by-target
+// CSR; the by-source CSR (rowptr_t, other_t, val_t) rides along for the autograd formula registered from Python
+// (dL/dx = spmm over it; the normalised weights are not differentiated: SURVEY.md §8 a6).
+at::Tensor propagate(const at::Tensor& rowptr, const at::Tensor& other, const at::Tensor& val, const at::Tensor& rowptr_t,
+                     const at::Tensor& other_t, const at::Tensor& val_t, const at::Tensor& x,
+                     const c10::optional<at::Tensor>& bias) {
+  (void)rowptr_t; (void)other_t; (void)val_t;
+  return spmm(rowptr, other, val, x, bias, rowptr.size(0) - 1);
+}
+
+// edge_gather_concat(z f32[N,D], edge_index i64[2,E], extra f32[E]?) -> f32 [E, 2D (+1)]   (src/gnn.py:173-175)
+at::Tensor edge_gather_concat(const at::Tensor& z, const at::Tensor& edge_index, const c10::optional<at::Tensor>& extra) {
+  on_gpu(z, "z");
+  on_gpu(edge_index, "edge_index");
+  TORCH_CHECK(z.dim() == 2 && edge_index.dim() == 2 && edge_index.size(0) == 2 && edge_index.scalar_type() == at::kLong,
+              "pangnn::edge_gather_concat: z [N, D], edge_index int64 [2, E]");
+  const at::Tensor zc = z.to(at::kFloat).contiguous(), ei = edge_index.contiguous();
+  c10::optional<at::Tensor> ex;
+  if (extra.has_value() && extra->defined()) ex = extra->to(at::kFloat).contiguous();
+  const int64_t e = ei.size(1), d = zc.size(1);
+  auto out = at::empty({e, 2 * d + (ex.has_value() ? 1 : 0)}, zc.options());
+  check_rc(pangnn_edge_gather_concat_f32(zc.data_ptr<float>(), zc.stride(0), zc.size(0), ei.data_ptr<int64_t>(), e, 0, e,
+                                         opt_ptr<float>(ex), out.data_ptr<float>(), out.stride(0), (int32_t)d,
+                                         stream_of(z)),
+           "pangnn_edge_gather_concat_f32");
+  return out;
+}
+
+// segment_sum_rows(rowptr, perm, m f32[E, W], col_off, f, n_rows) -> f32 [n_rows, f]: out[r] = sum_{k in row r} m[perm[k], col_off : col_off + f]
+at::Tensor segment_sum_rows(const at::Tensor& rowptr, const at::Tensor& perm, const at::Tensor& m, int64_t col_off,
+                            int64_t f, int64_t n_rows) {
+  on_gpu(m, "m");
+  TORCH_CHECK(m.dim() == 2 && col_off >= 0 && col_off + f <= m.size(1), "pangnn::segment_sum_rows: bad column window");
+  const at::Tensor mc = m.to(at::kFloat).contiguous();
+  auto out = at::empty({n_rows, f}, mc.options());
+  check_rc(pangnn_segment_sum_rows_f32(rowptr.data_ptr<int64_t>(), perm.data_ptr<int32_t>(), mc.data_ptr<float>(),
+                                       mc.stride(0), mc.size(0), col_off, out.data_ptr<float>(), out.stride(0), n_rows,
+                                       (int32_t)f, 0, stream_of(m)),
+           "pangnn_segment_sum_rows_f32");
+  return out;
+}
+
+// segment_max_rows(rowptr, perm, m f32[E, F], n_rows) -> (f32 [n_rows, F], arg i32 [n_rows, F])   aggr = 'max' (convolution.py:7)
+std::tuple<at::Tensor, at::Tensor> segment_max_rows(const at::Tensor& rowptr, const at::Tensor& perm, const at::Tensor& m,
+                                                    int64_t n_rows) {
+  on_gpu(m, "m");
+  const at::Tensor mc = m.to(at::kFloat).contiguous();
+  auto out = at::empty({n_rows, mc.size(1)}, mc.options());
+  auto arg = at::empty({n_rows, mc.size(1)}, mc.options().dtype(at::kInt));
+  check_rc(pangnn_segment_max_rows_f32(rowptr.data_ptr<int64_t>(), perm.data_ptr<int32_t>(), mc.data_ptr<float>(),
+                                       mc.stride(0), out.data_ptr<float>(), arg.data_ptr<int32_t>(), out.stride(0), n_rows,
+                                       (int32_t)mc.size(1), stream_of(m)),
+           "pangnn_segment_max_rows_f32");
+  return {out, arg};
+}
+
+// segment_max_bwd(g f32[n_rows, F], arg i32[n_rows, F], rowptr, num_edges) -> f32 [E, F]
+at::Tensor segment_max_bwd(const at::Tensor& g, const at::Tensor& arg, const at::Tensor& rowptr, int64_t num_edges) {
+  on_gpu(g, "g");
+  const at::Tensor gc = g.to(at::kFloat).contiguous();
+  auto gm = at::zeros({num_edges, gc.size(1)}, gc.options());
+  check_rc(pangnn_segment_max_bwd_f32(gc.data_ptr<float>(), arg.data_ptr<int32_t>(), rowptr.data_ptr<int64_t>(),
+                                      gm.data_ptr<float>(), gm.stride(0), gc.stride(0), gc.size(0), (int32_t)gc.size(1),
+                                      stream_of(g)),
+           "pangnn_segment_max_bwd_f32");
+  return gm;
+}
+
+}  // namespace
+
+TORCH_LIBRARY(pangnn, m) {
+  m.def("csr_from_coo(Tensor edge_index, int num_nodes, int group_by) -> (Tensor, Tensor, Tensor)");
+  m.def("gcn_norm(Tensor rowptr, Tensor other, Tensor perm, Tensor? edge_weight) -> (Tensor, Tensor, Tensor)");
+  m.def("spmm(Tensor rowptr, Tensor other, Tensor? val, Tensor x, Tensor? bias, int n_rows) -> Tensor");
+  m.def("propagate(Tensor rowptr, Tensor other, Tensor val, Tensor rowptr_t, Tensor other_t, Tensor val_t, Tensor x, "
+        "Tensor? bias) -> Tensor");
+  m.def("edge_gather_concat(Tensor z, Tensor edge_index, Tensor? extra) -> Tensor");
+  m.def("segment_sum_rows(Tensor rowptr, Tensor perm, Tensor m, int col_off, int f, int n_rows) -> Tensor");
+  m.def("segment_max_rows(Tensor rowptr, Tensor perm, Tensor m, int n_rows) -> (Tensor, Tensor)");
+  m.def("segment_max_bwd(Tensor g, Tensor arg, Tensor rowptr, int num_edges) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(pangnn, CUDA, m) {       // "CUDA" is the dispatch key of HIP tensors on ROCm builds of torch
+  m.impl("csr_from_coo", &csr_from_coo);
+  m.impl("gcn_norm", &gcn_norm);
+  m.impl("spmm", &spmm);
+  m.impl("propagate", &propagate);
+  m.impl("edge_gather_concat", &edge_gather_concat);
+  m.impl("segment_sum_rows", &segment_sum_rows);
+  m.impl("segment_max_rows", &segment_max_rows);
+  m.impl("segment_max_bwd", &segment_max_bwd);
+}

@@ -178,6 +178,8 @@ class HaloGather(torch.autograd.Function):
     def forward(ctx, x, plan: HaloPlan, accumulate_back):
         ctx.plan, ctx.acc = plan, accumulate_back
         x = x.contiguous()
+        if plan.n_halo == 0 and plan.send_idx.numel() == 0:
+            return x.view_as(x)                                 # nothing to exchange (one rank): the table IS the block
         send = x.index_select(0, plan.send_idx)
         recv = torch.empty((plan.n_halo,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         _all_to_all_v(recv, send, plan.recv_splits, plan.send_splits, plan.group)
@@ -187,6 +189,8 @@ class HaloGather(torch.autograd.Function):
     def backward(ctx, g):
         plan = ctx.plan
         g = g.contiguous()
+        if plan.n_halo == 0 and plan.send_idx.numel() == 0:
+            return g, None, None
         g_halo = torch.cat([g[: plan.n_low], g[plan.n_low + plan.n_local:]], dim=0)
         back = torch.empty((plan.send_idx.numel(),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
         _all_to_all_v(back, g_halo, plan.send_splits, plan.recv_splits, plan.group)

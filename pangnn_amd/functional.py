@@ -121,7 +121,17 @@ class _Propagate(torch.autograd.Function):
         return gx, gb, None, None, None
 
 
+# PANGNN_DISPATCHER_OPS=1: the propagate goes through the registered dispatcher op torch.ops.pangnn.propagate
+# (csrc/torch_ops.cpp + torch_ops.py: autograd, fake kernel, autocast policy) instead of the ctypes autograd.Function —
+# same kernels, bit-identical results; what torch.compile / accelerate's autocast need to see the operator.
+USE_DISPATCHER_OPS = os.environ.get("PANGNN_DISPATCHER_OPS", "0") == "1"
+
+
 def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
+    if USE_DISPATCHER_OPS and st.num_src == st.num_nodes and (KERNEL_TIMER is None or tag is None):
+        from . import torch_ops
+        _lib.require_device(x, bias)
+        return torch_ops.propagate(x, bias, st, norm)
     return _Propagate.apply(x, bias, st, norm, tag)
 
 

@@ -74,14 +74,25 @@ def _distinct_positions(k: torch.Tensor, n: int, gen, device):
     return owner, pos
 
 
-def _synteny_order(n: int, genomes: int, frag_size: int, n_shuffle: int, gen):
-    """new position of every gene after shuffle_synteny_blocks; returns pos_of[g, p] -> slot."""
+def _mix(seed: int, *parts: int) -> int:
+    """counter-based seed of one piece of the data set (a genome, a genome pair): any rank can draw any piece"""
+    h = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+    for p_ in parts:
+        h ^= (int(p_) + 0x9E3779B97F4A7C15 + ((h << 6) & 0xFFFFFFFFFFFFFFFF) + (h >> 2)) & 0xFFFFFFFFFFFFFFFF
+        h = (h * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    return h & 0x7FFFFFFFFFFFFFFF
+
+
+def _synteny_order(n: int, genomes: int, frag_size: int, n_shuffle: int, seed: int):
+    """new position of every gene after shuffle_synteny_blocks; returns pos_of[g, p] -> slot.  One generator per
+    genome (seeded by (seed, genome)): the order of a genome does not depend on which other genomes are drawn."""
     out = torch.empty(genomes, n, dtype=torch.int64)
     base = torch.arange(n)
     for g in range(genomes):
         if n_shuffle <= 1 or frag_size <= 0:
             out[g] = base
             continue
+        gen = torch.Generator().manual_seed(_mix(seed, 1, g))
         blocks = list(torch.split(base, frag_size))
         chosen = torch.randperm(len(blocks), generator=gen)[:n_shuffle].tolist()
         perm = torch.randperm(len(chosen), generator=gen).tolist()
@@ -95,55 +106,107 @@ def _synteny_order(n: int, genomes: int, frag_size: int, n_shuffle: int, gen):
     return out
 
 
-def simulate_raw(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
-                 means=(200, 500), seed: int = 0, device="cpu"):
-    """raw similarity relation (before remove_trivial_cases) + node metadata."""
-    device = torch.device(device)
-    gen = torch.Generator(device=device).manual_seed(seed)
-    cgen = torch.Generator().manual_seed(seed + 1)
-    G, N = int(genomes), int(n) * int(genomes)
+def _mean_negatives(n: int, G: int, frac_pos: float) -> int:
+    num_pos = G * (G - 1) // 2 * n
+    return math.floor((math.floor(num_pos / frac_pos) - num_pos) / (n * G))      # simulate.py:128
+
+
+def _adjacent_block(b: int, n: int, node, m: int, means, seed: int, device):
+    """everything the relation holds between genome b and genome b + 1: the ortholog pair of every position and the
+    negatives genome b draws in genome b + 1 (both directions; simulate.py:156-190).  Drawn from its own generator
+    (seed, b), so a rank that owns genomes around b produces exactly what a whole-graph run produces for them."""
     neg_mean, pos_mean = means
-    pairs_per_group = G * (G - 1) // 2
-    num_pos = pairs_per_group * n
-    num_total = math.floor(num_pos / frac_pos)
-    m = math.floor((num_total - num_pos) / N)                    # simulate.py:128
-
-    pos_of = _synteny_order(n, G, math.floor(n / num_fragments), int(n_shuffle), cgen).to(device)
-    node = (torch.arange(G, device=device).view(-1, 1) * n + pos_of)        # node id of gene (g, p)
-
-    # ---- positives: all genome pairs at every position
-    ga, gb = torch.triu_indices(G, G, offset=1, device=device)
+    gen = torch.Generator(device=device).manual_seed(_mix(seed, 2, b))
     p_all = torch.arange(n, device=device)
-    a = node[ga][:, p_all].reshape(-1)                           # [pairs * n]
-    b = node[gb][:, p_all].reshape(-1)
-    ps = _gamma_int(pos_mean, a.numel(), gen, device)
-    adj = (gb - ga == 1)                                         # adjacent pairs can be hit by a negative
-    adj_slot = torch.full((G,), -1, dtype=torch.int64, device=device)
-    adj_slot[ga[adj]] = torch.nonzero(adj).view(-1)
-
-    # ---- negatives: genes of genomes 0..G-2 -> k distinct positions of genome g+1
-    n_src = (G - 1) * n
-    k = _neg_binomial(0.2, float(m), n_src, gen, device).clamp_(1, n) if m > 0 else \
-        torch.ones(n_src, dtype=torch.int64, device=device)
-    owner, q = _distinct_positions(k, n, gen, device)
-    sg, sp = owner // n, owner % n
-    ns = _gamma_int(neg_mean, owner.numel(), gen, device)
-    hit = q == sp                                                # negative lands on the own ortholog
+    a, bb = node[b], node[b + 1]                                   # node ids of position p in the two genomes
+    ps = _gamma_int(pos_mean, n, gen, device)
+    k = _neg_binomial(0.2, float(m), n, gen, device).clamp_(1, n) if m > 0 else \
+        torch.ones(n, dtype=torch.int64, device=device)
+    sp, q = _distinct_positions(k, n, gen, device)                 # source position, target position
+    ns = _gamma_int(neg_mean, sp.numel(), gen, device)
+    hit = q == sp                                                  # negative lands on the own ortholog
     if bool(hit.any()):
-        ps[adj_slot[sg[hit]] * n + sp[hit]] = ns[hit]            # overwrite that pair's score
+        ps[sp[hit]] = ns[hit]                                      # overwrite that pair's score
     keep = ~hit
-    na = node[sg[keep], sp[keep]]
-    nb = node[sg[keep] + 1, q[keep]]
-    nsc = ns[keep]
+    na, nb, nsc = a[sp[keep]], bb[q[keep]], ns[keep]
+    src = torch.cat([a[p_all], bb[p_all], na, nb])
+    dst = torch.cat([bb[p_all], a[p_all], nb, na])
+    return src, dst, torch.cat([ps, ps, nsc, nsc])
 
-    src = torch.cat([a, b, na, nb])
-    dst = torch.cat([b, a, nb, na])
-    score = torch.cat([ps, ps, nsc, nsc])
+
+def simulate_raw(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
+                 means=(200, 500), seed: int = 0, device="cpu", blocks=None):
+    """raw similarity relation (before remove_trivial_cases) + node metadata.
+    `blocks` (list of b): only the adjacent genome pairs (b, b + 1) listed — what survives remove_trivial_cases can
+    only come from those (a gene has exactly one candidate, its ortholog, in every non-adjacent genome), which is
+    what rank-local generation relies on; None = the whole relation, non-adjacent ortholog pairs included."""
+    device = torch.device(device)
+    G, N = int(genomes), int(n) * int(genomes)
+    m = _mean_negatives(n, G, frac_pos)
+    pos_of = _synteny_order(n, G, math.floor(n / num_fragments), int(n_shuffle), seed).to(device)
+    node = (torch.arange(G, device=device).view(-1, 1) * n + pos_of)        # node id of gene (g, p)
+    p_all = torch.arange(n, device=device)
+
+    parts = [_adjacent_block(b, n, node, m, means, seed, device) for b in (range(G - 1) if blocks is None else blocks)]
+    if blocks is None and G > 2:
+        # ortholog pairs of non-adjacent genomes (one generator for all of them)
+        ga, gb = torch.triu_indices(G, G, offset=1, device=device)
+        far = gb - ga > 1
+        ga, gb = ga[far], gb[far]
+        gen = torch.Generator(device=device).manual_seed(_mix(seed, 3))
+        a = node[ga][:, p_all].reshape(-1)
+        b_ = node[gb][:, p_all].reshape(-1)
+        ps = _gamma_int(means[1], a.numel(), gen, device)
+        parts.append((torch.cat([a, b_]), torch.cat([b_, a]), torch.cat([ps, ps])))
+    if parts:
+        src, dst, score = (torch.cat([p_[i] for p_ in parts]) for i in range(3))
+    else:
+        src = dst = torch.zeros(0, dtype=torch.int64, device=device)
+        score = torch.zeros(0, dtype=torch.float64, device=device)
     genome_of = torch.arange(N, device=device) // n
     group_of = torch.empty(N, dtype=torch.int64, device=device)
     group_of[node.reshape(-1)] = p_all.repeat(G)
     return SimpleNamespace(num_nodes=N, src=src, dst=dst, score=score, genome_of=genome_of, group_of=group_of,
                            mean_neg_per_gene=m)
+
+
+def simulate_shard(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
+                   neighbours: int = 1, seed: int = 0, device="cpu", temperature: float = 0.8, rank: int = 0,
+                   world: int = 1):
+    """Rank `rank`'s destination-partitioned shard of the simulated graph WITHOUT building the whole graph: the rank
+    draws only the genome pairs that touch its node range (per-pair generators), normalises them (every
+    (source, candidate genome) group lies inside one pair) and keeps the edges whose target it owns.  Bit-identical to
+    `dist.partition_graph(simulate_graph(...), rank, world)` (tests/test_construct.py).  Global quantities a shard
+    cannot know are left as LOCAL counts for the caller to all-reduce: `n_pos_local`, `e_sim_local`
+    (-> class_balance = (E - P) / P and e_sim_total)."""
+    device = torch.device(device)
+    G, N = int(genomes), int(n) * int(genomes)
+    n_local = (N + world - 1) // world
+    lo, hi = rank * n_local, min((rank + 1) * n_local, N)
+    g_lo, g_hi = lo // n, max(lo, hi - 1) // n
+    blocks = list(range(max(g_lo - 1, 0), min(g_hi, G - 2) + 1)) if hi > lo else []
+    raw = simulate_raw(n, genomes, frac_pos, num_fragments, n_shuffle, seed=seed, device=device, blocks=blocks)
+    s, d, sc = construct.remove_trivial_cases(raw.src, raw.dst, raw.score, raw.genome_of)
+    s, d, w = construct.normalize_sim_scores(s, d, sc, raw.genome_of, t=temperature)
+    own = (d >= lo) & (d < hi) & (s != d)
+    s, d, w = s[own], d[own], w[own]
+    o = construct.canonical_order(s, d, N)
+    s, d, w = s[o], d[o], w[o]
+    gs, gd = raw.group_of[s], raw.group_of[d]
+    y = ((gs == gd) & (gs >= 0)).to(torch.float32)
+    # positional neighbours (i, j), j in [i - k, i + k], of the targets j this rank owns, in whole-graph order
+    k = int(neighbours)
+    i = torch.arange(max(lo - k, 0), min(hi + k, N), dtype=torch.int64, device=device).repeat_interleave(2 * k + 1)
+    j = i + torch.arange(-k, k + 1, dtype=torch.int64, device=device).repeat(i.numel() // (2 * k + 1))
+    keep = (j >= lo) & (j < hi)
+    x = torch.zeros(n_local, 1, dtype=torch.float32, device=device)
+    x[: hi - lo] = 1.0
+    return SimpleNamespace(
+        x=x, edge_index=torch.stack([s, d - lo]).contiguous(), edge_attr=w.to(torch.float32).contiguous(), y=y,
+        neighbour_edge_index=torch.stack([i[keep], j[keep] - lo]).contiguous(),
+        n_local=n_local, n_pad=n_local * world, n_global=N, lo=lo, hi=hi, rank=rank, world=world,
+        e_sim_local=int(s.numel()), n_pos_local=int(y.sum().item()), e_sim_total=None, owned_mask=None,
+        genome_of=raw.genome_of)
 
 
 def simulate_graph(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
