@@ -16,6 +16,7 @@ all-gather / reduce-scatter of node embeddings (pangnn_amd/dist.py).
 One JSON line on rank 0: value = supervised similarity edges per second over the whole job.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -34,7 +35,14 @@ WORKLOADS = {
     # the reference's own regime on config 2: DataLoader(batch_size=32) over per-group sub-graphs
     # (pangnn.py:152-153); a step = one mini-batch; informational, not the headline line
     "cfg2mb": (1000, 5, 0.3, 10, 2, 64, 64),
+    # BASELINE.json config 5: --simulate_dataset 200000 50 0.1 500 50 --skip_connections --categorical_node, bf16 mixed
+    # precision, 8 GPUs (N = 1e7 nodes, 4.3e9 similarity edges: only runs partitioned, --gpus 8)
+    "cfg5": (200000, 50, 0.1, 500, 50, 64, 128),
+    # one GPU's share of config 5 on ONE GPU: 6 of its 50 genomes with config 5's negative-edge law (m = 220 per gene),
+    # same flags and precision — 1.2e6 nodes, ~4.4e8 similarity edges, i.e. what each of the 8 ranks holds
+    "cfg5slice": (200000, 6, 0.1, 500, 50, 64, 128),
 }
+CFG5 = {"cfg5", "cfg5slice"}
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -174,13 +182,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     partitioned = world > 1 or force_dist
+    cfg5 = args.workload in CFG5
+    mean_neg = 220 if args.workload == "cfg5slice" else None       # floor(49 / 2 * 9): config 5's law on a 6-genome slice
+    model_flags = dict(skip_connections=True) if cfg5 else {}
+    amp = torch.autocast("cuda", dtype=torch.bfloat16) if cfg5 else contextlib.nullcontext()
+    if args.workload == "cfg5" and world < 8 and not args.genes:
+        sys.exit("cfg5 (4.3e9 edges) only runs partitioned over 8 GPUs; on one GPU use --workload cfg5slice")
     replicated = os.environ.get("PANGNN_BENCH_REPLICATED") == "1"    # round-1 way: every rank builds the whole graph
     t_gen = time.perf_counter()
     g = None
     if partitioned and not replicated:
         # rank-local generation: a rank draws only the genome pairs around its node range (simulate.simulate_shard,
         # bit-identical to partitioning the whole graph: tests/test_construct.py) — what lets config 5 exist at all
-        part = simulate.simulate_shard(genes, G, frac, frags, shuf, seed=args.seed, device=dev, rank=rank, world=world)
+        part = simulate.simulate_shard(genes, G, frac, frags, shuf, seed=args.seed, device=dev, rank=rank, world=world,
+                                       mean_neg=mean_neg)
         cnt = torch.tensor([part.e_sim_local, part.n_pos_local, part.neighbour_edge_index.shape[1]], dtype=torch.int64,
                            device=dev)
         if world > 1:
@@ -190,7 +205,8 @@ def main():
         n = part.n_global
         class_balance = torch.tensor((e_sim - n_pos) / max(n_pos, 1), dtype=torch.float32, device=dev)   # dataset.py:346
     else:
-        g = simulate.simulate_graph(genes, G, frac, frags, shuf, seed=args.seed, device=dev)
+        g = simulate.simulate_graph(genes, G, frac, frags, shuf, seed=args.seed, device=dev, mean_neg=mean_neg,
+                                    adjacent_only=cfg5)
         n, e_sim, e_nb = g.num_nodes, g.edge_index.shape[1], g.neighbour_edge_index.shape[1]
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
@@ -211,15 +227,24 @@ def main():
             part = pdist.partition_graph(g, rank, world)
             class_balance = g.class_balance
             del g
-        model = pdist.DistAlternateGCN(dev, dims=[d, h], part=part)
+        model = pdist.DistAlternateGCN(dev, dims=[d, h], part=part, categorical_nodes=cfg5, **model_flags)
         graph, labels = part, part.y
         pos_weight = class_balance
-        step_fn = lambda: pdist.train_step(model, opt, graph, labels, pos_weight)   # noqa: E731
+
+        def step_fn():
+            with amp:
+                return pdist.train_step(model, opt, graph, labels, pos_weight)
     else:
-        model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h],
-                                        fold_activation=os.environ.get("PANGNN_FOLD_ACT", "1") == "1")   # A/B switch
+        model = pangnn_amd.AlternateGCN(dev, None, cfg5, dims=[d, h], num_nodes=n,
+                                        fold_activation=os.environ.get("PANGNN_FOLD_ACT", "1") == "1",   # A/B switch
+                                        **model_flags)
+        if cfg5:
+            g.x = torch.arange(n, device=dev)         # --categorical_node: x = node ids (build-defined)
         graph, labels, pos_weight = g, g.y, g.class_balance
-        step_fn = lambda: train_step(model, opt, graph, labels, pos_weight)         # noqa: E731
+
+        def step_fn():
+            with amp:
+                return train_step(model, opt, graph, labels, pos_weight)
     opt = make_optimizer(model)
 
     t_struct = time.perf_counter()
@@ -228,7 +253,7 @@ def main():
     torch.cuda.synchronize()
     t_struct = time.perf_counter() - t_struct
 
-    PF.KERNEL_TIMER = {"sim.fwd": [], "dec.bwd": [], "dec.dgrad": []}
+    PF.KERNEL_TIMER = {"sim.fwd": [], "sim.bwd": [], "dec.bwd": [], "dec.dgrad": []}
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -258,7 +283,7 @@ def main():
     # embedding operator: config 5's --categorical_node puts it back), timed on a fuse_embedding=False model;
     # (ii) the strict-fp32 step (every decoder product on f32 MFMA: PANGNN_DECODER_PRECISION=0)
     extra = {}
-    if world == 1 and not force_dist and not args.no_extras:
+    if world == 1 and not force_dist and not args.no_extras and not cfg5:
         try:
             PF.KERNEL_TIMER = {"sim.bwd": []}
             m2 = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h], fuse_embedding=False)
@@ -306,9 +331,13 @@ def main():
             "metric": "edges/sec in GNN forward+backward (link-pred train step)",
             "value": e_sim * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16 rows / f32" if cfg5 else "f32", "data": "synthetic",
             "config": {"workload": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf}, whole graph as one batch, "
-                                   f"node_dim={d} hidden_dim={h}, AlternateGCN default topology, mlp decoder",
+                                   f"node_dim={d} hidden_dim={h}, AlternateGCN default topology, mlp decoder" +
+                                   (", --skip_connections --categorical_node, bf16 autocast (propagated rows stored in "
+                                    "bfloat16; dense layers and decoder fp32-level)" if cfg5 else "") +
+                                   (", one GPU's share of config 5 (6 of 50 genomes, m = 220 negatives per gene)"
+                                    if args.workload == "cfg5slice" else ""),
                        "nodes": n, "sim_edges": e_sim, "neighbour_edges": e_nb,
                        "partition": "none" if world == 1 else f"destination-partitioned x{world}, rank-local generation, halo rows by all-to-all-v (conv_in needs no exchange)",
                        "arithmetic": "fp32 storage and accumulation everywhere; the three per-edge decoder products run on the bf16 "
@@ -371,7 +400,7 @@ def main():
                 "fabric_rate_note": "7.4-7.9 TB/s is the guide's gather ceiling for a table of this size "
                                     "(MI355X_MICROARCH.md, indexed rows): the kernel sits at it",
                 "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_prop * 1e3, "share_of_step": t_prop / step_s,
-                "bwd_avg_launch_ms": extra.get("bwd_avg_launch_ms")}
+                "bwd_avg_launch_ms": extra.get("bwd_avg_launch_ms", (_avg("sim.bwd") or 0) * 1e3 or None)}
         for k_ in ("strict_fp32", "extras_error"):
             if k_ in extra:
                 line[k_] = extra[k_]

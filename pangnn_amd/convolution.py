@@ -135,7 +135,7 @@ class GCNConv(MessagePassing):
         # Under bf16 autocast (`accelerate` mixed precision) PyG's propagate gathers bf16 rows — the
         # output of its autocast Linear — and multiplies / accumulates in fp32: the rows this layer propagates are
         # stored in bfloat16 (half the gather bytes, pangnn_spmm_csr_bf16); the dense part itself stays fp32.
-        rows_bf16 = x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        rows_bf16 = x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
         if in_elu and self.in_channels < self.out_channels:
             x, in_elu = torch.nn.functional.elu(x), False       # propagate comes first: nothing to fold into
         if self.in_channels < self.out_channels:

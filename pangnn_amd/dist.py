@@ -280,8 +280,21 @@ class HipOps:
 class DistAlternateGCN(AlternateGCN):
     """AlternateGCN (same parameters / state_dict) evaluated on a destination-partitioned shard."""
 
-    def __init__(self, device=None, dims=(64, 128), part=None, group=None, ops=None, exchange="halo", **kw):
+    def __init__(self, device=None, dims=(64, 128), part=None, group=None, ops=None, exchange="halo",
+                 categorical_nodes: bool = False, **kw):
+        """`categorical_nodes` (config 5, `--categorical_node`): one embedding row per node, SHARDED like the nodes — a
+        rank holds `Embedding(n_local, D)` for the rows it owns (needs `part`), the halo rows travel with the first
+        layer's exchange, and `embedding.weight` is a rank-local parameter that the gradient all-reduce skips (a
+        replicated [N, D] table would cost a 2.5 GB all-reduce per step at N = 1e7)."""
         super().__init__(device, None, False, dims=dims, **kw)
+        self.sharded_embedding = bool(categorical_nodes)
+        if self.sharded_embedding:
+            if part is None:
+                raise ValueError("categorical_nodes=True needs part= (the shard whose rows the embedding covers)")
+            self.embedding = torch.nn.Embedding(int(part.n_local), dims[0])
+            self.categorical_nodes = True
+            if device is not None:
+                self.embedding.to(device)
         self.group = group
         self.ops = ops or HipOps()
         if exchange not in ("halo", "allgather"):
@@ -354,6 +367,9 @@ class DistAlternateGCN(AlternateGCN):
         """conv_in(embedding(x)): x is constant, so the scalar features of the halo rows are exchanged once
         (cached on the shard) and the first layer runs without any per-step exchange, forward or backward."""
         conv = self.conv_in
+        if self.sharded_embedding:
+            # rows of the owned nodes are the parameter itself; the exchange of the first layer carries the halo rows
+            return self._conv(conv, self.embedding.weight, shard, name, weight, "w", name)
         if conv.in_channels < conv.out_channels and self.fuse_embedding and hasattr(self.ops, "embed_propagate"):
             cache = shard.__dict__.setdefault("_dist_xtab", {})
             key = (name, self.exchange)
@@ -424,7 +440,8 @@ class DistAlternateGCN(AlternateGCN):
 
     def sync_gradients(self):
         """one flat all-reduce (sum) of every parameter gradient: 216 KB at default dims"""
-        grads = [p.grad for p in self.parameters() if p.grad is not None]
+        local = self.embedding.weight if self.sharded_embedding else None      # rank-local rows: nothing to reduce
+        grads = [p.grad for p in self.parameters() if p.grad is not None and p is not local]
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])

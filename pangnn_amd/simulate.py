@@ -135,14 +135,14 @@ def _adjacent_block(b: int, n: int, node, m: int, means, seed: int, device):
 
 
 def simulate_raw(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
-                 means=(200, 500), seed: int = 0, device="cpu", blocks=None):
+                 means=(200, 500), seed: int = 0, device="cpu", blocks=None, mean_neg=None):
     """raw similarity relation (before remove_trivial_cases) + node metadata.
     `blocks` (list of b): only the adjacent genome pairs (b, b + 1) listed — what survives remove_trivial_cases can
     only come from those (a gene has exactly one candidate, its ortholog, in every non-adjacent genome), which is
     what rank-local generation relies on; None = the whole relation, non-adjacent ortholog pairs included."""
     device = torch.device(device)
     G, N = int(genomes), int(n) * int(genomes)
-    m = _mean_negatives(n, G, frac_pos)
+    m = _mean_negatives(n, G, frac_pos) if mean_neg is None else int(mean_neg)   # override: a slice of a bigger data set
     pos_of = _synteny_order(n, G, math.floor(n / num_fragments), int(n_shuffle), seed).to(device)
     node = (torch.arange(G, device=device).view(-1, 1) * n + pos_of)        # node id of gene (g, p)
     p_all = torch.arange(n, device=device)
@@ -172,7 +172,7 @@ def simulate_raw(n: int, genomes: int, frac_pos: float, num_fragments: float = 1
 
 def simulate_shard(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
                    neighbours: int = 1, seed: int = 0, device="cpu", temperature: float = 0.8, rank: int = 0,
-                   world: int = 1):
+                   world: int = 1, mean_neg=None):
     """Rank `rank`'s destination-partitioned shard of the simulated graph WITHOUT building the whole graph: the rank
     draws only the genome pairs that touch its node range (per-pair generators), normalises them (every
     (source, candidate genome) group lies inside one pair) and keeps the edges whose target it owns.  Bit-identical to
@@ -185,7 +185,8 @@ def simulate_shard(n: int, genomes: int, frac_pos: float, num_fragments: float =
     lo, hi = rank * n_local, min((rank + 1) * n_local, N)
     g_lo, g_hi = lo // n, max(lo, hi - 1) // n
     blocks = list(range(max(g_lo - 1, 0), min(g_hi, G - 2) + 1)) if hi > lo else []
-    raw = simulate_raw(n, genomes, frac_pos, num_fragments, n_shuffle, seed=seed, device=device, blocks=blocks)
+    raw = simulate_raw(n, genomes, frac_pos, num_fragments, n_shuffle, seed=seed, device=device, blocks=blocks,
+                       mean_neg=mean_neg)
     s, d, sc = construct.remove_trivial_cases(raw.src, raw.dst, raw.score, raw.genome_of)
     s, d, w = construct.normalize_sim_scores(s, d, sc, raw.genome_of, t=temperature)
     own = (d >= lo) & (d < hi) & (s != d)
@@ -210,10 +211,14 @@ def simulate_shard(n: int, genomes: int, frac_pos: float, num_fragments: float =
 
 
 def simulate_graph(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
-                   neighbours: int = 1, seed: int = 0, device="cpu", temperature: float = 0.8):
+                   neighbours: int = 1, seed: int = 0, device="cpu", temperature: float = 0.8, mean_neg=None,
+                   adjacent_only: bool = False):
     """whole simulated graph as the reference's `generate_graphs()` would emit it (dataset.py:157-158):
     x, edge_index (canonical order), edge_attr, y, neighbour_edge_index, class_balance."""
-    raw = simulate_raw(n, genomes, frac_pos, num_fragments, n_shuffle, seed=seed, device=device)
+    # adjacent_only: skip the ortholog pairs of non-adjacent genomes — remove_trivial_cases drops every one of them
+    # anyway (same graph), and at config-5 scale they are most of the raw relation
+    raw = simulate_raw(n, genomes, frac_pos, num_fragments, n_shuffle, seed=seed, device=device, mean_neg=mean_neg,
+                       blocks=list(range(int(genomes) - 1)) if adjacent_only else None)
     g = construct.build_from_raw(raw.num_nodes, raw.src, raw.dst, raw.score, raw.genome_of,
                                  group_of=raw.group_of, neighbours=neighbours, t=temperature)
     pos = g.y.sum()

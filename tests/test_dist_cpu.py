@@ -70,14 +70,26 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
     if flags.get("union_edge_weights"):
         g.edge_attr = g.union_edge_attr
     torch.manual_seed(0)
-    oracle = go.AlternateGCNOracle(dims=(64, 128), flags=go.default_flags(**flags))
+    flags = dict(flags)
+    categorical = flags.pop("categorical_nodes", False)          # config 5: --skip_connections --categorical_node
+    n = g.x.shape[0]
+    oracle = go.AlternateGCNOracle(dims=(64, 128), flags=go.default_flags(**flags), categorical_nodes=categorical,
+                                   num_nodes=n)
     with torch.no_grad():
         for k, p in oracle.named_parameters():
             if k.endswith("bias"):
                 p.uniform_(-0.5, 0.5)
-    model = pdist.DistAlternateGCN(None, dims=[64, 128], ops=TorchOps(), exchange=exchange, **flags)
-    model.load_state_dict(oracle.state_dict())
+    if categorical:
+        g.x = torch.arange(n)
     shard = pdist.partition_graph(g, rank, world)
+    model = pdist.DistAlternateGCN(None, dims=[64, 128], ops=TorchOps(), exchange=exchange, part=shard,
+                                   categorical_nodes=categorical, **flags)
+    sd = oracle.state_dict()
+    if categorical:                                              # a rank holds the embedding rows of its own nodes
+        rows = torch.zeros(shard.n_local, 64)
+        rows[: shard.hi - shard.lo] = sd["embedding.weight"][shard.lo:shard.hi]
+        sd = dict(sd, **{"embedding.weight": rows})
+    model.load_state_dict(sd)
     assert shard.n_pad == shard.n_local * world and shard.e_sim_total == g.edge_index.shape[1]
     pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -100,6 +112,11 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
         if q.grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
+        if categorical and k == "embedding.weight":              # sharded rows, not all-reduced
+            scale = float(q.grad.abs().max()) + 1e-12
+            assert torch.allclose(p.grad[: shard.hi - shard.lo], q.grad[shard.lo:shard.hi], atol=1e-4 * scale + 1e-8,
+                                  rtol=1e-3), k
+            continue
         scale = float(q.grad.abs().max()) + 1e-12
         assert torch.allclose(p.grad, q.grad, atol=1e-4 * scale + 1e-8, rtol=1e-3), (k, (p.grad - q.grad).abs().max())
     if exchange == "halo":
@@ -121,8 +138,9 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True), dict(base_model=True),
-                                   dict(union_edge_weights=True)],
-                         ids=["default", "skip", "base", "union"])
+                                   dict(union_edge_weights=True),
+                                   dict(skip_connections=True, categorical_nodes=True)],
+                         ids=["default", "skip", "base", "union", "cfg5-skip-categorical"])
 def test_partitioned_model_matches_single_process_oracle(world, flags):
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "rdzv")

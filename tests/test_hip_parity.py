@@ -1018,3 +1018,39 @@ def test_gcn_norm_cache_survives_address_reuse():
     st2 = structure_of(view, n)
     assert torch.equal(st2.edge_index.cpu(), ei)
     clear_cache()
+
+
+def test_config5_slice_skip_connections_categorical_bf16_autocast():
+    """BASELINE.json config 5 on a 1-GPU-sized slice: `--skip_connections --categorical_node` under bf16 mixed
+    precision.  The oracle under CPU bf16 autocast (what `accelerate` makes of the reference: its Linear layers run in
+    bf16) is the reference; the product stores only the propagated rows in bf16 and keeps the dense layers and the
+    decoder in fp32-level arithmetic, so it must (i) agree with the autocast oracle to bf16 resolution, (ii) be at
+    least as close to the fp32 oracle as the autocast oracle is, (iii) train: three steps lower the loss like the
+    oracle's."""
+    g, gd, oracle, model = _pair("cfg2_sim_1000x5", (64, 64), dict(skip_connections=True), categorical=True)
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    exact = oracle(g)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref = oracle(g).float()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(gd)
+        loss, logits = model.loss_and_logits(gd, gd.y, pw.to(dev()))
+    assert out.dtype == torch.float32 and torch.allclose(out, logits, atol=1e-4, rtol=1e-4)    # inference form vs one-pass training form
+    scale = float(exact.abs().max())
+    e_ref = float((ref - exact).abs().max())
+    e_out = float((out.cpu() - exact).abs().max())
+    assert float((out.cpu() - ref).abs().max()) < 5e-2 * scale          # bf16 resolution
+    assert e_out <= e_ref + 1e-3 * scale                                 # no further from fp32 than the reference's own autocast
+    assert e_out > 1e-6 * scale                                          # the bf16 row storage is really on
+    # a few training steps under autocast track the oracle's
+    from pangnn_amd.train import make_optimizer, train_step
+    opt_m, opt_o = make_optimizer(model), torch.optim.Adam(oracle.parameters(), lr=1e-3)
+    lm, lo = [], []
+    for _ in range(3):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            l_, _ = train_step(model, opt_m, gd, gd.y, pw.to(dev()))
+        lm.append(float(l_))
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            l2, _ = go.train_step(oracle, opt_o, g, g.y, pw)
+        lo.append(float(l2))
+    assert lm[-1] < lm[0] and abs(lm[-1] - lo[-1]) < 5e-2 * abs(lo[0])
