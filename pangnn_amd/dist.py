@@ -33,7 +33,10 @@ constructs anything but `HipOps`.
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
+from typing import Optional
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -166,8 +169,39 @@ class HaloPlan:
         new_src = torch.where(remote, torch.where(src < lo, pos, pos + n_local), src - lo + self.n_low)
         self.edge_index = torch.stack([new_src, ei_local[1]]).contiguous()
         self.group = group
+        # A source-sorted list is [sources of lower ranks | own sources | sources of higher ranks]: the middle range
+        # needs no exchanged row, so the decoder can run on it while the halo rows travel (decoder_loss_overlapped)
+        self.sorted_by_src = bool((new_src[1:] >= new_src[:-1]).all()) if new_src.numel() > 1 else True
+        self.e_lo = int((new_src < self.n_low).sum())
+        self.e_hi = int((new_src < self.n_low + n_local).sum())
+        self._split_cache = {}
         # fixed-order accumulation of returned halo gradients into the owner's rows
         self.back_csr = make_csr(self.send_idx, n_local) if (make_csr is not None and self.send_idx.numel()) else None
+
+
+    def split_edges(self):
+        """(own-source edges, halo-source edges) of the re-indexed list, each still sorted by source"""
+        ei = self.edge_index
+        loc = ei[:, self.e_lo:self.e_hi].contiguous()
+        halo = torch.cat([ei[:, : self.e_lo], ei[:, self.e_hi:]], dim=1).contiguous()
+        return loc, halo
+
+    def split_edge_values(self, t: Optional[torch.Tensor]):
+        """a per-edge tensor of the shard (labels, skip feature) in the two ranges; cached on the tensor's identity"""
+        if t is None:
+            return None, None
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        hit = self._split_cache.get(key)
+        if hit is None:
+            if len(self._split_cache) >= 4:
+                self._split_cache.pop(next(iter(self._split_cache)))
+            hit = self._split_cache[key] = (t, t[self.e_lo:self.e_hi].contiguous(),
+                                            torch.cat([t[: self.e_lo], t[self.e_hi:]]).contiguous())
+        return hit[1], hit[2]
+
+    def merge_edge_values(self, loc: torch.Tensor, halo: torch.Tensor) -> torch.Tensor:
+        """inverse of split_edge_values: back to the shard's edge order"""
+        return torch.cat([halo[: self.e_lo], loc, halo[self.e_lo:]])
 
 
 class HaloGather(torch.autograd.Function):
@@ -198,6 +232,120 @@ class HaloGather(torch.autograd.Function):
         if back.shape[0]:
             ctx.acc(g_local, back, plan)
         return g_local, None, None
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """one extra stream per device for the exchanges that run under compute (None on the CPU)"""
+    if device.type != "cuda":
+        return None
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device)
+    return s
+
+
+class _Side:
+    """`with _Side(device, *tensors)`: run the block on the side stream, after everything enqueued so far on the
+    current one; the listed tensors are marked as used there (caching-allocator lifetime).  `.done()` afterwards makes
+    the current stream wait for the block.  On the CPU both are no-ops and the block simply runs in order."""
+
+    def __init__(self, device, *tensors):
+        self.side = _side_stream(device)
+        self.tensors = tensors
+        self.event = None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.main = torch.cuda.current_stream(self.side.device)
+            self.side.wait_stream(self.main)
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def keep(self, *tensors):
+        """tensors allocated inside the block that the main stream will read"""
+        if self.side is not None:
+            for t in tensors:
+                t.record_stream(self.main)
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.event = self.side.record_event()
+            self.ctx.__exit__(*exc)
+        return False
+
+    def done(self):
+        if self.event is not None:
+            torch.cuda.current_stream(self.side.device).wait_event(self.event)
+
+
+class _OverlappedDecoderLoss(torch.autograd.Function):
+    """The training decoder of one shard with both halo exchanges hidden under compute.
+
+      side stream:  rows of P to the ranks that read them  ............  halo rows' dL/dP back to their owners
+      main stream:  decoder over the own-source edges | decoder over the halo-source edges (S | dL/dP | T) | add
+
+    `ops.decoder_train` is the one-pass training decoder (loss, logits and every gradient in forward), so like
+    functional._DecoderLoss this function finishes all gradients in forward() and backward() only hands them out.
+    Inputs are this rank's blocks p_local, q_local [n_local, D]; the table [halo | own | halo] exists only inside."""
+
+    @staticmethod
+    def forward(ctx, p_local, q_local, ops, plan: HaloPlan, st_loc, st_halo, extra, cvec, w2, b2, w3, b3, y,
+                pos_weight, denom):
+        dev = p_local.device
+        p_local = p_local.contiguous()
+        n_low, n_loc, d = plan.n_low, plan.n_local, p_local.shape[1]
+        table = p_local.new_empty((plan.n_table, d))
+        with _Side(dev, p_local, table) as fwd:
+            send = p_local.index_select(0, plan.send_idx)
+            recv = p_local.new_empty((plan.n_halo, d))
+            _all_to_all_v(recv, send, plan.recv_splits, plan.send_splits, plan.group)
+            table[:n_low] = recv[:n_low]
+            table[n_low + n_loc:] = recv[n_low:]
+        table[n_low:n_low + n_loc] = p_local
+        ex_l, ex_h = plan.split_edge_values(extra)
+        y_l, y_h = plan.split_edge_values(y)
+        # own-source edges: read rows n_low .. n_low + n_local of the table only
+        r_loc = ops.decoder_train(table, q_local, st_loc, ex_l, cvec, w2, b2, w3, b3, y_l, pos_weight, denom)
+        fwd.done()
+        box = {}
+
+        def send_back(gp_table):
+            with _Side(dev, gp_table) as bwd:
+                g_halo = torch.cat([gp_table[:n_low], gp_table[n_low + n_loc:]], dim=0)
+                back = gp_table.new_empty((plan.send_idx.numel(), d))
+                _all_to_all_v(back, g_halo, plan.send_splits, plan.recv_splits, plan.group)
+                bwd.keep(back)
+            box["bwd"], box["back"] = bwd, back
+
+        r_halo = ops.decoder_train(table, q_local, st_halo, ex_h, cvec, w2, b2, w3, b3, y_h, pos_weight, denom,
+                                   after_p=send_back)
+        loss_l, logit_l, gp_l, gq_l = r_loc[:4]
+        loss_h, logit_h, _, gq_h = r_halo[:4]
+        gp_local = gp_l[n_low:n_low + n_loc]                     # rows of halo sources are zero in gp_l
+        box["bwd"].done()
+        if box["back"].shape[0]:
+            ops.accumulate_back(gp_local, box["back"], plan)
+        gq = gq_l.add_(gq_h)
+        small = [None if a is None else a + b for a, b in zip(r_loc[4:], r_halo[4:])]     # g_cv, g_w2, g_b2, g_w3, g_b3
+        logits = plan.merge_edge_values(logit_l, logit_h)
+        ctx.has_cv = small[0] is not None
+        ctx.save_for_backward(gp_local, gq, small[0] if small[0] is not None else gq.new_empty(0), *small[1:])
+        ctx.mark_non_differentiable(logits)
+        return (loss_l + loss_h).view(()), logits
+
+    @staticmethod
+    def backward(ctx, go, _go_logits):
+        gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
+        k = (lambda t: t) if PF.is_unit_grad(go) else (lambda t: t * go)
+        return (k(gp), k(gq), None, None, None, None, None, k(g_cv) if ctx.has_cv else None, k(g_w2), k(g_b2), k(g_w3),
+                k(g_b3), None, None, None)
 
 
 # --------------------------------------------------------------------------------------
@@ -269,6 +417,16 @@ class HipOps:
     def decoder_loss(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
         return PF.decoder_loss(p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
 
+    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None):
+        """one-pass training decoder on (a range of) a shard: (loss, logits, dL/dtable, dL/dq, g_cvec, g_w2, g_b2, g_w3,
+        g_b3), all finished; `after_p(dL/dtable)` runs before the by-target pass is enqueued"""
+        f = PF._f32c
+        pw = None if pos_weight is None else f(pos_weight).reshape(-1)
+        loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = PF._decoder_train16(
+            PF._rows_f32(table), PF._rows_f32(q_local), st, None if extra is None else f(extra),
+            None if cvec is None else f(cvec), f(w2), f(b2), f(w3), f(b3), y=f(y), pw=pw, denom=denom, after_p=after_p)
+        return loss.view(()), logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
+
     def linear(self, x, w, b, in_act: int = 0):
         return PF.linear(x, w, b, in_act)
 
@@ -300,6 +458,7 @@ class DistAlternateGCN(AlternateGCN):
         if exchange not in ("halo", "allgather"):
             raise ValueError("exchange must be 'halo' or 'allgather'")
         self.exchange = exchange
+        self.overlap = os.environ.get("PANGNN_DIST_OVERLAP", "1") != "0"
         if self.flags.decoder != "mlp":
             raise NotImplementedError("partitioned mode implements the mlp decoder")
         if dims[0] != 64 and isinstance(self.ops, HipOps):
@@ -327,6 +486,27 @@ class DistAlternateGCN(AlternateGCN):
                       "union": getattr(shard, "union_edge_index", None)}[name]
                 cache[key] = self.ops.structure(ei, shard.n_local, shard.n_pad)
         return cache[key]
+
+    def _st_split(self, shard):
+        """structures of the own-source and halo-source ranges of the shard's sim edges (overlapped decoder)"""
+        cache = shard.__dict__.setdefault("_dist_structs", {})
+        key = ("sim", "split")
+        if key not in cache:
+            plan = self._plan(shard, "sim")
+            loc, halo = plan.split_edges()
+            cache[key] = (self.ops.structure(loc, shard.n_local, plan.n_table),
+                          self.ops.structure(halo, shard.n_local, plan.n_table))
+        return cache[key]
+
+    def _overlap_ok(self, shard) -> bool:
+        """the exchange can hide under the decoder: halo exchange, a back end with the one-pass decoder, a source-
+        sorted shard and something to exchange (PANGNN_DIST_OVERLAP=0 switches it off)"""
+        if self.exchange != "halo" or not self.overlap or not hasattr(self.ops, "decoder_train"):
+            return False
+        if isinstance(self.ops, HipOps) and PF.DECODER_PRECISION != 1:
+            return False
+        plan = self._plan(shard, "sim")
+        return plan.sorted_by_src and (plan.n_halo > 0 or plan.send_idx.numel() > 0)
 
     def _table(self, x_local, shard, name):
         """rows of every node this rank's `name` edges read: [own | halo] or the all-gathered [N_pad]"""
@@ -404,14 +584,15 @@ class DistAlternateGCN(AlternateGCN):
         h, pending = self._encode_pre(shard)
         return self.activation_fct(h) if pending else h
 
-    def _dec_in(self, z, shard, in_act: int = 0):
+    def _dec_in(self, z, shard, in_act: int = 0, gather: bool = True):
+        """gather=False: p stays this rank's block (the overlapped decoder exchanges the halo rows itself)"""
         fl = self.flags
         d = z.shape[1]
         lin0 = self.mlp[0]
         w = lin0.weight
         p = self._linear(z, w[:, :d].contiguous(), None, in_act)
         q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias, in_act)
-        p_full = self._table(p, shard, "sim")
+        p_full = self._table(p, shard, "sim") if gather else p
         extra = shard.edge_attr if fl.skip_connections else None
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
         return p_full, q, extra, cvec
@@ -430,6 +611,12 @@ class DistAlternateGCN(AlternateGCN):
         fold = pending and self._fold_elu()
         if not fold:
             z = self.activation_fct(z) if pending else z
+        if torch.is_grad_enabled() and self._overlap_ok(shard):
+            p, q, extra, cvec = self._dec_in(z, shard, 1 if fold else 0, gather=False)
+            st_loc, st_halo = self._st_split(shard)
+            return _OverlappedDecoderLoss.apply(p, q, self.ops, self._plan(shard, "sim"), st_loc, st_halo, extra, cvec,
+                                                self.mlp[2].weight, self.mlp[2].bias, self.mlp[4].weight.view(-1),
+                                                self.mlp[4].bias, labels, pos_weight, shard.e_sim_total)
         if hasattr(self.ops, "decoder_loss") and torch.is_grad_enabled():
             p_full, q, extra, cvec = self._dec_in(z, shard, 1 if fold else 0)
             return self.ops.decoder_loss(p_full, q, self._st(shard, "sim"), extra, cvec, self.mlp[2].weight,

@@ -308,11 +308,13 @@ def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 
 
 
 def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw=None, denom=0, g_logits=None,
-                     out_p=None, out_q=None, need_p=True, need_q=True):
+                     out_p=None, out_q=None, need_p=True, need_q=True, after_p=None):
     """Two-wave-per-SIMD training decoder (csrc/decoder16.hip).  One pass over the edges in the caller's order (S):
     logits, loss (y given) or the given dL/dlogits, every parameter gradient, per-source run sums when the list is
     source-sorted, and a 32-byte record per edge; then dL/dQ (and dL/dP for unsorted lists) from the records in CSR
-    order (T).  No [E, 64] tensor exists.  Returns (loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3)."""
+    order (T).  No [E, 64] tensor exists.  Returns (loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3).
+    `after_p(gp)` is called once dL/dP is enqueued and before the T pass (the partitioned model starts the return
+    exchange of the halo rows' gradients there, so that it runs under T)."""
     lib = _lib.load()
     dev = p.device
     e, d = st.num_edges, p.shape[1]
@@ -347,6 +349,8 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
         else:
             gp = _dgrad_sum(rec, st, "src", w2, w3, p.shape[0], out_p, g_b2=b2_out)
             b2_out = None
+        if after_p is not None:
+            after_p(gp)
     if need_q:
         if e == 0:
             gq = (out_q if out_q is not None else torch.empty(q.shape[0], d, device=dev)).zero_()

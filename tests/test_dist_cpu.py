@@ -53,6 +53,22 @@ class TorchOps:
             h = h + extra.view(-1, 1) * cvec
         return torch.relu(torch.relu(h) @ w2.t() + b2) @ w3 + b3
 
+    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None):
+        """the one-pass training decoder of HipOps, by autograd: everything finished on return"""
+        leaves = [t.detach().clone().requires_grad_() for t in (table, q_local, w2, b2, w3, b3)]
+        cv = None if cvec is None else cvec.detach().clone().requires_grad_()
+        with torch.enable_grad():
+            logits = self.decoder(leaves[0], leaves[1], st, extra, cv, *leaves[2:])
+            loss = self.bce_sum_over(logits, y, pos_weight, denom)
+            if logits.numel():
+                grads = torch.autograd.grad(loss, leaves + ([cv] if cv is not None else []))
+            else:
+                grads = [torch.zeros_like(t) for t in leaves + ([cv] if cv is not None else [])]
+        if after_p is not None:
+            after_p(grads[0])
+        g_cv = grads[6] if cv is not None else None
+        return (loss.detach(), logits.detach(), grads[0], grads[1], g_cv, grads[2], grads[3], grads[4], grads[5])
+
     def linear(self, x, w, b, in_act=0):
         return torch.nn.functional.linear(torch.nn.functional.elu(x) if in_act else x, w, b)
 
@@ -61,7 +77,7 @@ class TorchOps:
                                                                     reduction="sum") / denom
 
 
-def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
+def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
@@ -69,6 +85,11 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
     g = whole_graph_from_golden("sim_200x4")
     if flags.get("union_edge_weights"):
         g.edge_attr = g.union_edge_attr
+    else:
+        # canonical (src, dst) order of construct.whole_graph (the fixture keeps the reference's set-iteration order)
+        o = torch.argsort(g.edge_index[0] * g.x.shape[0] + g.edge_index[1], stable=True)
+        g.edge_index, g.edge_attr, g.y = g.edge_index[:, o].contiguous(), g.edge_attr[o].contiguous(), g.y[o].contiguous()
+    canonical = not flags.get("union_edge_weights")
     torch.manual_seed(0)
     flags = dict(flags)
     categorical = flags.pop("categorical_nodes", False)          # config 5: --skip_connections --categorical_node
@@ -84,6 +105,9 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
     shard = pdist.partition_graph(g, rank, world)
     model = pdist.DistAlternateGCN(None, dims=[64, 128], ops=TorchOps(), exchange=exchange, part=shard,
                                    categorical_nodes=categorical, **flags)
+    model.overlap = overlap
+    # the exchange hides under the decoder exactly when there is one (halo exchange, source-sorted shard)
+    assert model._overlap_ok(shard) == (overlap and exchange == "halo" and canonical)
     sd = oracle.state_dict()
     if categorical:                                              # a rank holds the embedding rows of its own nodes
         rows = torch.zeros(shard.n_local, 64)
@@ -121,6 +145,15 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo"):
         assert torch.allclose(p.grad, q.grad, atol=1e-4 * scale + 1e-8, rtol=1e-3), (k, (p.grad - q.grad).abs().max())
     if exchange == "halo":
         plan = model._plan(shard, "sim")
+        # [sources of lower ranks | own sources | sources of higher ranks]
+        ts = plan.edge_index[0]
+        assert plan.sorted_by_src == canonical and 0 <= plan.e_lo <= plan.e_hi <= ts.numel()
+    if exchange == "halo" and canonical:
+        assert bool((ts[: plan.e_lo] < plan.n_low).all()) and bool((ts[plan.e_hi:] >= plan.n_low + plan.n_local).all())
+        mid = ts[plan.e_lo:plan.e_hi]
+        assert bool(((mid >= plan.n_low) & (mid < plan.n_low + plan.n_local)).all())
+        a, b = plan.split_edge_values(shard.y)
+        assert torch.equal(plan.merge_edge_values(a, b), shard.y)
         # the halo is exactly the set of remote sources this rank's edges reference
         src = shard.edge_index[0]
         rem = (src < shard.lo) | (src >= shard.lo + shard.n_local)
@@ -146,6 +179,15 @@ def test_partitioned_model_matches_single_process_oracle(world, flags):
         init_file = os.path.join(d, "rdzv")
         mp.spawn(_worker, args=(world, init_file, flags, d, "halo"), nprocs=world, join=True)
         assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(world))
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True)], ids=["default", "skip"])
+def test_partitioned_model_without_overlap(flags):
+    """PANGNN_DIST_OVERLAP=0: the table is gathered first and the decoder runs once over the shard"""
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "rdzv")
+        mp.spawn(_worker, args=(2, init_file, flags, d, "halo", False), nprocs=2, join=True)
+        assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(2))
 
 
 @pytest.mark.parametrize("flags", [dict(), dict(union_edge_weights=True)], ids=["default", "union"])

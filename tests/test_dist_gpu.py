@@ -17,7 +17,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, init_file, exchange, out_dir):
+def _worker(rank, world, init_file, exchange, out_dir, overlap=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import copy_graph, whole_graph_from_golden
@@ -42,6 +42,10 @@ def _worker(rank, world, init_file, exchange, out_dir):
     model = pdist.DistAlternateGCN(dev, dims=[64, 128], exchange=exchange)
     model.load_state_dict(oracle.state_dict())
     shard = pdist.partition_graph(gd, rank, world)
+    model.overlap = overlap
+    # halo exchange on a source-sorted shard: both exchanges of the decoder run on the side stream, under the
+    # own-source pass and the by-target pass (dist._OverlappedDecoderLoss)
+    assert model._overlap_ok(shard) == (overlap and exchange == "halo")
 
     full = pdist.gather_logits(model(shard).detach(), shard)
     ref = oracle(g).detach()
@@ -74,8 +78,9 @@ def _worker(rank, world, init_file, exchange, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "halo"), (2, "allgather"), (4, "halo")])
-def test_ranks_on_one_gpu_match_the_single_gpu_model(world, exchange):
+@pytest.mark.parametrize("world,exchange,overlap", [(2, "halo", True), (2, "halo", False), (2, "allgather", True),
+                                                    (4, "halo", True)])
+def test_ranks_on_one_gpu_match_the_single_gpu_model(world, exchange, overlap):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, os.path.join(d, "rdzv"), exchange, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, os.path.join(d, "rdzv"), exchange, d, overlap), nprocs=world, join=True)
         assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(world))
