@@ -31,6 +31,10 @@ extern "C" {
 #define PANGNN_E_WORKSPACE (-3)  /* workspace smaller than *_workspace_bytes() asked for     */
 #define PANGNN_E_ALIGN     (-4)  /* pointer / leading dimension not 16-byte aligned          */
 
+/* storage types of the *_mixed entry points: the arithmetic is fp32 either way, a matrix may be STORED as bfloat16 */
+#define PANGNN_DTYPE_F32  0
+#define PANGNN_DTYPE_BF16 1
+
 typedef void* pangnn_stream_t;   /* hipStream_t */
 
 int         pangnn_abi_version(void);
@@ -239,6 +243,23 @@ int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_
                              int64_t denom, const float* g_logits, float* logits, float* loss, uint32_t* rec,
                              float* part_buf, const int32_t* part_off, float* g_w2, float* g_w3, float* g_b3,
                              float* g_cvec, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+/* bf16-storage mode of the gather (config 5, bf16 mixed precision: mlp[0] is an autocast Linear, src/gnn.py:173, so
+ * its node-level halves P and Q are bf16 tensors): pq_dtype = PANGNN_DTYPE_BF16 reads p and q as bfloat16 rows
+ * (ldp / ldq in elements, multiples of 8; half the gather bytes).  bf16 -> f32 is exact, so logits, loss and all
+ * gradients equal, bit for bit, those of the f32 entry points on the up-converted tables.  Gradients stay fp32.
+ * pangnn_decoder_train_f32 / the precision-1 pangnn_decoder_mlp_infer_f32 are these with PANGNN_DTYPE_F32. */
+int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void* q, int64_t ldq, int32_t pq_dtype,
+                               int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                               const float* extra, const float* cvec, const float* w2, const float* b2,
+                               const float* w3, const float* b3, int32_t D, const float* y, const float* pos_weight,
+                               int64_t denom, const float* g_logits, float* logits, float* loss, uint32_t* rec,
+                               float* part_buf, const int32_t* part_off, float* g_w2, float* g_w3, float* g_b3,
+                               float* g_cvec, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+int pangnn_decoder_mlp_infer_mixed(const void* p, int64_t ldp, const void* q, int64_t ldq, int32_t pq_dtype,
+                                   int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                                   const float* extra, const float* cvec, const float* w2, const float* b2,
+                                   const float* w3, const float* b3, int32_t D, float* logits,
+                                   pangnn_stream_t stream);
 size_t pangnn_decoder_dgrad_workspace_bytes(void);
 int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys, const float* extra,
                              const float* w2, const float* w3, int64_t num_edges, float* part_buf,
@@ -274,6 +295,19 @@ int    pangnn_linear_act_fwd_f32(const float* x, int64_t ldx, const float* w, co
 int    pangnn_linear_act_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
                                    int32_t K, int32_t M, int32_t in_act, float* gw, float* gb,
                                    void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+/* bf16-storage modes (config 5: `accelerate` bf16 mixed precision, pangnn.py:25 — the reference's autocast Linear
+ * layers, src/gnn.py:93,111,173, hand bf16 tensors to the next layer).  x / y / gate / g may each be stored as
+ * bfloat16 (PANGNN_DTYPE_*; ld in ELEMENTS; rows start on 8 bytes); products and sums are the same exact-fp32 MFMA
+ * chains as above, a bf16 result is rounded to nearest even once, on store.  w, bias, gw, gb stay fp32 (the
+ * parameters are fp32 under autocast).  A gated product is the gradient of its gate tensor and is stored like it:
+ * gate_dtype must equal y_dtype.  The *_f32 entry points are these with every dtype = PANGNN_DTYPE_F32. */
+int    pangnn_linear_act_fwd_mixed(const void* x, int32_t x_dtype, int64_t ldx, const float* w, const float* bias,
+                                   void* y, int32_t y_dtype, int64_t ldy, int64_t n, int32_t K, int32_t M,
+                                   int32_t in_act, const void* gate, int32_t gate_dtype, int64_t ldgate,
+                                   pangnn_stream_t stream);
+int    pangnn_linear_act_wgrad_mixed(const void* g, int32_t g_dtype, int64_t ldg, const void* x, int32_t x_dtype,
+                                     int64_t ldx, int64_t n, int32_t K, int32_t M, int32_t in_act, float* gw,
+                                     float* gb, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Confusion counts of thresholded link predictions, accumulated on the device:

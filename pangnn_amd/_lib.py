@@ -40,6 +40,12 @@ SIGNATURES = {
     "pangnn_linear_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
     "pangnn_linear_act_fwd_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "pangnn_linear_act_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
+    # bf16-storage modes: (x, x_dtype, ldx, w, bias, y, y_dtype, ldy, n, K, M, in_act, gate, gate_dtype, ldgate, stream)
+    "pangnn_linear_act_fwd_mixed": (C.c_int, [_p, _i32, _i64, _p, _p, _p, _i32, _i64, _i64, _i32, _i32, _i32, _p, _i32,
+                                              _i64, _p]),
+    # (g, g_dtype, ldg, x, x_dtype, ldx, n, K, M, in_act, gw, gb, workspace, bytes, stream)
+    "pangnn_linear_act_wgrad_mixed": (C.c_int, [_p, _i32, _i64, _p, _i32, _i64, _i64, _i32, _i32, _i32, _p, _p, _p, _sz,
+                                                _p]),
     "pangnn_confusion_update_f32": (C.c_int, [_p, _p, _i64, C.c_float, C.c_int, _p, _p]),
     "pangnn_weighted_colsum_workspace_bytes": (_sz, [_i32]),
     "pangnn_weighted_colsum_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _p, _p, _sz, _p]),
@@ -65,6 +71,10 @@ SIGNATURES = {
                                            _p, _p, _p, _p, _p,                      # logits, loss, rec, part_buf, part_off
                                            _p, _p, _p, _p,                          # g_w2, g_w3, g_b3, g_cvec
                                            _p, _sz, _p]),
+    "pangnn_decoder_train_mixed": (C.c_int, [_p, _i64, _p, _i64, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
+                                             _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pangnn_decoder_mlp_infer_mixed": (C.c_int, [_p, _i64, _p, _i64, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p,
+                                                 _i32, _p, _p]),
     # T kernel: dL/dh1 run sums in a permuted (CSR) edge order from the records
     "pangnn_decoder_dgrad_workspace_bytes": (_sz, []),
     "pangnn_decoder_dgrad_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),

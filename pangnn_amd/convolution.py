@@ -91,8 +91,8 @@ class _GlorotLinear(nn.Module):
         a = math.sqrt(6.0 / (self.in_channels + self.out_channels))
         nn.init.uniform_(self.weight, -a, a)
 
-    def forward(self, x, in_act: int = 0):
-        return PF.linear(x, self.weight, None, in_act)
+    def forward(self, x, in_act: int = 0, out_dtype=None):
+        return PF.linear(x, self.weight, None, in_act, out_dtype)
 
 
 class GCNConv(MessagePassing):
@@ -131,7 +131,8 @@ class GCNConv(MessagePassing):
             # raise on the length mismatch, so do we
             raise ValueError(f"edge_weight has {edge_weight.shape[0]} entries for {st.num_edges} edges")
         norm = st.gcn_norm(edge_weight)
-        x = x.float()
+        if not (x.dtype == torch.bfloat16 and self.in_channels >= self.out_channels):
+            x = x.float()          # (a bf16-stored input of a dense-first layer is read as stored by the linear kernel)
         # Under bf16 autocast (`accelerate` mixed precision) PyG's propagate gathers bf16 rows — the
         # output of its autocast Linear — and multiplies / accumulates in fp32: the rows this layer propagates are
         # stored in bfloat16 (half the gather bytes, pangnn_spmm_csr_bf16); the dense part itself stays fp32.
@@ -142,9 +143,11 @@ class GCNConv(MessagePassing):
             # A_hat (x W^T) == (A_hat x) W^T: propagate on the narrower side (half the gather bytes for
             # 64 -> 128), then the dense layer with the bias fused
             agg = PF.propagate(x.to(torch.bfloat16) if rows_bf16 else x, None, st, norm, tag=name or None)
-            return PF.linear(agg, self.lin.weight, self.bias)
-        xw = self.lin(x, 1 if in_elu else 0)
-        return PF.propagate(xw.to(torch.bfloat16) if rows_bf16 else xw, self.bias, st, norm, tag=name or None)
+            # the autocast Linear's output is a bf16 tensor (src/gnn.py:111 under mixed precision): stored as such
+            return PF.linear(agg, self.lin.weight, self.bias, 0, torch.bfloat16 if rows_bf16 else None)
+        # dense part first: under bf16 autocast its result is WRITTEN as bfloat16 by the linear kernel (no separate cast)
+        xw = self.lin(x, 1 if in_elu else 0, torch.bfloat16 if rows_bf16 else None)
+        return PF.propagate(xw, self.bias, st, norm, tag=name or None)
 
     def message(self, x_j, edge_weight):            # kept for API parity; forward() is fused
         return edge_weight.view(-1, 1) * x_j

@@ -148,7 +148,7 @@ __device__ float* d16_dbg_v = nullptr;     // [E][64] dL/dh1pre as the S kernel 
 #endif
 
 struct D16Params {
-  const float* p; const float* q; uint32_t ldp_b; uint32_t ldq_b;   // row strides in bytes
+  const void* p; const void* q; uint32_t ldp_b; uint32_t ldq_b;     // row strides in bytes; rows are f32 or bf16 (PQ16)
   const int64_t* ei; int64_t ld; int64_t E;
   const float* extra; const float* cvec;
   const float* w2; const float* b2; const float* w3; const float* b3;
@@ -156,8 +156,11 @@ struct D16Params {
 struct D16Loss { const float* y; const float* pos_weight; float inv_denom; };
 struct D16Run { float* part; const int32_t* part_off; };
 
-__device__ __forceinline__ float4 ld_row16(const float* table, uint32_t byte_off) {
+__device__ __forceinline__ float4 ld_row16(const void* table, uint32_t byte_off) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table) + byte_off);
+}
+__device__ __forceinline__ uint4 ld_row16u(const void* table, uint32_t byte_off) {
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(table) + byte_off);
 }
 
 // ---- weights -> LDS images (once per workgroup).  which = 1: W2 (P1), 2: W2'^T (P2), 3: both.
@@ -334,7 +337,13 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], unsigned m16, floa
 // S kernel
 // ------------------------------------------------------------------------------------------------------------------
 struct HalfIn { uint32_t poff, qoff; float aux, w_e; int key, key_nxt; };
-struct HalfRows { float4 p[4], q[4]; };
+// The gathered row pieces of lane (c, g): columns 32 ks + 8 g + 0..7 of P[src_c] and Q[dst_c], ks = 0, 1.
+// PQ16: the tables are stored as bfloat16 (config 5's autocast: mlp[0] is an autocast Linear, src/gnn.py:173) — half
+// the gather bytes and registers; bf16 -> f32 is exact, so everything downstream is the f32-table arithmetic.
+template <bool PQ16> struct HalfRowsT;
+template <> struct HalfRowsT<false> { float4 p[4], q[4]; };
+template <> struct HalfRowsT<true> { uint4 p[2], q[2]; };
+typedef HalfRowsT<false> HalfRows;
 
 // ids / label (or given gradient) / skip feature of the 16 edges of half `hx` of tile `tile`.  Addresses are a
 // wave-uniform tile base (scalar registers) plus a 32-bit lane offset; edges past the end of the list (the last
@@ -357,12 +366,20 @@ __device__ __forceinline__ HalfIn load_half(const D16Params& a, const float* aux
   h.w_e = a.extra ? (a.extra + e_tile)[k] : 0.f;
   return h;
 }
-__device__ __forceinline__ void issue_half_rows(const D16Params& a, const HalfIn& in, int g, HalfRows& r) {
+__device__ __forceinline__ void issue_half_rows(const D16Params& a, const HalfIn& in, int g, HalfRowsT<false>& r) {
   const uint32_t po = in.poff + 32u * g, qo = in.qoff + 32u * g;
 #pragma unroll
   for (int x = 0; x < 4; ++x) {                          // x = 2 ks + half: k = 32 ks + 8 g + 4 half ..
     r.p[x] = ld_row16(a.p, po + 128u * (x >> 1) + 16u * (x & 1));
     r.q[x] = ld_row16(a.q, qo + 128u * (x >> 1) + 16u * (x & 1));
+  }
+}
+__device__ __forceinline__ void issue_half_rows(const D16Params& a, const HalfIn& in, int g, HalfRowsT<true>& r) {
+  const uint32_t po = in.poff + 16u * g, qo = in.qoff + 16u * g;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {                       // 8 bf16 = 16 bytes: k = 32 ks + 8 g ..
+    r.p[ks] = ld_row16u(a.p, po + 64u * ks);
+    r.q[ks] = ld_row16u(a.q, qo + 64u * ks);
   }
 }
 
@@ -423,8 +440,7 @@ __device__ __forceinline__ float p1_logit(const char* lds, const float (&h)[2][8
   return xsum32(xsum16(part)) + b3v;
 }
 // h1 fragments from the gathered row pieces: h = relu(p + q (+ w_e c))
-__device__ __forceinline__ void h1_frags(const HalfRows& rows, bool has_extra, float w_e, const float* cvl, int g,
-                                         float (&h)[2][8]) {
+__device__ __forceinline__ void sum_rows(const HalfRowsT<false>& rows, float (&h)[2][8]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -435,6 +451,23 @@ __device__ __forceinline__ void h1_frags(const HalfRows& rows, bool has_extra, f
       h[ks][4 * hf + 2] = pv.z + qv.z;
       h[ks][4 * hf + 3] = pv.w + qv.w;
     }
+}
+__device__ __forceinline__ void sum_rows(const HalfRowsT<true>& rows, float (&h)[2][8]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t pw[4] = {rows.p[ks].x, rows.p[ks].y, rows.p[ks].z, rows.p[ks].w};
+    const uint32_t qw[4] = {rows.q[ks].x, rows.q[ks].y, rows.q[ks].z, rows.q[ks].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[ks][2 * j] = __builtin_bit_cast(float, pw[j] << 16) + __builtin_bit_cast(float, qw[j] << 16);
+      h[ks][2 * j + 1] = __builtin_bit_cast(float, pw[j] & 0xffff0000u) + __builtin_bit_cast(float, qw[j] & 0xffff0000u);
+    }
+  }
+}
+template <bool PQ16>
+__device__ __forceinline__ void h1_frags(const HalfRowsT<PQ16>& rows, bool has_extra, float w_e, const float* cvl, int g,
+                                         float (&h)[2][8]) {
+  sum_rows(rows, h);
   if (has_extra) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -447,7 +480,7 @@ __device__ __forceinline__ void h1_frags(const HalfRows& rows, bool has_extra, f
     for (int s = 0; s < 8; ++s) h[ks][s] = relu1(h[ks][s]);
 }
 
-template <bool FUSED_LOSS, bool RUNSUM>
+template <bool FUSED_LOSS, bool RUNSUM, bool PQ16 = false>
 __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     D16Params a, const float* __restrict__ g_logits, D16Loss lp, float* __restrict__ logits, D16Run rs,
     uint32_t* __restrict__ rec, float* __restrict__ slabs, int64_t n_tiles) {
@@ -500,7 +533,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   const int64_t stride = (int64_t)gridDim.x * S_WAVES;
   int64_t tile = (int64_t)blockIdx.x * S_WAVES + wave;
   HalfIn in_cur = load_half(a, auxp, tile, n_tiles, 0, c);
-  HalfRows rows;
+  HalfRowsT<PQ16> rows;
   issue_half_rows(a, in_cur, g, rows);
   int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile] : 0;
 
@@ -890,6 +923,7 @@ __device__ __forceinline__ HalfIn load_tile16(const D16Params& a, int64_t tile, 
   h.w_e = a.extra ? (a.extra + e_tile)[k] : 0.f;
   return h;
 }
+template <bool PQ16>
 __global__ __launch_bounds__(I_WAVES * 64) void decoder_infer16_kernel(D16Params a, float* __restrict__ logits,
                                                                       int64_t n_tiles) {
   // LDS: W2 hi | mid | lo at LDS_W2 (the W2' slot stays unused), vectors at LDS_VEC
@@ -907,7 +941,7 @@ __global__ __launch_bounds__(I_WAVES * 64) void decoder_infer16_kernel(D16Params
   int64_t tile = (int64_t)blockIdx.x * I_WAVES + wave;
   HalfIn cur = load_tile16(a, tile, n_tiles, c);
   HalfIn nxt = load_tile16(a, tile + stride, n_tiles, c);
-  HalfRows rows;
+  HalfRowsT<PQ16> rows;
   issue_half_rows(a, cur, g, rows);
   for (; tile < n_tiles; tile += stride) {
     float h[2][8];
@@ -952,17 +986,26 @@ static int cu_count() {
 
 namespace pangnn {
 // decoder.hip (pangnn_decoder_mlp_infer_f32, precision = 1) -> the 16-edge-tile inference kernel of this file
-int launch_decoder_infer16(const float* p, int64_t ldp, const float* q, int64_t ldq, const int64_t* edge_index, int64_t ld,
-                           int64_t num_edges, const float* extra, const float* cvec, const float* w2, const float* b2,
-                           const float* w3, const float* b3, float* logits, hipStream_t s) {
+static int launch_infer16_any(const void* p, int64_t ldp, const void* q, int64_t ldq, bool pq16, const int64_t* edge_index,
+                              int64_t ld, int64_t num_edges, const float* extra, const float* cvec, const float* w2,
+                              const float* b2, const float* w3, const float* b3, float* logits, hipStream_t s) {
   const int64_t n_tiles = (num_edges + 15) / 16;
   int64_t grid = (n_tiles + I_WAVES - 1) / I_WAVES;
   const int cus = cu_count();
   if (grid > cus) grid = cus;
-  D16Params a{p, q, (uint32_t)(ldp * 4), (uint32_t)(ldq * 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
-  hipLaunchKernelGGL(decoder_infer16_kernel, dim3((unsigned)grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles);
-  PG_CHECK_LAUNCH("pangnn_decoder_mlp_infer_f32");
+  const uint32_t esz = pq16 ? 2u : 4u;
+  D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  if (pq16)
+    hipLaunchKernelGGL(decoder_infer16_kernel<true>, dim3((unsigned)grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles);
+  else
+    hipLaunchKernelGGL(decoder_infer16_kernel<false>, dim3((unsigned)grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles);
+  PG_CHECK_LAUNCH("pangnn_decoder_mlp_infer");
   return 0;
+}
+int launch_decoder_infer16(const float* p, int64_t ldp, const float* q, int64_t ldq, const int64_t* edge_index, int64_t ld,
+                           int64_t num_edges, const float* extra, const float* cvec, const float* w2, const float* b2,
+                           const float* w3, const float* b3, float* logits, hipStream_t s) {
+  return launch_infer16_any(p, ldp, q, ldq, false, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3, logits, s);
 }
 }  // namespace pangnn
 
@@ -976,20 +1019,44 @@ extern "C" int pangnn_debug_set_v(float* ptr) {
 
 extern "C" size_t pangnn_decoder_train_workspace_bytes(void) { return (size_t)cu_count() * SLAB16 * sizeof(float); }
 
-extern "C" int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
-                                        const int64_t* edge_index, int64_t ld, int64_t num_edges, const float* extra,
-                                        const float* cvec, const float* w2, const float* b2, const float* w3,
-                                        const float* b3, int32_t D, const float* y, const float* pos_weight,
-                                        int64_t denom, const float* g_logits, float* logits, float* loss,
-                                        uint32_t* rec, float* part_buf, const int32_t* part_off, float* g_w2,
-                                        float* g_w3, float* g_b3, float* g_cvec, void* workspace,
-                                        size_t workspace_bytes, pangnn_stream_t stream) {
-  const char* who = "pangnn_decoder_train_f32";
+extern "C" int pangnn_decoder_mlp_infer_mixed(const void* p, int64_t ldp, const void* q, int64_t ldq, int32_t pq_dtype,
+                                             int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                                             const float* extra, const float* cvec, const float* w2, const float* b2,
+                                             const float* w3, const float* b3, int32_t D, float* logits,
+                                             pangnn_stream_t stream) {
+  const char* who = "pangnn_decoder_mlp_infer_mixed";
+  const bool pq16 = pq_dtype == PANGNN_DTYPE_BF16;
+  PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16", who);
   PG_CHECK_ARG(D == D16, PANGNN_E_BADARG, "%s: built for node_dim 64, got %d", who, (int)D);
   PG_CHECK_ARG(num_edges >= 0 && ld >= num_edges && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
-  PG_CHECK_ARG(ldp >= D16 && ldq >= D16 && ldp % 4 == 0 && ldq % 4 == 0, PANGNN_E_BADARG,
-               "%s: ldp / ldq must be multiples of 4 and >= 64", who);
-  PG_CHECK_ARG((double)num_nodes * (double)(ldp > ldq ? ldp : ldq) * 4.0 < 4294967296.0, PANGNN_E_TOOLARGE,
+  PG_CHECK_ARG(ldp >= D16 && ldq >= D16 && ldp % 8 == 0 && ldq % 8 == 0, PANGNN_E_BADARG,
+               "%s: ldp / ldq must be multiples of 8 and >= 64", who);
+  PG_CHECK_ARG((double)num_nodes * (double)(ldp > ldq ? ldp : ldq) * (pq16 ? 2.0 : 4.0) < 4294967296.0, PANGNN_E_TOOLARGE,
+               "%s: node tables must stay under 4 GiB (32-bit gather offsets)", who);
+  if (num_edges == 0) return 0;
+  PG_CHECK_ARG(p && q && edge_index && w2 && b2 && w3 && b3 && logits && (!extra || cvec), PANGNN_E_BADARG,
+               "%s: null pointer", who);
+  PG_CHECK_ARG(aligned16(p) && aligned16(q) && aligned16(w2), PANGNN_E_ALIGN, "%s: p / q / w2 must be 16-byte aligned", who);
+  return launch_infer16_any(p, ldp, q, ldq, pq16, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3, logits,
+                            (hipStream_t)stream);
+}
+
+extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void* q, int64_t ldq, int32_t pq_dtype,
+                                          int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
+                                          const float* extra, const float* cvec, const float* w2, const float* b2,
+                                          const float* w3, const float* b3, int32_t D, const float* y,
+                                          const float* pos_weight, int64_t denom, const float* g_logits, float* logits,
+                                          float* loss, uint32_t* rec, float* part_buf, const int32_t* part_off,
+                                          float* g_w2, float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                          size_t workspace_bytes, pangnn_stream_t stream) {
+  const char* who = "pangnn_decoder_train";
+  const bool pq16 = pq_dtype == PANGNN_DTYPE_BF16;
+  PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  PG_CHECK_ARG(D == D16, PANGNN_E_BADARG, "%s: built for node_dim 64, got %d", who, (int)D);
+  PG_CHECK_ARG(num_edges >= 0 && ld >= num_edges && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
+  PG_CHECK_ARG(ldp >= D16 && ldq >= D16 && ldp % (pq16 ? 8 : 4) == 0 && ldq % (pq16 ? 8 : 4) == 0, PANGNN_E_BADARG,
+               "%s: ldp / ldq must be multiples of 4 (f32) / 8 (bf16) and >= 64", who);
+  PG_CHECK_ARG((double)num_nodes * (double)(ldp > ldq ? ldp : ldq) * (pq16 ? 2.0 : 4.0) < 4294967296.0, PANGNN_E_TOOLARGE,
                "%s: node tables must stay under 4 GiB (32-bit gather offsets)", who);
   PG_CHECK_ARG(g_w2 && g_w3 && g_b3, PANGNN_E_BADARG, "%s: null gradient output", who);
   PG_CHECK_ARG((y != nullptr) != (g_logits != nullptr) || num_edges == 0, PANGNN_E_BADARG,
@@ -1015,21 +1082,40 @@ extern "C" int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float
     PG_CHECK_ARG(aligned16(p) && aligned16(q) && aligned16(w2), PANGNN_E_ALIGN, "%s: p / q / w2 must be 16-byte aligned",
                  who);
     PG_CHECK_ARG(!rec || aligned16(rec), PANGNN_E_ALIGN, "%s: rec must be 16-byte aligned", who);
-    D16Params a{p, q, (uint32_t)(ldp * 4), (uint32_t)(ldq * 4), edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+    const uint32_t esz = pq16 ? 2u : 4u;
+    D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
     const D16Loss lp{y, pos_weight, y ? 1.0f / (float)denom : 0.f};
     const D16Run rs{part_buf, part_off};
     const dim3 gd((unsigned)grid), bd(S_WAVES * 64);
-    if (y && part_buf)
-      hipLaunchKernelGGL((decoder_train16_kernel<true, true>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
-    else if (y)
-      hipLaunchKernelGGL((decoder_train16_kernel<true, false>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
-    else if (part_buf)
-      hipLaunchKernelGGL((decoder_train16_kernel<false, true>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
-    else
-      hipLaunchKernelGGL((decoder_train16_kernel<false, false>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);
+#define PG_S(F, R, H) hipLaunchKernelGGL((decoder_train16_kernel<F, R, H>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles)
+    if (pq16) {
+      if (y && part_buf) PG_S(true, true, true);
+      else if (y) PG_S(true, false, true);
+      else if (part_buf) PG_S(false, true, true);
+      else PG_S(false, false, true);
+    } else {
+      if (y && part_buf) PG_S(true, true, false);
+      else if (y) PG_S(true, false, false);
+      else if (part_buf) PG_S(false, true, false);
+      else PG_S(false, false, false);
+    }
+#undef PG_S
     PG_CHECK_LAUNCH(who);
   }
   return launch_decoder_reduce(ws, (int)grid, g_w2, nullptr, g_w3, g_cvec, g_b3, loss, s);
+}
+
+extern "C" int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
+                                        const int64_t* edge_index, int64_t ld, int64_t num_edges, const float* extra,
+                                        const float* cvec, const float* w2, const float* b2, const float* w3,
+                                        const float* b3, int32_t D, const float* y, const float* pos_weight,
+                                        int64_t denom, const float* g_logits, float* logits, float* loss,
+                                        uint32_t* rec, float* part_buf, const int32_t* part_off, float* g_w2,
+                                        float* g_w3, float* g_b3, float* g_cvec, void* workspace,
+                                        size_t workspace_bytes, pangnn_stream_t stream) {
+  return pangnn_decoder_train_mixed(p, ldp, q, ldq, PANGNN_DTYPE_F32, num_nodes, edge_index, ld, num_edges, extra, cvec,
+                                    w2, b2, w3, b3, D, y, pos_weight, denom, g_logits, logits, loss, rec, part_buf,
+                                    part_off, g_w2, g_w3, g_b3, g_cvec, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t pangnn_decoder_dgrad_workspace_bytes(void) { return (size_t)cu_count() * 128 * sizeof(float); }

@@ -45,39 +45,78 @@ __device__ __forceinline__ void st_f32(float* ubase, uint32_t byte_off, float v)
   *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byte_off) = v;
 }
 
+// ---- storage types.  Arithmetic is fp32 everywhere (f32 MFMA); a matrix may be STORED as bfloat16 (config 5's
+// autocast: the reference's Linear outputs are bf16 tensors, gnn.py:93,111,173 under accelerate's mixed precision):
+// half the HBM bytes of the row streams these kernels are bound by.  bf16 -> f32 is a shift, f32 -> bf16 rounds to
+// nearest even.  Elem<T>: 4 consecutive elements as raw registers (converted only when they go to LDS, so the
+// prefetch distance of the f32 path is kept), one element in / out for the strided epilogue accesses.
+typedef unsigned short bf16s;
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  typedef float4 raw4;
+  static __device__ __forceinline__ raw4 ld4(const float* ubase, uint32_t byte_off) { return ld_f4(ubase, byte_off); }
+  static __device__ __forceinline__ raw4 ld4_plain(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ raw4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ float4 cvt4(raw4 r) { return r; }
+  static __device__ __forceinline__ float ld1(const float* ubase, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + byte_off);
+  }
+  static __device__ __forceinline__ void st1(float* ubase, uint32_t byte_off, float v) { st_f32(ubase, byte_off, v); }
+};
+template <> struct Elem<bf16s> {
+  typedef uint2 raw4;
+  static __device__ __forceinline__ raw4 ld4(const bf16s* ubase, uint32_t byte_off) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(ubase) + byte_off));
+    return make_uint2(t[0], t[1]);
+  }
+  static __device__ __forceinline__ raw4 ld4_plain(const bf16s* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ raw4 zero4() { return make_uint2(0u, 0u); }
+  static __device__ __forceinline__ float4 cvt4(raw4 r) {
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ float ld1(const bf16s* ubase, uint32_t byte_off) {
+    return __uint_as_float((uint32_t)*reinterpret_cast<const bf16s*>(reinterpret_cast<const char*>(ubase) + byte_off) << 16);
+  }
+  static __device__ __forceinline__ void st1(bf16s* ubase, uint32_t byte_off, float v) {
+    *reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ubase) + byte_off) = (__bf16)v;     // round to nearest even
+  }
+};
+
 // rows [base, base+32) of a [n, C] matrix (leading dim ld): issued into registers one tile ahead
 // (`load_rows`), written to the LDS tile [32][C+4] when the previous tile's MFMAs are done
 // (`store_rows`); rows >= n are zero.
-template <int C>
-struct RowRegs { float4 v[32 / (64 / (C / 4))]; };
+template <int C, typename T = float>
+struct RowRegs { typename Elem<T>::raw4 v[32 / (64 / (C / 4))]; };
 
-template <int C>
-__device__ __forceinline__ void load_rows_full(const float* __restrict__ src, int64_t ld, int64_t base, int lane,
-                                               RowRegs<C>& rg) {      // whole tile inside the matrix: no predicate
+template <int C, typename T>
+__device__ __forceinline__ void load_rows_full(const T* __restrict__ src, int64_t ld, int64_t base, int lane,
+                                               RowRegs<C, T>& rg) {   // whole tile inside the matrix: no predicate
   constexpr int LPR = C / 4;            // lanes per row
   constexpr int RPI = 64 / LPR;         // rows per wave-instruction
   const int c4 = lane % LPR, r0 = lane / LPR;
-  uint32_t loff = ((uint32_t)r0 * (uint32_t)ld + 4u * c4) * 4u;
+  uint32_t loff = ((uint32_t)r0 * (uint32_t)ld + 4u * c4) * (uint32_t)sizeof(T);
   pin(base, loff);
 #pragma unroll
-  for (int i = 0; i < 32 / RPI; ++i) rg.v[i] = ld_f4(src + (base + i * RPI) * ld, loff);
+  for (int i = 0; i < 32 / RPI; ++i) rg.v[i] = Elem<T>::ld4(src + (base + i * RPI) * ld, loff);
 }
 
-template <int C>
-__device__ __forceinline__ void load_rows(const float* __restrict__ src, int64_t ld, int64_t n, int64_t base,
-                                          int lane, RowRegs<C>& rg) {
+template <int C, typename T>
+__device__ __forceinline__ void load_rows(const T* __restrict__ src, int64_t ld, int64_t n, int64_t base,
+                                          int lane, RowRegs<C, T>& rg) {
   constexpr int LPR = C / 4;
   constexpr int RPI = 64 / LPR;
   const int c4 = lane % LPR, r0 = lane / LPR;
   if (base + 32 <= n) {                 // wave-uniform
-    load_rows_full<C>(src, ld, base, lane, rg);
+    load_rows_full<C, T>(src, ld, base, lane, rg);
     return;
   }
 #pragma unroll
   for (int i = 0; i < 32 / RPI; ++i) {
     const int row = i * RPI + r0;
-    rg.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (base + row < n) rg.v[i] = *reinterpret_cast<const float4*>(src + (base + row) * ld + 4 * c4);
+    rg.v[i] = Elem<T>::zero4();
+    if (base + row < n) rg.v[i] = Elem<T>::ld4_plain(src + (base + row) * ld + 4 * c4);
   }
 }
 
@@ -87,15 +126,15 @@ __device__ __forceinline__ float elu1_grad(float v) { return v > 0.f ? 1.f : __e
 
 // ACT = 1: the rows go through ELU on their way to LDS, i.e. the kernel multiplies elu(x) without elu(x) ever
 // existing in HBM (gnn.py:131-166: every activation of the encoder is followed by exactly one dense layer)
-template <int C, int ACT = 0>
-__device__ __forceinline__ void store_rows(const RowRegs<C>& rg, int lane, float* tile) {
+template <int C, int ACT = 0, typename T = float>
+__device__ __forceinline__ void store_rows(const RowRegs<C, T>& rg, int lane, float* tile) {
   constexpr int LPR = C / 4;
   constexpr int RPI = 64 / LPR;
   constexpr int RS = C + 4;
   const int c4 = lane % LPR, r0 = lane / LPR;
 #pragma unroll
   for (int i = 0; i < 32 / RPI; ++i) {
-    float4 v = rg.v[i];
+    float4 v = Elem<T>::cvt4(rg.v[i]);
     if (ACT == 1) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
     *reinterpret_cast<float4*>(tile + (i * RPI + r0) * RS + 4 * c4) = v;
   }
@@ -165,12 +204,13 @@ __device__ __forceinline__ void tile_product(const float* Xt, const float* Wl, i
 // The one partial tile at the end of the matrix is handled after the loop by the wave whose turn it is.
 // ACT: input activation (0 none, 1 ELU).  GATE: the result is multiplied by elu'(gate[row][col]) — the backward of
 // "dense layer after ELU" w.r.t. the pre-activation, produced directly by the dL/dx product.
-template <int K, int M, int ACT, bool GATE>
-__global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+// TX / TY / TG: storage types of x, y and gate (float or bf16s).
+template <int K, int M, int ACT, bool GATE, typename TX = float, typename TY = float, typename TG = float>
+__global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(const TX* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
-                                                         float* __restrict__ y, int64_t ldy, int64_t n,
-                                                         int64_t n_tiles, const float* __restrict__ gate,
+                                                         TY* __restrict__ y, int64_t ldy, int64_t n,
+                                                         int64_t n_tiles, const TG* __restrict__ gate,
                                                          int64_t ldgate) {
   constexpr int KS = K + 4;
   constexpr int WAVES = FwdGeo<K, M>::WAVES;
@@ -191,55 +231,54 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
 #pragma unroll
   for (int b = 0; b < M / 32; ++b) bv[b] = bias ? bias[r + 32 * b] : 0.f;
   f32x16 acc[M / 32];
-  RowRegs<K> rg;
+  RowRegs<K, TX> rg;
   if (tile < n_full) {
     const int64_t last = n_full - 1;
-    load_rows_full<K>(x, ldx, tile * 32, lane, rg);
-    store_rows<K, ACT>(rg, lane, Xt);
-    load_rows_full<K>(x, ldx, (tile + stride < last ? tile + stride : last) * 32, lane, rg);
+    load_rows_full<K, TX>(x, ldx, tile * 32, lane, rg);
+    store_rows<K, ACT, TX>(rg, lane, Xt);
+    load_rows_full<K, TX>(x, ldx, (tile + stride < last ? tile + stride : last) * 32, lane, rg);
     wave_sync_lds();
     for (; tile < n_full; tile += stride) {
       // GATE: the tile's gate values are fetched before the product so that they land behind the MFMAs (fetched
       // in the epilogue, one load-and-use at a time, the 128-wide variant took 0.98 ms instead of 0.17)
       float gv[GATE ? M / 32 : 1][16];
       if (GATE) {
-        uint32_t goff = (4u * hh * (uint32_t)ldgate + r) * 4u;
+        uint32_t goff = (4u * hh * (uint32_t)ldgate + r) * (uint32_t)sizeof(TG);
         int64_t gbase = tile * 32;
         pin(gbase, goff);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float* gr = gate + (gbase + (i & 3) + 8 * (i >> 2)) * ldgate;
+          const TG* gr = gate + (gbase + (i & 3) + 8 * (i >> 2)) * ldgate;
 #pragma unroll
-          for (int b = 0; b < M / 32; ++b)
-            gv[b][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gr + 32 * b) + goff);
+          for (int b = 0; b < M / 32; ++b) gv[b][i] = Elem<TG>::ld1(gr + 32 * b, goff);
         }
       }
       tile_product<K, M>(Xt, Wl, r, hh, acc);
       // C[row = jrow(i,hh)][m = r + 32b]: 128-byte row segments
-      uint32_t loff = (4u * hh * (uint32_t)ldy + r) * 4u;
+      uint32_t loff = (4u * hh * (uint32_t)ldy + r) * (uint32_t)sizeof(TY);
       int64_t sbase = tile * 32;
       pin(sbase, loff);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float* yr = y + (sbase + (i & 3) + 8 * (i >> 2)) * ldy;           // scalar
+        TY* yr = y + (sbase + (i & 3) + 8 * (i >> 2)) * ldy;              // scalar
 #pragma unroll
         for (int b = 0; b < M / 32; ++b) {
           float v = acc[b][i] + bv[b];
           if (GATE) v *= elu1_grad(gv[b][i]);
-          st_f32(yr + 32 * b, loff, v);
+          Elem<TY>::st1(yr + 32 * b, loff, v);
         }
       }
-      store_rows<K, ACT>(rg, lane, Xt);               // tile + stride (see the pipeline note)
+      store_rows<K, ACT, TX>(rg, lane, Xt);           // tile + stride (see the pipeline note)
       const int64_t nxt = tile + 2 * stride;
-      load_rows_full<K>(x, ldx, (nxt < last ? nxt : last) * 32, lane, rg);
+      load_rows_full<K, TX>(x, ldx, (nxt < last ? nxt : last) * 32, lane, rg);
       wave_sync_lds();
     }
   }
   if (tile == n_full && n_full < n_tiles) {            // the partial tile, rows [32 n_full, n)
     const int64_t base = n_full * 32;
-    load_rows<K>(x, ldx, n, base, lane, rg);
+    load_rows<K, TX>(x, ldx, n, base, lane, rg);
     wave_sync_lds();
-    store_rows<K, ACT>(rg, lane, Xt);
+    store_rows<K, ACT, TX>(rg, lane, Xt);
     wave_sync_lds();
     tile_product<K, M>(Xt, Wl, r, hh, acc);
 #pragma unroll
@@ -249,8 +288,8 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
         const int64_t row = base + jrow(i, hh);
         if (row < n) {
           float v = acc[b][i] + bv[b];
-          if (GATE) v *= elu1_grad(gate[row * ldgate + r + 32 * b]);
-          y[row * ldy + r + 32 * b] = v;
+          if (GATE) v *= elu1_grad(Elem<TG>::ld1(gate + row * ldgate + r + 32 * b, 0u));
+          Elem<TY>::st1(y + row * ldy + r + 32 * b, 0u, v);
         }
       }
   }
@@ -261,9 +300,9 @@ struct WgradGeo {
   static constexpr int SLAB = M * K + M;     // gw | gb
 };
 
-template <int K, int M, int ACT>
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ g, int64_t ldg,
-                                                           const float* __restrict__ x, int64_t ldx,
+template <int K, int M, int ACT, typename TG = float, typename TX = float>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const TG* __restrict__ g, int64_t ldg,
+                                                           const TX* __restrict__ x, int64_t ldx,
                                                            int64_t n, int64_t n_tiles,
                                                            float* __restrict__ slabs) {
   constexpr int KS = K + 4, MS = M + 4;
@@ -287,15 +326,15 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   }
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  RowRegs<K> rx;
-  RowRegs<M> rgm;
-  load_rows<K>(x, ldx, n, tile * 32, lane, rx);
-  load_rows<M>(g, ldg, n, tile * 32, lane, rgm);
+  RowRegs<K, TX> rx;
+  RowRegs<M, TG> rgm;
+  load_rows<K, TX>(x, ldx, n, tile * 32, lane, rx);
+  load_rows<M, TG>(g, ldg, n, tile * 32, lane, rgm);
   for (; tile < n_tiles; tile += stride) {
-    store_rows<K, ACT>(rx, lane, Xt);
-    store_rows<M>(rgm, lane, Gt);
-    load_rows<K>(x, ldx, n, (tile + stride) * 32, lane, rx);
-    load_rows<M>(g, ldg, n, (tile + stride) * 32, lane, rgm);
+    store_rows<K, ACT, TX>(rx, lane, Xt);
+    store_rows<M, 0, TG>(rgm, lane, Gt);
+    load_rows<K, TX>(x, ldx, n, (tile + stride) * 32, lane, rx);
+    load_rows<M, TG>(g, ldg, n, (tile + stride) * 32, lane, rgm);
     wave_sync_lds();
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -357,28 +396,50 @@ static int num_cus() {
   return 256;
 }
 
-template <int K, int M>
-static int launch_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
-                      int64_t n, int in_act, const float* gate, int64_t ldgate, hipStream_t s) {
+template <int K, int M, typename TX, typename TY, typename TG>
+static int launch_fwd_t(const void* x, int64_t ldx, const float* w, const float* bias, void* y, int64_t ldy, int64_t n,
+                        int in_act, const void* gate, int64_t ldgate, hipStream_t s) {
   constexpr int WAVES = FwdGeo<K, M>::WAVES;
   const int64_t n_tiles = (n + 31) / 32;
   int64_t grid = (n_tiles + WAVES - 1) / WAVES;
   const int64_t cap = (int64_t)num_cus();          // one workgroup per CU fills its LDS
   if (grid > cap) grid = cap;
   const dim3 g((unsigned)grid), b(WAVES * 64);
+  const TX* xp = static_cast<const TX*>(x);
+  TY* yp = static_cast<TY*>(y);
+  const TG* gp = static_cast<const TG*>(gate);
   if (gate)
-    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, true>), g, b, 0, s, x, ldx, w, bias, y, ldy, n, n_tiles, gate, ldgate);
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, true, TX, TY, TG>), g, b, 0, s, xp, ldx, w, bias, yp, ldy, n, n_tiles, gp, ldgate);
   else if (in_act)
-    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 1, false>), g, b, 0, s, x, ldx, w, bias, y, ldy, n, n_tiles, gate, ldgate);
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 1, false, TX, TY, float>), g, b, 0, s, xp, ldx, w, bias, yp, ldy, n, n_tiles,
+                       static_cast<const float*>(nullptr), ldgate);
   else
-    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, false>), g, b, 0, s, x, ldx, w, bias, y, ldy, n, n_tiles, gate, ldgate);
-  PG_CHECK_LAUNCH("pangnn_linear_fwd_f32");
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, false, TX, TY, float>), g, b, 0, s, xp, ldx, w, bias, yp, ldy, n, n_tiles,
+                       static_cast<const float*>(nullptr), ldgate);
+  PG_CHECK_LAUNCH("pangnn_linear_fwd");
   return 0;
 }
 
+// storage-type dispatch.  A gated product (dL/dx of "dense after ELU") writes the gradient of the gate tensor, so its
+// result is stored like the gate: (TG, TY) is (f32, f32) or (bf16, bf16).
 template <int K, int M>
-static int launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n, int in_act, float* gw,
-                        float* gb, float* ws, size_t ws_bytes, hipStream_t s) {
+static int launch_fwd(const void* x, int x_bf16, int64_t ldx, const float* w, const float* bias, void* y, int y_bf16,
+                      int64_t ldy, int64_t n, int in_act, const void* gate, int gate_bf16, int64_t ldgate, hipStream_t s) {
+#define PG_FWD(TX, TY, TG) return launch_fwd_t<K, M, TX, TY, TG>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s)
+  if (gate) {
+    if (gate_bf16) { if (x_bf16) PG_FWD(bf16s, bf16s, bf16s); PG_FWD(float, bf16s, bf16s); }
+    if (x_bf16) PG_FWD(bf16s, float, float);
+    PG_FWD(float, float, float);
+  }
+  if (x_bf16) { if (y_bf16) PG_FWD(bf16s, bf16s, float); PG_FWD(bf16s, float, float); }
+  if (y_bf16) PG_FWD(float, bf16s, float);
+  PG_FWD(float, float, float);
+#undef PG_FWD
+}
+
+template <int K, int M, typename TG, typename TX>
+static int launch_wgrad_t(const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t n, int in_act, float* gw,
+                          float* gb, float* ws, size_t ws_bytes, hipStream_t s) {
   constexpr int SLAB = WgradGeo<K, M>::SLAB;
   const int64_t n_tiles = (n + 31) / 32;
   int64_t grid = (n_tiles + 3) / 4;
@@ -386,18 +447,30 @@ static int launch_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   PG_CHECK_ARG(ws && ws_bytes >= (size_t)grid * SLAB * sizeof(float), PANGNN_E_WORKSPACE,
-               "pangnn_linear_wgrad_f32: workspace too small");
+               "pangnn_linear_wgrad: workspace too small");
+  const TG* gp = static_cast<const TG*>(g);
+  const TX* xp = static_cast<const TX*>(x);
   if (in_act)
-    hipLaunchKernelGGL((linear_wgrad_kernel<K, M, 1>), dim3((unsigned)grid), dim3(256), 0, s, g, ldg, x, ldx, n,
+    hipLaunchKernelGGL((linear_wgrad_kernel<K, M, 1, TG, TX>), dim3((unsigned)grid), dim3(256), 0, s, gp, ldg, xp, ldx, n,
                        n_tiles, ws);
   else
-    hipLaunchKernelGGL((linear_wgrad_kernel<K, M, 0>), dim3((unsigned)grid), dim3(256), 0, s, g, ldg, x, ldx, n,
+    hipLaunchKernelGGL((linear_wgrad_kernel<K, M, 0, TG, TX>), dim3((unsigned)grid), dim3(256), 0, s, gp, ldg, xp, ldx, n,
                        n_tiles, ws);
-  PG_CHECK_LAUNCH("pangnn_linear_wgrad_f32");
+  PG_CHECK_LAUNCH("pangnn_linear_wgrad");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB + kWave - 1) / kWave), dim3(kSumThreads), 0, s, ws, (int)grid,
                      SLAB, M * K, gw, gb);
-  PG_CHECK_LAUNCH("pangnn_linear_wgrad_f32(reduce)");
+  PG_CHECK_LAUNCH("pangnn_linear_wgrad(reduce)");
   return 0;
+}
+
+template <int K, int M>
+static int launch_wgrad(const void* g, int g_bf16, int64_t ldg, const void* x, int x_bf16, int64_t ldx, int64_t n,
+                        int in_act, float* gw, float* gb, float* ws, size_t ws_bytes, hipStream_t s) {
+#define PG_WG(TG, TX) return launch_wgrad_t<K, M, TG, TX>(g, ldg, x, ldx, n, in_act, gw, gb, ws, ws_bytes, s)
+  if (g_bf16) { if (x_bf16) PG_WG(bf16s, bf16s); PG_WG(bf16s, float); }
+  if (x_bf16) PG_WG(float, bf16s);
+  PG_WG(float, float);
+#undef PG_WG
 }
 
 }  // namespace pangnn
@@ -411,23 +484,39 @@ extern "C" int pangnn_linear_supported(int32_t K, int32_t M, int wgrad) {
   return 1;
 }
 
+static bool dtype_ok(int32_t d) { return d == PANGNN_DTYPE_F32 || d == PANGNN_DTYPE_BF16; }
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+extern "C" int pangnn_linear_act_fwd_mixed(const void* x, int32_t x_dtype, int64_t ldx, const float* w, const float* bias,
+                                           void* y, int32_t y_dtype, int64_t ldy, int64_t n, int32_t K, int32_t M,
+                                           int32_t in_act, const void* gate, int32_t gate_dtype, int64_t ldgate,
+                                           pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_fwd: negative size");
+  PG_CHECK_ARG(pangnn_linear_supported(K, M, 0), PANGNN_E_BADARG,
+               "pangnn_linear_fwd: K and M must be 64 or 128 (got %d, %d)", (int)K, (int)M);
+  PG_CHECK_ARG(dtype_ok(x_dtype) && dtype_ok(y_dtype) && (!gate || dtype_ok(gate_dtype)), PANGNN_E_BADARG,
+               "pangnn_linear_fwd: storage types are PANGNN_DTYPE_F32 / PANGNN_DTYPE_BF16");
+  PG_CHECK_ARG((in_act == 0 || in_act == 1) && !(in_act && gate) && (!gate || ldgate >= M), PANGNN_E_BADARG,
+               "pangnn_linear_act_fwd: in_act must be 0 or 1 (ELU) and excludes gate; ldgate >= M");
+  PG_CHECK_ARG(!gate || gate_dtype == y_dtype, PANGNN_E_BADARG,
+               "pangnn_linear_act_fwd: a gated product is stored like its gate (it is the gate tensor's gradient)");
+  if (n == 0) return 0;
+  PG_CHECK_ARG(x && w && y && ldx >= K && ldy >= M, PANGNN_E_BADARG, "pangnn_linear_fwd: bad pointer / ld");
+  PG_CHECK_ARG((x_dtype == PANGNN_DTYPE_BF16 ? aligned8(x) : aligned16(x)) && aligned16(w) && ldx % 4 == 0,
+               PANGNN_E_ALIGN, "pangnn_linear_fwd: x rows must start on 16 bytes (f32) / 8 bytes (bf16), w on 16, ldx % 4 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int xb = x_dtype == PANGNN_DTYPE_BF16, yb = y_dtype == PANGNN_DTYPE_BF16, gb = gate_dtype == PANGNN_DTYPE_BF16;
+  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  return launch_fwd<128, 128>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+}
+
 extern "C" int pangnn_linear_act_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
                                          int64_t ldy, int64_t n, int32_t K, int32_t M, int32_t in_act,
                                          const float* gate, int64_t ldgate, pangnn_stream_t stream) {
-  PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_fwd_f32: negative size");
-  PG_CHECK_ARG(pangnn_linear_supported(K, M, 0), PANGNN_E_BADARG,
-               "pangnn_linear_fwd_f32: K and M must be 64 or 128 (got %d, %d)", (int)K, (int)M);
-  PG_CHECK_ARG((in_act == 0 || in_act == 1) && !(in_act && gate) && (!gate || ldgate >= M), PANGNN_E_BADARG,
-               "pangnn_linear_act_fwd_f32: in_act must be 0 or 1 (ELU) and excludes gate; ldgate >= M");
-  if (n == 0) return 0;
-  PG_CHECK_ARG(x && w && y && ldx >= K && ldy >= M, PANGNN_E_BADARG, "pangnn_linear_fwd_f32: bad pointer / ld");
-  PG_CHECK_ARG(aligned16(x) && aligned16(w) && ldx % 4 == 0, PANGNN_E_ALIGN,
-               "pangnn_linear_fwd_f32: x / w must be 16-byte aligned, ldx a multiple of 4");
-  hipStream_t s = (hipStream_t)stream;
-  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
-  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
-  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
-  return launch_fwd<128, 128>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s);
+  return pangnn_linear_act_fwd_mixed(x, PANGNN_DTYPE_F32, ldx, w, bias, y, PANGNN_DTYPE_F32, ldy, n, K, M, in_act, gate,
+                                     PANGNN_DTYPE_F32, ldgate, stream);
 }
 
 extern "C" int pangnn_linear_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
@@ -439,22 +528,33 @@ extern "C" size_t pangnn_linear_wgrad_workspace_bytes(int32_t K, int32_t M) {
   return (size_t)num_cus() * ((size_t)M * K + M) * sizeof(float);
 }
 
+extern "C" int pangnn_linear_act_wgrad_mixed(const void* g, int32_t g_dtype, int64_t ldg, const void* x, int32_t x_dtype,
+                                             int64_t ldx, int64_t n, int32_t K, int32_t M, int32_t in_act, float* gw,
+                                             float* gb, void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_wgrad: negative size");
+  PG_CHECK_ARG(pangnn_linear_supported(K, M, 1), PANGNN_E_BADARG,
+               "pangnn_linear_wgrad: unsupported (K, M) = (%d, %d)", (int)K, (int)M);
+  PG_CHECK_ARG(in_act == 0 || in_act == 1, PANGNN_E_BADARG, "pangnn_linear_act_wgrad: in_act must be 0 or 1");
+  PG_CHECK_ARG(dtype_ok(g_dtype) && dtype_ok(x_dtype), PANGNN_E_BADARG,
+               "pangnn_linear_wgrad: storage types are PANGNN_DTYPE_F32 / PANGNN_DTYPE_BF16");
+  PG_CHECK_ARG(gw && (n == 0 || (g && x)) && ldg >= M && ldx >= K, PANGNN_E_BADARG,
+               "pangnn_linear_wgrad: bad pointer / ld");
+  PG_CHECK_ARG((g_dtype == PANGNN_DTYPE_BF16 ? aligned8(g) : aligned16(g)) &&
+                   (x_dtype == PANGNN_DTYPE_BF16 ? aligned8(x) : aligned16(x)) && ldg % 4 == 0 && ldx % 4 == 0,
+               PANGNN_E_ALIGN, "pangnn_linear_wgrad: rows must start on 16 bytes (f32) / 8 bytes (bf16), ld multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = static_cast<float*>(workspace);
+  const int gbf = g_dtype == PANGNN_DTYPE_BF16, xbf = x_dtype == PANGNN_DTYPE_BF16;
+  if (K == 64 && M == 64) return launch_wgrad<64, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+  if (K == 64 && M == 128) return launch_wgrad<64, 128>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+  return launch_wgrad<128, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+}
+
 extern "C" int pangnn_linear_act_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,
                                            int32_t K, int32_t M, int32_t in_act, float* gw, float* gb,
                                            void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
-  PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_wgrad_f32: negative size");
-  PG_CHECK_ARG(pangnn_linear_supported(K, M, 1), PANGNN_E_BADARG,
-               "pangnn_linear_wgrad_f32: unsupported (K, M) = (%d, %d)", (int)K, (int)M);
-  PG_CHECK_ARG(in_act == 0 || in_act == 1, PANGNN_E_BADARG, "pangnn_linear_act_wgrad_f32: in_act must be 0 or 1");
-  PG_CHECK_ARG(gw && (n == 0 || (g && x)) && ldg >= M && ldx >= K, PANGNN_E_BADARG,
-               "pangnn_linear_wgrad_f32: bad pointer / ld");
-  PG_CHECK_ARG(aligned16(g) && aligned16(x) && ldg % 4 == 0 && ldx % 4 == 0, PANGNN_E_ALIGN,
-               "pangnn_linear_wgrad_f32: g / x must be 16-byte aligned, ld multiples of 4");
-  hipStream_t s = (hipStream_t)stream;
-  float* ws = static_cast<float*>(workspace);
-  if (K == 64 && M == 64) return launch_wgrad<64, 64>(g, ldg, x, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
-  if (K == 64 && M == 128) return launch_wgrad<64, 128>(g, ldg, x, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
-  return launch_wgrad<128, 64>(g, ldg, x, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+  return pangnn_linear_act_wgrad_mixed(g, PANGNN_DTYPE_F32, ldg, x, PANGNN_DTYPE_F32, ldx, n, K, M, in_act, gw, gb,
+                                       workspace, workspace_bytes, stream);
 }
 
 extern "C" int pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,

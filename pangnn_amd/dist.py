@@ -228,9 +228,10 @@ class HaloGather(torch.autograd.Function):
         g_halo = torch.cat([g[: plan.n_low], g[plan.n_low + plan.n_local:]], dim=0)
         back = torch.empty((plan.send_idx.numel(),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
         _all_to_all_v(back, g_halo, plan.send_splits, plan.recv_splits, plan.group)
-        g_local = g[plan.n_low: plan.n_low + plan.n_local].clone()
+        # a bf16-stored table (config 5) exchanges its gradient rows as bf16 too; the sums are fp32
+        g_local = g[plan.n_low: plan.n_low + plan.n_local].to(torch.float32, copy=True)
         if back.shape[0]:
-            ctx.acc(g_local, back, plan)
+            ctx.acc(g_local, back.float(), plan)
         return g_local, None, None
 
 
@@ -318,8 +319,8 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
 
         def send_back(gp_table):
             with _Side(dev, gp_table) as bwd:
-                g_halo = torch.cat([gp_table[:n_low], gp_table[n_low + n_loc:]], dim=0)
-                back = gp_table.new_empty((plan.send_idx.numel(), d))
+                g_halo = torch.cat([gp_table[:n_low], gp_table[n_low + n_loc:]], dim=0).to(p_local.dtype)
+                back = p_local.new_empty((plan.send_idx.numel(), d))    # travels in the table's storage type
                 _all_to_all_v(back, g_halo, plan.send_splits, plan.recv_splits, plan.group)
                 bwd.keep(back)
             box["bwd"], box["back"] = bwd, back
@@ -331,7 +332,7 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
         gp_local = gp_l[n_low:n_low + n_loc]                     # rows of halo sources are zero in gp_l
         box["bwd"].done()
         if box["back"].shape[0]:
-            ops.accumulate_back(gp_local, box["back"], plan)
+            ops.accumulate_back(gp_local, box["back"].float(), plan)
         gq = gq_l.add_(gq_h)
         small = [None if a is None else a + b for a, b in zip(r_loc[4:], r_halo[4:])]     # g_cv, g_w2, g_b2, g_w3, g_b3
         logits = plan.merge_edge_values(logit_l, logit_h)
@@ -423,12 +424,12 @@ class HipOps:
         f = PF._f32c
         pw = None if pos_weight is None else f(pos_weight).reshape(-1)
         loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = PF._decoder_train16(
-            PF._rows_f32(table), PF._rows_f32(q_local), st, None if extra is None else f(extra),
+            PF._rows_any(table), PF._rows_any(q_local), st, None if extra is None else f(extra),
             None if cvec is None else f(cvec), f(w2), f(b2), f(w3), f(b3), y=f(y), pw=pw, denom=denom, after_p=after_p)
         return loss.view(()), logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
 
-    def linear(self, x, w, b, in_act: int = 0):
-        return PF.linear(x, w, b, in_act)
+    def linear(self, x, w, b, in_act: int = 0, out_dtype=None):
+        return PF.linear(x, w, b, in_act, out_dtype)
 
     def bce_sum_over(self, logits, labels, pos_weight, denom):
         """sum_i BCEWithLogits_i / denom (this rank's share of the global mean)"""
@@ -526,8 +527,10 @@ class DistAlternateGCN(AlternateGCN):
             hit = cache[key] = (ident, self.ops.norm(self._st(shard, name), weight, gather), weight)
         return hit[1]
 
-    def _linear(self, x, w, b, in_act: int = 0):
-        return self.ops.linear(x, w, b, in_act)
+    def _linear(self, x, w, b, in_act: int = 0, out_dtype=None):
+        if out_dtype is None:
+            return self.ops.linear(x, w, b, in_act)
+        return self.ops.linear(x, w, b, in_act, out_dtype)
 
     def _conv(self, conv, h_local, shard, name, weight, wkey, tag, in_elu: bool = False):
         """`in_elu`: h_local is the pre-activation of the deferred ELU (see AlternateGCN._encode_pre)"""
@@ -590,8 +593,11 @@ class DistAlternateGCN(AlternateGCN):
         d = z.shape[1]
         lin0 = self.mlp[0]
         w = lin0.weight
-        p = self._linear(z, w[:, :d].contiguous(), None, in_act)
-        q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias, in_act)
+        # bf16 mixed precision (config 5): P and Q are stored as bfloat16 — the halo exchange of P moves half the bytes
+        pq_dtype = torch.bfloat16 if (isinstance(self.ops, HipOps) and PF.autocast_bf16(z) and d == 64
+                                      and PF.DECODER_PRECISION == 1) else None
+        p = self._linear(z, w[:, :d].contiguous(), None, in_act, pq_dtype)
+        q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias, in_act, pq_dtype)
         p_full = self._table(p, shard, "sim") if gather else p
         extra = shard.edge_attr if fl.skip_connections else None
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None

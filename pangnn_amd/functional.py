@@ -331,13 +331,15 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
         ws_bytes = lib.pangnn_decoder_train_workspace_bytes()
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         ev = _timer_start("dec.bwd")
-        _lib.check(lib.pangnn_decoder_train_f32(
-            p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), max(p.shape[0], q.shape[0]),
+        if p.dtype != q.dtype:
+            raise ValueError("p and q must be stored alike (both float32 or both bfloat16)")
+        _lib.check(lib.pangnn_decoder_train_mixed(
+            p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), _dt(p), max(p.shape[0], q.shape[0]),
             st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
             b3.data_ptr(), d, _lib.ptr(y), _lib.ptr(pw), int(denom), _lib.ptr(g_logits), _lib.ptr(logits),
             _lib.ptr(loss), rec.data_ptr(), _lib.ptr(parts), None if plan is None else plan.part_off.data_ptr(),
             g_w2.data_ptr(), g_w3.data_ptr(), g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(),
-            ws_bytes, _lib.stream_ptr()), "pangnn_decoder_train_f32")
+            ws_bytes, _lib.stream_ptr()), "pangnn_decoder_train_mixed")
         _timer_stop("dec.bwd", ev)
     gp = gq = None
     b2_out = g_b2          # dL/db2 comes out of exactly one dgrad call
@@ -376,6 +378,26 @@ def _rows_f32(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def _rows_any(t: torch.Tensor) -> torch.Tensor:
+    """_rows_f32 that lets bfloat16 storage through (the *_mixed entry points read it as stored)"""
+    if t.dtype != torch.bfloat16:
+        return _rows_f32(t)
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.stride(0) >= t.shape[1] \
+            and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
+def autocast_bf16(t: torch.Tensor) -> bool:
+    """bf16 mixed precision is on for `t`'s device (config 5: accelerate's autocast, pangnn.py:25)"""
+    return t.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
+def _dt(t: torch.Tensor) -> int:
+    """PANGNN_DTYPE_* of a tensor's storage"""
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
 class _DecoderMLP(torch.autograd.Function):
     """Fused link decoder (node_dim 64): logits[e] = w3 . relu(W2 relu(p[src]+q[dst] (+w_e c)) + b2) + b3.
     Forward keeps every [E, 64] intermediate on chip; backward recomputes per tile, emits
@@ -387,12 +409,15 @@ class _DecoderMLP(torch.autograd.Function):
     def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3, pq_joint=False):
         lib = _lib.load()
         _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3)
+        rows = _rows_any if DECODER_PRECISION == 1 else _rows_f32      # bf16-stored tables: gathered as stored
         if pq_joint:
-            pq = _rows_f32(p)
+            pq = rows(p)
             d = pq.shape[1] // 2
             p, q = pq[:, :d], pq[:, d:]
         else:
-            p, q = _rows_f32(p), _rows_f32(q)
+            p, q = rows(p), rows(q)
+            if p.dtype != q.dtype:
+                p, q = p.float(), q.float()
         w2, b2, w3, b3 = (_f32c(t) for t in (w2, b2, w3, b3))
         ex = None if extra is None else _f32c(extra)
         cv = None if cvec is None else _f32c(cvec)
@@ -400,12 +425,20 @@ class _DecoderMLP(torch.autograd.Function):
         logits = torch.empty(e, dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
             ev = _timer_start("dec.fwd")
-            _lib.check(lib.pangnn_decoder_mlp_infer_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
-                                                        max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
-                                                        _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
-                                                        w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(logits),
-                                                        DECODER_PRECISION, _lib.stream_ptr()),
-                       "pangnn_decoder_mlp_infer_f32")
+            if p.dtype == torch.bfloat16:
+                _lib.check(lib.pangnn_decoder_mlp_infer_mixed(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), 1,
+                                                              max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e,
+                                                              e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(),
+                                                              b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), d,
+                                                              _lib.ptr(logits), _lib.stream_ptr()),
+                           "pangnn_decoder_mlp_infer_mixed")
+            else:
+                _lib.check(lib.pangnn_decoder_mlp_infer_f32(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0),
+                                                            max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e, e,
+                                                            _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(),
+                                                            w3.data_ptr(), b3.data_ptr(), d, _lib.ptr(logits),
+                                                            DECODER_PRECISION, _lib.stream_ptr()),
+                           "pangnn_decoder_mlp_infer_f32")
             _timer_stop("dec.fwd", ev)
         ctx.st, ctx.joint = st, pq_joint
         ctx.save_for_backward(p, q, ex, cv, w2, b2, w3, b3)
@@ -504,12 +537,15 @@ class _DecoderLoss(torch.autograd.Function):
     def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, pq_joint):
         lib = _lib.load()
         _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3, y, pos_weight)
+        rows = _rows_any if DECODER_PRECISION == 1 else _rows_f32      # bf16-stored tables: gathered as stored
         if pq_joint:
-            pq = _rows_f32(p)
+            pq = rows(p)
             d = pq.shape[1] // 2
             p, q = pq[:, :d], pq[:, d:]
         else:
-            p, q = _rows_f32(p), _rows_f32(q)
+            p, q = rows(p), rows(q)
+            if p.dtype != q.dtype:
+                p, q = p.float(), q.float()
         w2, b2, w3, b3, y = (_f32c(t) for t in (w2, b2, w3, b3, y))
         ex = None if extra is None else _f32c(extra)
         cv = None if cvec is None else _f32c(cvec)
@@ -597,18 +633,18 @@ class _Linear(torch.autograd.Function):
     written, and dL/dx comes out already multiplied by ELU'(x) (no activation-backward kernel)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, in_act=0):
+    def forward(ctx, x, w, bias, in_act=0, out_dtype=None):
         lib = _lib.load()
         _lib.require_device(x, w, bias)
-        x, w = _rows_f32(x), _f32c(w)
+        x, w = _rows_any(x), _f32c(w)
         b = None if bias is None else _f32c(bias)
         n, k = x.shape
         m = w.shape[0]
-        y = torch.empty(n, m, dtype=torch.float32, device=x.device)
+        y = torch.empty(n, m, dtype=out_dtype or torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(lib.pangnn_linear_act_fwd_f32(x.data_ptr(), x.stride(0), w.data_ptr(), _lib.ptr(b), y.data_ptr(),
-                                                     y.stride(0), n, k, m, int(in_act), None, 0, _lib.stream_ptr()),
-                       "pangnn_linear_act_fwd_f32")
+            _lib.check(lib.pangnn_linear_act_fwd_mixed(x.data_ptr(), _dt(x), x.stride(0), w.data_ptr(), _lib.ptr(b),
+                                                       y.data_ptr(), _dt(y), y.stride(0), n, k, m, int(in_act), None, 0,
+                                                       0, _lib.stream_ptr()), "pangnn_linear_act_fwd_mixed")
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.in_act = int(in_act)
@@ -618,7 +654,7 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         x, w = ctx.saved_tensors
-        g = _rows_f32(g)
+        g = _rows_any(g)                               # bf16 when the output was stored as bf16 (autograd's dtype rule)
         n, k = x.shape
         m = w.shape[0]
         dev = x.device
@@ -626,33 +662,37 @@ class _Linear(torch.autograd.Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0]:
                 wt = w.t().contiguous()                       # [K, M]: gx = g . w = linear(g, w^T)
-                gx = torch.empty(n, k, dtype=torch.float32, device=dev)
+                gx = torch.empty(n, k, dtype=x.dtype, device=dev)        # stored like x (it is x's gradient)
                 gate, ldgate = (x.data_ptr(), x.stride(0)) if ctx.in_act else (None, 0)
-                _lib.check(lib.pangnn_linear_act_fwd_f32(g.data_ptr(), g.stride(0), wt.data_ptr(), None, gx.data_ptr(),
-                                                         gx.stride(0), n, m, k, 0, gate, ldgate, _lib.stream_ptr()),
-                           "pangnn_linear_act_fwd_f32(dx)")
+                _lib.check(lib.pangnn_linear_act_fwd_mixed(g.data_ptr(), _dt(g), g.stride(0), wt.data_ptr(), None,
+                                                           gx.data_ptr(), _dt(gx), gx.stride(0), n, m, k, 0, gate, _dt(x),
+                                                           ldgate, _lib.stream_ptr()), "pangnn_linear_act_fwd_mixed(dx)")
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 gw = torch.empty_like(w)
                 gb = torch.empty(m, dtype=torch.float32, device=dev) if ctx.has_bias else None
                 ws_bytes = lib.pangnn_linear_wgrad_workspace_bytes(k, m)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                _lib.check(lib.pangnn_linear_act_wgrad_f32(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), n, k, m,
-                                                           ctx.in_act, gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(),
-                                                           ws_bytes, _lib.stream_ptr()), "pangnn_linear_act_wgrad_f32")
-        return gx, gw, gb, None
+                _lib.check(lib.pangnn_linear_act_wgrad_mixed(g.data_ptr(), _dt(g), g.stride(0), x.data_ptr(), _dt(x),
+                                                             x.stride(0), n, k, m, ctx.in_act, gw.data_ptr(), _lib.ptr(gb),
+                                                             ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
+                           "pangnn_linear_act_wgrad_mixed")
+        return gx, gw, gb, None, None
 
 
-def linear(x, w, bias=None, in_act: int = 0):
+def linear(x, w, bias=None, in_act: int = 0, out_dtype=None):
     """torch.nn.functional.linear for node-level layers; shapes the HIP kernels do not cover
     (K or M outside {64,128}, or the 128x128 weight gradient) go to hipBLASLt via torch.
-    in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels (see _Linear)."""
+    in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels (see _Linear).
+    `x` may be stored as bfloat16 and `out_dtype=torch.bfloat16` stores the result as bfloat16 (config 5's autocast
+    Linear outputs): fp32 products and sums either way, one rounding on store; gradients of bf16 tensors are bf16."""
     lib = _lib.load()
     k, m = w.shape[1], w.shape[0]
     if x.dim() == 2 and x.is_cuda and lib.pangnn_linear_supported(k, m, 1):
-        return _Linear.apply(x, w, bias, in_act)
+        return _Linear.apply(x, w, bias, in_act, out_dtype)
     if in_act:
         x = torch.nn.functional.elu(x)
-    return torch.nn.functional.linear(x, w, bias)
+    y = torch.nn.functional.linear(x.float(), w, bias)
+    return y if out_dtype is None else y.to(out_dtype)
 
 
 class _BCEWithLogits(torch.autograd.Function):

@@ -105,7 +105,7 @@ class AlternateGCN(nn.Module):
             if w is not None and w.shape[0] != st.num_edges:
                 raise ValueError(f"edge_weight has {w.shape[0]} entries for {st.num_edges} edges")
             agg = PF.embed_propagate(x, self.embedding.weight, self.embedding.bias, st, st.gcn_norm(w), tag=name)
-            return PF.linear(agg, conv.lin.weight, conv.bias)
+            return PF.linear(agg, conv.lin.weight, conv.bias, 0, torch.bfloat16 if PF.autocast_bf16(agg) else None)
         # Linear(1, D) on a [N,1] column is an outer product; as a GEMM its weight gradient is a
         # 64 x 1 x N problem that the BLAS library runs at < 0.1 TB/s
         h = x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
@@ -156,7 +156,9 @@ class AlternateGCN(nn.Module):
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
         w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
         b_pq = torch.cat([torch.zeros_like(self.mlp[0].bias), self.mlp[0].bias])
-        return PF.linear(z, w_pq, b_pq, in_act), st, extra, cvec
+        # bf16 mixed precision: mlp[0] is an autocast Linear, its node-level halves are stored (and gathered) as bfloat16
+        pq_dtype = torch.bfloat16 if (PF.autocast_bf16(z) and d == 64 and PF.DECODER_PRECISION == 1) else None
+        return PF.linear(z, w_pq, b_pq, in_act, pq_dtype), st, extra, cvec
 
     def loss_and_logits(self, graph, labels, pos_weight=None):
         """`criterion(model(graph), labels)` (pangnn.py:200-203) as ONE decoder pass when the fused kernel
@@ -199,8 +201,10 @@ class AlternateGCN(nn.Module):
             # one node-level product gives P | Q = z [W_a ; W_b]^T + [0 ; b1]
             w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
             b_pq = torch.cat([torch.zeros_like(lin0.bias), lin0.bias])
-            pq = PF.linear(z, w_pq, b_pq)
-            if d == 64 and self.fused_decoder != "pair_add":
+            fused = d == 64 and self.fused_decoder != "pair_add"
+            pq_dtype = torch.bfloat16 if (fused and PF.autocast_bf16(z) and PF.DECODER_PRECISION == 1) else None
+            pq = PF.linear(z, w_pq, b_pq, 0, pq_dtype)
+            if fused:
                 # whole per-edge MLP in one HIP kernel (f32 MFMA), no [E, D] tensor in HBM on the way
                 return PF.decoder_mlp_pq(pq, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
                                          self.mlp[4].weight.view(-1), self.mlp[4].bias)
