@@ -334,12 +334,13 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16 rows / f32" if cfg5 else "f32", "data": "synthetic",
             "config": {"workload": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf}, whole graph as one batch, "
                                    f"node_dim={d} hidden_dim={h}, AlternateGCN default topology, mlp decoder" +
-                                   (", --skip_connections --categorical_node, bf16 autocast (propagated rows stored in "
-                                    "bfloat16; dense layers and decoder fp32-level)" if cfg5 else "") +
+                                   (", --skip_connections --categorical_node, bf16 autocast (the Linear outputs — hidden "
+                                    "pre-activation, propagated rows, decoder P|Q — are stored / gathered as bfloat16; products and "
+                                    "sums fp32-level)" if cfg5 else "") +
                                    (", one GPU's share of config 5 (6 of 50 genomes, m = 220 negatives per gene)"
                                     if args.workload == "cfg5slice" else ""),
                        "nodes": n, "sim_edges": e_sim, "neighbour_edges": e_nb,
-                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, rank-local generation, halo rows by all-to-all-v (conv_in needs no exchange)",
+                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, rank-local generation, halo rows by all-to-all-v (conv_in needs no exchange; the decoder's P halo and its gradient travel on a side stream under the own-source pass / the by-target pass)",
                        "arithmetic": "fp32 storage and accumulation everywhere; the three per-edge decoder products run on the bf16 "
                                      "matrix pipe with fp32-exact operand handling (W2 h1: both operands split into three bf16 terms, "
                                      "six partial products; dL/dh1 and dL/dW2: the relu mask is the exact bf16 operand, the other "
