@@ -204,13 +204,19 @@ def main():
     if args.workload == "cfg5" and world < 8 and not args.genes:
         sys.exit("cfg5 (4.3e9 edges) only runs partitioned over 8 GPUs; on one GPU use --workload cfg5slice")
     replicated = os.environ.get("PANGNN_BENCH_REPLICATED") == "1"    # round-1 way: every rank builds the whole graph
+    # node ranges with equal expected in-edge counts (the two end genomes have one neighbour genome, the others two):
+    # PANGNN_PARTITION=nodes keeps equal node ranges
+    bounds = None
+    if partitioned and world > 1 and os.environ.get("PANGNN_PARTITION", "edges") == "edges":
+        from pangnn_amd.dist import balanced_bounds
+        bounds = balanced_bounds(genes, G, world)
     t_gen = time.perf_counter()
     g = None
     if partitioned and not replicated:
         # rank-local generation: a rank draws only the genome pairs around its node range (simulate.simulate_shard,
         # bit-identical to partitioning the whole graph: tests/test_construct.py) — what lets config 5 exist at all
         part = simulate.simulate_shard(genes, G, frac, frags, shuf, seed=args.seed, device=dev, rank=rank, world=world,
-                                       mean_neg=mean_neg)
+                                       mean_neg=mean_neg, bounds=bounds)
         cnt = torch.tensor([part.e_sim_local, part.n_pos_local, part.neighbour_edge_index.shape[1]], dtype=torch.int64,
                            device=dev)
         if world > 1:
@@ -239,7 +245,7 @@ def main():
                 all_reduce_(hi_, torch.distributed.ReduceOp.MAX)
             if not torch.equal(lo_, hi_):
                 raise RuntimeError("ranks generated different graphs from the same seed")
-            part = pdist.partition_graph(g, rank, world)
+            part = pdist.partition_graph(g, rank, world, bounds)
             class_balance = g.class_balance
             del g
         model = pdist.DistAlternateGCN(dev, dims=[d, h], part=part, categorical_nodes=cfg5, **model_flags)
@@ -355,7 +361,7 @@ def main():
                                    (", one GPU's share of config 5 (6 of 50 genomes, m = 220 negatives per gene)"
                                     if args.workload == "cfg5slice" else ""),
                        "nodes": n, "sim_edges": e_sim, "neighbour_edges": e_nb,
-                       "partition": "none" if world == 1 else f"destination-partitioned x{world}, rank-local generation, halo rows by all-to-all-v (conv_in needs no exchange; the decoder's P halo and its gradient travel on a side stream under the own-source pass / the by-target pass)",
+                       "partition": "none" if world == 1 else f"destination-partitioned x{world} ({'node ranges with equal expected in-edge counts' if bounds else 'equal node ranges'}), rank-local generation, halo rows by all-to-all-v (conv_in needs no exchange; the decoder's P halo and its gradient travel on a side stream under the own-source pass / the by-target pass)",
                        "arithmetic": "fp32 storage and accumulation everywhere; the three per-edge decoder products run on the bf16 "
                                      "matrix pipe with fp32-exact operand handling (W2 h1: both operands split into three bf16 terms, "
                                      "six partial products; dL/dh1 and dL/dW2: the relu mask is the exact bf16 operand, the other "

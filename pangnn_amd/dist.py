@@ -139,14 +139,19 @@ class HaloPlan:
     global-id order, so an edge list that was sorted by source stays sorted (the decoder's per-source
     partial sums keep working on shards).  Built once per (graph, partition)."""
 
-    def __init__(self, ei_local: torch.Tensor, lo: int, n_local: int, group=None, make_csr=None):
+    def __init__(self, ei_local: torch.Tensor, lo: int, n_local: int, group=None, make_csr=None, bounds=None):
+        """`bounds` [world + 1]: first node of every rank's range when the ranges are not equal (balanced_bounds)"""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         dev = ei_local.device
         src = ei_local[0]
         hi = lo + n_local
         remote = (src < lo) | (src >= hi)
         need = torch.unique(src[remote])                                   # sorted global ids
-        owner = torch.div(need, n_local, rounding_mode="floor")
+        if bounds is None:
+            owner = torch.div(need, n_local, rounding_mode="floor")
+        else:
+            b = torch.as_tensor(list(bounds), dtype=torch.int64, device=dev)
+            owner = torch.searchsorted(b, need, right=True) - 1
         need_counts = torch.bincount(owner, minlength=world)
         all_counts = _all_gather_rows(need_counts.view(1, world), group)       # [world(asker), world(owner)]
         mx = max(int(all_counts.max()), 1)
@@ -352,12 +357,40 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 # partition
 # --------------------------------------------------------------------------------------
-def partition_graph(g, rank: int, world: int):
+def balanced_bounds(genes: int, genomes: int, world: int):
+    """Node ranges [bounds[r], bounds[r + 1]) with equal expected numbers of in-edges for a simulated pan-genome
+    (genome-major node ids): after remove_trivial_cases only adjacent genomes are joined and every adjacent pair
+    carries the same expected number of edges in both directions, so a node of an end genome receives half the edges
+    of any other node.  Computable on every rank without communication (rank-local generation needs it before a
+    single edge exists).  Equal node ranges leave the two end ranks ~20 % short of work at 8 ranks x 20 genomes."""
+    genes, genomes, world = int(genes), int(genomes), int(world)
+    w = [1 if (g == 0 or g == genomes - 1) else 2 for g in range(genomes)] if genomes > 1 else [1]
+    total = genes * sum(w)
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r // world               # cumulative weight before the boundary
+        g, before = 0, 0
+        while g < genomes - 1 and before + genes * w[g] <= target:
+            before += genes * w[g]
+            g += 1
+        bounds.append(min(g * genes + (target - before) // w[g], genes * genomes))
+    bounds.append(genes * genomes)
+    return bounds
+
+
+def partition_graph(g, rank: int, world: int, bounds=None):
     """Slice a whole graph (x, edge_index, edge_attr, y, neighbour_edge_index[, union_edge_index]) into
-    rank's shard.  Index tensors keep GLOBAL source ids and get LOCAL target ids."""
+    rank's shard.  Index tensors keep GLOBAL source ids and get LOCAL target ids.  `bounds` [world + 1]: unequal
+    node ranges (balanced_bounds); default = equal ranges of ceil(N / world) nodes."""
     n = int(g.x.shape[0])
-    n_local = (n + world - 1) // world
-    lo, hi = rank * n_local, min((rank + 1) * n_local, n)
+    if bounds is None:
+        n_local = (n + world - 1) // world
+        lo, hi = rank * n_local, min((rank + 1) * n_local, n)
+        n_pad = n_local * world
+    else:
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        n_local = hi - lo
+        n_pad = None                     # no all-gather exchange over unequal blocks
     dev = g.x.device
 
     def own(ei):
@@ -372,7 +405,8 @@ def partition_graph(g, rank: int, world: int):
     shard = SimpleNamespace(
         x=x, edge_index=ei, edge_attr=g.edge_attr[: g.edge_index.shape[1]][m_sim].contiguous(),
         y=g.y[m_sim].contiguous() if getattr(g, "y", None) is not None else None,
-        n_local=n_local, n_pad=n_local * world, n_global=n, lo=lo, hi=hi, rank=rank, world=world,
+        n_local=n_local, n_pad=n_pad, n_global=n, lo=lo, hi=hi, rank=rank, world=world,
+        bounds=None if bounds is None else [int(b) for b in bounds],
         e_sim_local=int(ei.shape[1]), e_sim_total=int(g.edge_index.shape[1]), owned_mask=m_sim)
     if getattr(g, "neighbour_edge_index", None) is not None:
         shard.neighbour_edge_index, _ = own(g.neighbour_edge_index)
@@ -472,7 +506,7 @@ class DistAlternateGCN(AlternateGCN):
             ei = {"sim": shard.edge_index, "nb": getattr(shard, "neighbour_edge_index", None),
                   "union": getattr(shard, "union_edge_index", None)}[name]
             cache[name] = HaloPlan(ei, shard.lo, shard.n_local, self.group,
-                                   getattr(self.ops, "make_back_csr", None))
+                                   getattr(self.ops, "make_back_csr", None), getattr(shard, "bounds", None))
         return cache[name]
 
     def _st(self, shard, name):
@@ -483,6 +517,8 @@ class DistAlternateGCN(AlternateGCN):
                 plan = self._plan(shard, name)
                 cache[key] = self.ops.structure(plan.edge_index, shard.n_local, plan.n_table)
             else:
+                if shard.n_pad is None:
+                    raise ValueError("exchange='allgather' needs equal node ranges (partition without bounds=)")
                 ei = {"sim": shard.edge_index, "nb": getattr(shard, "neighbour_edge_index", None),
                       "union": getattr(shard, "union_edge_index", None)}[name]
                 cache[key] = self.ops.structure(ei, shard.n_local, shard.n_pad)

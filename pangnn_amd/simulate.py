@@ -172,17 +172,22 @@ def simulate_raw(n: int, genomes: int, frac_pos: float, num_fragments: float = 1
 
 def simulate_shard(n: int, genomes: int, frac_pos: float, num_fragments: float = 10, n_shuffle: float = 2,
                    neighbours: int = 1, seed: int = 0, device="cpu", temperature: float = 0.8, rank: int = 0,
-                   world: int = 1, mean_neg=None):
+                   world: int = 1, mean_neg=None, bounds=None):
     """Rank `rank`'s destination-partitioned shard of the simulated graph WITHOUT building the whole graph: the rank
     draws only the genome pairs that touch its node range (per-pair generators), normalises them (every
     (source, candidate genome) group lies inside one pair) and keeps the edges whose target it owns.  Bit-identical to
-    `dist.partition_graph(simulate_graph(...), rank, world)` (tests/test_construct.py).  Global quantities a shard
+    `dist.partition_graph(simulate_graph(...), rank, world[, bounds])` (tests/test_construct.py).  Global quantities a shard
     cannot know are left as LOCAL counts for the caller to all-reduce: `n_pos_local`, `e_sim_local`
     (-> class_balance = (E - P) / P and e_sim_total)."""
     device = torch.device(device)
     G, N = int(genomes), int(n) * int(genomes)
-    n_local = (N + world - 1) // world
-    lo, hi = rank * n_local, min((rank + 1) * n_local, N)
+    if bounds is None:
+        n_local = (N + world - 1) // world
+        lo, hi = rank * n_local, min((rank + 1) * n_local, N)
+        n_pad = n_local * world
+    else:                                   # unequal node ranges (dist.balanced_bounds)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        n_local, n_pad = hi - lo, None
     g_lo, g_hi = lo // n, max(lo, hi - 1) // n
     blocks = list(range(max(g_lo - 1, 0), min(g_hi, G - 2) + 1)) if hi > lo else []
     raw = simulate_raw(n, genomes, frac_pos, num_fragments, n_shuffle, seed=seed, device=device, blocks=blocks,
@@ -205,7 +210,8 @@ def simulate_shard(n: int, genomes: int, frac_pos: float, num_fragments: float =
     return SimpleNamespace(
         x=x, edge_index=torch.stack([s, d - lo]).contiguous(), edge_attr=w.to(torch.float32).contiguous(), y=y,
         neighbour_edge_index=torch.stack([i[keep], j[keep] - lo]).contiguous(),
-        n_local=n_local, n_pad=n_local * world, n_global=N, lo=lo, hi=hi, rank=rank, world=world,
+        n_local=n_local, n_pad=n_pad, n_global=N, lo=lo, hi=hi, rank=rank, world=world,
+        bounds=None if bounds is None else [int(b) for b in bounds],
         e_sim_local=int(s.numel()), n_pos_local=int(y.sum().item()), e_sim_total=None, owned_mask=None,
         genome_of=raw.genome_of)
 

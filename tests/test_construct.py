@@ -203,17 +203,19 @@ def test_simulator_is_seeded(device):
 
 # ---------------------------------------------------------------- rank-local generation (config 5: no rank holds the graph)
 @pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("balanced", [False, True], ids=["equal-nodes", "equal-edges"])
 @pytest.mark.parametrize("n,G,frac,world", [(300, 5, 0.3, 2), (1000, 5, 0.3, 3), (400, 7, 0.2, 4), (250, 20, 0.2, 8)])
-def test_rank_local_generation_equals_partition_of_the_whole_graph(n, G, frac, world, device):
+def test_rank_local_generation_equals_partition_of_the_whole_graph(n, G, frac, world, device, balanced):
     """simulate_shard draws only the genome pairs around the rank's node range; its shard must be the one
     dist.partition_graph cuts out of the whole graph of the same seed — edge ids, labels and neighbour edges
     bit-exact, fp32 weights bit-exact on the CPU and within the construction test's device bound on the GPU."""
-    from pangnn_amd.dist import partition_graph
+    from pangnn_amd.dist import balanced_bounds, partition_graph
     g = simulate.simulate_graph(n, G, frac, 10, 2, seed=5, device=device)
+    bounds = balanced_bounds(n, G, world) if balanced else None
     tot = pos = 0
     for r in range(world):
-        ref = partition_graph(g, r, world)
-        sh = simulate.simulate_shard(n, G, frac, 10, 2, seed=5, device=device, rank=r, world=world)
+        ref = partition_graph(g, r, world, bounds)
+        sh = simulate.simulate_shard(n, G, frac, 10, 2, seed=5, device=device, rank=r, world=world, bounds=bounds)
         assert sh.edge_index.device.type == device
         assert torch.equal(ref.edge_index, sh.edge_index) and torch.equal(ref.y, sh.y)
         assert torch.equal(ref.neighbour_edge_index, sh.neighbour_edge_index) and torch.equal(ref.x, sh.x)
@@ -222,3 +224,28 @@ def test_rank_local_generation_equals_partition_of_the_whole_graph(n, G, frac, w
         tot += sh.e_sim_local
         pos += sh.n_pos_local
     assert tot == g.edge_index.shape[1] and pos == int(g.y.sum())
+
+
+@pytest.mark.parametrize("n,G,world", [(2000, 20, 8), (1500, 7, 4), (1000, 50, 8), (3000, 5, 2), (3000, 3, 3)])
+def test_balanced_bounds_give_every_rank_the_same_share_of_edges(n, G, world):
+    """dist.balanced_bounds: node ranges from the genome adjacency alone (no edge exists yet when a rank needs its
+    range).  Ranges are contiguous, cover every node once, and the in-edges they own differ by a few per cent, where
+    equal node ranges leave the two end ranks short (they hold an end genome, which has one neighbour genome)."""
+    from pangnn_amd.dist import balanced_bounds
+    b = balanced_bounds(n, G, world)
+    assert len(b) == world + 1 and b[0] == 0 and b[-1] == n * G and all(b[i] <= b[i + 1] for i in range(world))
+    # exact in expectation: every node weighs the number of genomes adjacent to its own (1 at the ends, else 2)
+    wnode = torch.tensor([1 if (k == 0 or k == G - 1) else 2 for k in range(G)], dtype=torch.int64).repeat_interleave(n)
+    load = torch.tensor([int(wnode[b[r]:b[r + 1]].sum()) for r in range(world)])
+    assert int(load.max() - load.min()) <= 2 * world        # whole-node granularity
+    # and on a drawn graph (per-pair edge counts are heavy-tailed negative-binomial sums: +-5 % at these sizes, 1 % at
+    # cfg 4; equal node ranges are short by 1 / (2 - 2 / G) on the end ranks whatever the size)
+    g = simulate.simulate_graph(n, G, 0.2, 10, 2, seed=3, device="cpu")
+    dst = g.edge_index[1]
+    bal = torch.tensor([int(((dst >= b[r]) & (dst < b[r + 1])).sum()) for r in range(world)], dtype=torch.float64)
+    nl = (n * G + world - 1) // world
+    eq = torch.tensor([int(((dst >= r * nl) & (dst < (r + 1) * nl)).sum()) for r in range(world)], dtype=torch.float64)
+    assert float(bal.max() / bal.mean()) < 1.15
+    if (G, world) == (3, 3):              # one genome per rank: the middle one has twice the in-edges
+        assert float(eq.max() / eq.mean()) > 1.4
+    assert balanced_bounds(n, G, 1) == [0, n * G]

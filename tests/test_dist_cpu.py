@@ -77,7 +77,7 @@ class TorchOps:
                                                                     reduction="sum") / denom
 
 
-def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=True):
+def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=True, uneven=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
@@ -102,7 +102,9 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=Tru
                 p.uniform_(-0.5, 0.5)
     if categorical:
         g.x = torch.arange(n)
-    shard = pdist.partition_graph(g, rank, world)
+    # uneven: node ranges of different sizes (what dist.balanced_bounds produces for a pan-genome)
+    bounds = [0] + [n * (2 * r + 1) // (2 * world + 1) for r in range(1, world)] + [n] if uneven else None
+    shard = pdist.partition_graph(g, rank, world, bounds)
     model = pdist.DistAlternateGCN(None, dims=[64, 128], ops=TorchOps(), exchange=exchange, part=shard,
                                    categorical_nodes=categorical, **flags)
     model.overlap = overlap
@@ -114,7 +116,8 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=Tru
         rows[: shard.hi - shard.lo] = sd["embedding.weight"][shard.lo:shard.hi]
         sd = dict(sd, **{"embedding.weight": rows})
     model.load_state_dict(sd)
-    assert shard.n_pad == shard.n_local * world and shard.e_sim_total == g.edge_index.shape[1]
+    assert (shard.n_pad is None if uneven else shard.n_pad == shard.n_local * world)
+    assert shard.e_sim_total == g.edge_index.shape[1] and shard.n_local == shard.hi - shard.lo or not uneven
     pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     opt_o = torch.optim.Adam(oracle.parameters(), lr=1e-3)
@@ -158,7 +161,7 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=Tru
         src = shard.edge_index[0]
         rem = (src < shard.lo) | (src >= shard.lo + shard.n_local)
         assert plan.n_halo == int(torch.unique(src[rem]).numel())
-        assert plan.n_halo < shard.n_pad - shard.n_local or world == 2
+        assert plan.n_halo < n - shard.n_local or world == 2
         assert sum(plan.recv_splits) == plan.n_halo and int(plan.edge_index[0].max()) < plan.n_table
     # owned-edge bookkeeping: every similarity edge has exactly one owner
     cnt = shard.owned_mask.to(torch.int32).clone()
@@ -188,6 +191,16 @@ def test_partitioned_model_without_overlap(flags):
         init_file = os.path.join(d, "rdzv")
         mp.spawn(_worker, args=(2, init_file, flags, d, "halo", False), nprocs=2, join=True)
         assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(2))
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True, categorical_nodes=True)],
+                         ids=["default", "cfg5-skip-categorical"])
+def test_partitioned_model_on_unequal_node_ranges(flags):
+    """node ranges of different sizes (edge-balanced partition): owners by boundary search, per-rank row counts"""
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "rdzv")
+        mp.spawn(_worker, args=(3, init_file, flags, d, "halo", True, True), nprocs=3, join=True)
+        assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(3))
 
 
 @pytest.mark.parametrize("flags", [dict(), dict(union_edge_weights=True)], ids=["default", "union"])
