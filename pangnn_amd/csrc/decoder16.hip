@@ -762,10 +762,14 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 // T kernel: dL/dh1 summed over runs of equal keys in a permuted edge order, from the records of S.
 //   perm[k] = edge id at sorted position k (NULL = identity); keys[k] = run key of position k (CSR row id).
 // ------------------------------------------------------------------------------------------------------------------
+// Two dependent loads per position (perm[k], then the record of edge perm[k]): a two-stage pipeline — the ids of half
+// tile n + 2 and the records of half tile n + 1 are in flight while half tile n is multiplied, so each of the two
+// random-access latencies has a whole iteration to land.
+struct TIds { uint32_t e; int key, key_nxt; };
 struct TIn { uint32_t recw; float g_e, w_e; int key, key_nxt; };
-__device__ __forceinline__ TIn load_t(const uint32_t* rec, const int32_t* perm, const int32_t* keys, const float* extra,
-                                      int64_t E, int64_t tile, int64_t n_tiles, int hx, int c, int g) {
-  TIn t;
+__device__ __forceinline__ TIds load_ids(const int32_t* perm, const int32_t* keys, int64_t E, int64_t tile, int64_t n_tiles,
+                                         int hx, int c) {
+  TIds t;
   const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
   const int64_t p_tile = tc * 32;
   const int64_t rest = E - 1 - p_tile;
@@ -774,11 +778,17 @@ __device__ __forceinline__ TIn load_t(const uint32_t* rec, const int32_t* perm, 
   const int32_t* kt = keys + p_tile;
   t.key = kt[k];
   t.key_nxt = kt[kn];
-  const uint32_t e = perm ? (uint32_t)(perm + p_tile)[k] : (uint32_t)(p_tile + k);
-  const uint32_t* r = rec + (uint64_t)e * 8;
+  t.e = perm ? (uint32_t)(perm + p_tile)[k] : (uint32_t)(p_tile + k);
+  return t;
+}
+__device__ __forceinline__ TIn load_rec(const uint32_t* rec, const float* extra, const TIds& id, int g) {
+  TIn t;
+  const uint32_t* r = rec + (uint64_t)id.e * 8;
   t.recw = r[g];
   t.g_e = __builtin_bit_cast(float, r[4]);
-  t.w_e = extra ? extra[e] : 0.f;
+  t.w_e = extra ? extra[id.e] : 0.f;
+  t.key = id.key;
+  t.key_nxt = id.key_nxt;
   return t;
 }
 
@@ -807,7 +817,8 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
 
   const int64_t stride = (int64_t)gridDim.x * T_WAVES;
   int64_t tile = (int64_t)blockIdx.x * T_WAVES + wave;
-  TIn cur = load_t(rec, perm, keys, extra, E, tile, n_tiles, 0, c, g);
+  TIn cur = load_rec(rec, extra, load_ids(perm, keys, E, tile, n_tiles, 0, c), g);
+  TIds ids_nxt = load_ids(perm, keys, E, tile, n_tiles, 1, c);
   int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile] : 0;
   for (; tile < n_tiles; tile += stride) {
     float carry = 0.f;
@@ -816,8 +827,9 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     const int live_lim = (int)min((int64_t)31, E - 1 - tile * 32);
 #pragma unroll 1
     for (int hx = 0; hx < 2; ++hx) {
-      const TIn nxt = hx == 0 ? load_t(rec, perm, keys, extra, E, tile, n_tiles, 1, c, g)
-                              : load_t(rec, perm, keys, extra, E, tile + stride, n_tiles, 0, c, g);
+      const TIn nxt = load_rec(rec, extra, ids_nxt, g);                          // half n + 1: ids landed an iteration ago
+      ids_nxt = hx == 0 ? load_ids(perm, keys, E, tile + stride, n_tiles, 0, c)    // half n + 2
+                        : load_ids(perm, keys, E, tile + stride, n_tiles, 1, c);
       const int pos = 16 * hx + c;
       const float g_e = pos <= live_lim ? cur.g_e : 0.f;
       *reinterpret_cast<uint32_t*>(wv + TW_REC + 16 * c + 4 * g) = cur.recw;
