@@ -202,6 +202,25 @@ __device__ __forceinline__ void stage_weights16(const float* w2, const float* b2
   }
 }
 
+// epilogue of P2: times g_e, masked by m1 (the record bits of the 16 edges in LDS)
+__device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl, int c, int g, f32x4 (&v)[4]) {
+  const f32x4 ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
+  const int bitpos = 16 * (c & 1) + 7 - ((c & 7) >> 1);
+  const char* rrow = recl + 64 * g + 4 * (c >> 3);      // edge 4 g + i at + 16 i; dwords (c >> 3) and 2 + (c >> 3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i);          // kb even
+    const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i + 8);      // kb odd
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const uint32_t d = (kb & 1) ? d1 : d0;
+      const int keep = __builtin_amdgcn_sbfe((int)d, bitpos - 4 * (kb >> 1), 1);     // 0 or -1
+      const float val = v[kb][i] * ge4[i];
+      v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
+    }
+  }
+}
+
 // ---- P2 + its epilogue + run sums, shared by S and T.  Lane (c = lane & 15, g = lane >> 4).
 //   a2[t]   mask m2 as bf16 0/1 A fragments: element s of K-step t is j = 32 t + 16 (s >> 2) + 4 g + (s & 3), edge c
 //   recl    [16][4] dwords in LDS: the m1 bits of edge e, lane group g' (bit 16 (s&1) + 7 - (4 ks + (s >> 1)) for
@@ -240,22 +259,37 @@ __device__ __forceinline__ void dgrad_tile(const char* lds, const char* recl, co
     v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], bq[st & 1][0], v[kb], 0, 0, 0);
   }
   D16_SETPRIO(0);
-  // epilogue: times g_e, masked by m1
-  const f32x4 ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
-  const int bitpos = 16 * (c & 1) + 7 - ((c & 7) >> 1);
-  const char* rrow = recl + 64 * g + 4 * (c >> 3);      // edge 4 g + i at + 16 i; dwords (c >> 3) and 2 + (c >> 3)
+  dgrad_epilogue(recl, gl, c, g, v);
+}
+
+// P2 of BOTH halves of a 32-edge tile per W2' fragment read (the T kernel): one ds_read_b128 triple feeds six MFMAs,
+// i.e. half the LDS bytes per edge of dgrad_tile — the T kernel at one fragment triple per three MFMAs ran the LDS
+// at ~70 % of its bandwidth — and two independent accumulator chains in the matrix pipe.
+__device__ __forceinline__ void dgrad_tile2(const char* lds, const bf16x8 (&a2)[2][2], int w2p_off0, int w2p_off1,
+                                            f32x4 (&v)[2][4]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i);          // kb even
-    const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i + 8);      // kb odd
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const uint32_t d = (kb & 1) ? d1 : d0;
-      const int keep = __builtin_amdgcn_sbfe((int)d, bitpos - 4 * (kb >> 1), 1);     // 0 or -1
-      const float val = v[kb][i] * ge4[i];
-      v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
+    for (int kb = 0; kb < 4; ++kb) v[h][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 bq[2][3];
+#pragma unroll
+  for (int x = 0; x < 3; ++x) bq[0][x] = ld_b128(lds, w2p_off0 + x * W_IMG);
+  D16_SETPRIO(1);
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int t = st >> 2, kb = st & 3;
+    if (st < 7) {
+      const int off = (((st + 1) >> 2) ? w2p_off1 : w2p_off0) + ((st + 1) & 3) * 2048;     // rows 16 kb + c
+#pragma unroll
+      for (int x = 0; x < 3; ++x) bq[(st + 1) & 1][x] = ld_b128(lds, off + x * W_IMG);
     }
+#pragma unroll
+    for (int x = 2; x >= 0; --x)                                                            // lo, mid, hi
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        v[h][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[h][t], bq[st & 1][x], v[h][kb], 0, 0, 0);
   }
+  D16_SETPRIO(0);
 }
 
 // Sums of the dL/dh1 rows of every run of equal keys (sources in S, targets in T) inside a 32-edge tile, written as
@@ -796,8 +830,9 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     const uint32_t* __restrict__ rec, const int32_t* __restrict__ perm, const int32_t* __restrict__ keys,
     const float* __restrict__ extra, const float* __restrict__ w2, const float* __restrict__ w3, int64_t E,
     D16Run rs, float* __restrict__ gcv_slabs, float* __restrict__ gb2_slabs, int64_t n_tiles) {
-  // LDS: W2'^T hi | mid | lo, (b2 w3 cvec: unused here), per wave: run-sum tile [17][64] floats | recl | gl | wl
-  constexpr int TW_REC = 17 * 64 * 4, TW_GL = TW_REC + 256, TW_WL = TW_GL + 64, TW_BYTES = TW_WL + 64;
+  // LDS: W2'^T hi | mid | lo, (b2 w3 cvec: unused here), per wave: run-sum tile [17][64] floats | recl | gl | wl of
+  // both halves of the wave's 32-edge tile
+  constexpr int TW_REC = 17 * 64 * 4, TW_GL = TW_REC + 2 * 256, TW_WL = TW_GL + 2 * 64, TW_BYTES = TW_WL + 2 * 64;
   constexpr int T_VEC = 3 * W_IMG, T_WAVE0 = T_VEC + 3 * 64 * 4;
   constexpr int T_LDS = T_WAVE0 + T_WAVES * TW_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[T_LDS];
@@ -817,32 +852,40 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
 
   const int64_t stride = (int64_t)gridDim.x * T_WAVES;
   int64_t tile = (int64_t)blockIdx.x * T_WAVES + wave;
-  TIn cur = load_rec(rec, extra, load_ids(perm, keys, E, tile, n_tiles, 0, c), g);
-  TIds ids_nxt = load_ids(perm, keys, E, tile, n_tiles, 1, c);
+  // pipeline over the wave's tiles: records of tile n + 1 and ids of tile n + 2 in flight under tile n
+  TIn cur[2];
+  TIds ids_nxt[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    cur[h] = load_rec(rec, extra, load_ids(perm, keys, E, tile, n_tiles, h, c), g);
+    ids_nxt[h] = load_ids(perm, keys, E, tile + stride, n_tiles, h, c);
+  }
   int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile] : 0;
   for (; tile < n_tiles; tile += stride) {
     float carry = 0.f;
     int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
     const int poff_nxt = (run && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
     const int live_lim = (int)min((int64_t)31, E - 1 - tile * 32);
-#pragma unroll 1
-    for (int hx = 0; hx < 2; ++hx) {
-      const TIn nxt = load_rec(rec, extra, ids_nxt, g);                          // half n + 1: ids landed an iteration ago
-      ids_nxt = hx == 0 ? load_ids(perm, keys, E, tile + stride, n_tiles, 0, c)    // half n + 2
-                        : load_ids(perm, keys, E, tile + stride, n_tiles, 1, c);
-      const int pos = 16 * hx + c;
-      const float g_e = pos <= live_lim ? cur.g_e : 0.f;
-      *reinterpret_cast<uint32_t*>(wv + TW_REC + 16 * c + 4 * g) = cur.recw;
-      *reinterpret_cast<float*>(wv + TW_GL + 4 * c) = g_e;
-      if (has_extra) *reinterpret_cast<float*>(wv + TW_WL + 4 * c) = cur.w_e;
+    TIn nxt[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      nxt[h] = load_rec(rec, extra, ids_nxt[h], g);
+      ids_nxt[h] = load_ids(perm, keys, E, tile + 2 * stride, n_tiles, h, c);
+    }
+    bf16x8 a2[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float g_e = 16 * h + c <= live_lim ? cur[h].g_e : 0.f;
+      *reinterpret_cast<uint32_t*>(wv + TW_REC + 256 * h + 16 * c + 4 * g) = cur[h].recw;
+      *reinterpret_cast<float*>(wv + TW_GL + 64 * h + 4 * c) = g_e;
+      if (has_extra) *reinterpret_cast<float*>(wv + TW_WL + 64 * h + 4 * c) = cur[h].w_e;
       // m2 bits of lane (c, g): dword qd of K-step t holds elements (2 qd, 2 qd + 1) at bits 15 - n and 31 - n, n = 4 t + qd
-      bf16x8 a2[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         u32x4 w;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) w[qd] = ((cur.recw >> (15 - (4 * t + qd))) & 0x00010001u) * 0x3f80u;
-        a2[t] = __builtin_bit_cast(bf16x8, w);
+        for (int qd = 0; qd < 4; ++qd) w[qd] = ((cur[h].recw >> (15 - (4 * t + qd))) & 0x00010001u) * 0x3f80u;
+        a2[h][t] = __builtin_bit_cast(bf16x8, w);
         if (gb2_slabs != nullptr) {
           // the halves of w are bf16 1.0 / 0.0: as fp32 bit patterns they are the mask value itself
 #pragma unroll
@@ -853,28 +896,30 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
           }
         }
       }
-      wave_sync();
-      if (!run) {                                       // parameter sums only
-        wave_sync();
-        cur = nxt;
-        continue;
-      }
-      f32x4 v[4];
-      dgrad_tile<false>(lds, wv + TW_REC, wv + TW_GL, a2, c, g, wfrag0, wfrag1, v);
-      if (has_extra && gcv_slabs != nullptr) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + TW_WL + 16 * g);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], v[kb][i], gcv[kb]);
-      }
-      const bool closes = cur.key != cur.key_nxt || pos == 31;
-      const unsigned long long bal = __ballot(closes);
-      const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
-      run_sums(v, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
-      wave_sync();
-      cur = nxt;
     }
+    wave_sync();
+    if (run) {
+      f32x4 v[2][4];
+      dgrad_tile2(lds, a2, wfrag0, wfrag1, v);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        dgrad_epilogue(wv + TW_REC + 256 * h, wv + TW_GL + 64 * h, c, g, v[h]);
+        if (has_extra && gcv_slabs != nullptr) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + TW_WL + 64 * h + 16 * g);
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], v[h][kb][i], gcv[kb]);
+        }
+        const bool closes = cur[h].key != cur[h].key_nxt || (h == 1 && c == 15);
+        const unsigned long long bal = __ballot(closes);
+        const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
+        run_sums(v[h], m16, carry, rs.part, pidx, wv, lane, c, g, colp);
+      }
+    }
+    wave_sync();          // the next tile overwrites recl / gl / wl
+#pragma unroll
+    for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
     poff_cur = poff_nxt;
   }
   if (gcv_slabs != nullptr || gb2_slabs != nullptr) {
