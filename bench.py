@@ -405,7 +405,8 @@ def main():
                 "traffic": prof.get(key + "_decoder_dgrad_bytes_fetch_undoubled"),
                 "traffic_note": "FETCH_SIZE NOT doubled here (random 32-byte record gathers: the raw counter is one 64-B "
                                 "sector per edge) + WRITE_SIZE, " + str(prof.get("_source", "profiles/")) + ", not this run; "
-                                "the kernel is bound by the latency of those gathers and by instruction issue"}
+                                "both halves of a 32-edge tile share every W2' fragment read (its matrix phase ran the LDS array "
+                                "at its 256 B/clk limit with one fragment per MFMA) and the gathers run two stages ahead"}
         if t_prop:
             b_alg = spmm_alg_bytes(e_local, rows_local, f_spmm)
             traffic = prof.get(key + "_spmm_fwd_bytes")
@@ -416,8 +417,8 @@ def main():
                 "frac_note": "algorithmic bytes (SURVEY.md §8d: every gathered row counted once per edge, no cache credit) over "
                              "the 8 TB/s spec; > 1 because the 256 MB source table is served from L2 / Infinity Cache",
                 "traffic": traffic,
-                "traffic_note": "L2-fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from "
-                                "profiles/r01p_pmc_*.csv, not this run",
+                "traffic_note": "L2-fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from " +
+                                str(prof.get("_source", "profiles/")) + ", not this run",
                 "fabric_rate_GBps": (traffic / t_prop / 1e9) if traffic else None,
                 "fabric_rate_note": "7.4-7.9 TB/s is the guide's gather ceiling for a table of this size "
                                     "(MI355X_MICROARCH.md, indexed rows): the kernel sits at it",
