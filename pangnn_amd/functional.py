@@ -686,8 +686,9 @@ def linear(x, w, bias=None, in_act: int = 0, out_dtype=None):
     `x` may be stored as bfloat16 and `out_dtype=torch.bfloat16` stores the result as bfloat16 (config 5's autocast
     Linear outputs): fp32 products and sums either way, one rounding on store; gradients of bf16 tensors are bf16."""
     lib = _lib.load()
+    _lib.require_device(x, w, bias)                  # no CPU path: the torch branch below is hipBLASLt on the GPU
     k, m = w.shape[1], w.shape[0]
-    if x.dim() == 2 and x.is_cuda and lib.pangnn_linear_supported(k, m, 1):
+    if x.dim() == 2 and lib.pangnn_linear_supported(k, m, 1):
         return _Linear.apply(x, w, bias, in_act, out_dtype)
     if in_act:
         x = torch.nn.functional.elu(x)

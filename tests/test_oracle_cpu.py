@@ -159,6 +159,14 @@ def test_product_refuses_cpu_tensors():
     m = pangnn_amd.GCNConv(4, 4)
     with pytest.raises(PangnnHipError):
         m(torch.randn(3, 4), torch.tensor([[0, 1], [1, 2]]))
+    # every operator of the functional layer: no silent torch-on-CPU path (shapes the HIP kernels do not cover go to
+    # hipBLASLt on the GPU, never to the host)
+    from pangnn_amd import functional as PF
+    for k, mm in ((64, 128), (5, 7)):
+        with pytest.raises(PangnnHipError):
+            PF.linear(torch.randn(3, k), torch.randn(mm, k), torch.randn(mm))
+    with pytest.raises(PangnnHipError):
+        PF.bce_with_logits(torch.randn(5), torch.ones(5))
 
 
 def test_c_abi_exports_every_declared_symbol():
