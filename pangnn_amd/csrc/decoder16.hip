@@ -801,6 +801,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 // random-access latencies has a whole iteration to land.
 struct TIds { uint32_t e; int key, key_nxt; };
 struct TIn { uint32_t recw; float g_e, w_e; int key, key_nxt; };
+template <bool PERM>
 __device__ __forceinline__ TIds load_ids(const int32_t* perm, const int32_t* keys, int64_t E, int64_t tile, int64_t n_tiles,
                                          int hx, int c) {
   TIds t;
@@ -812,20 +813,25 @@ __device__ __forceinline__ TIds load_ids(const int32_t* perm, const int32_t* key
   const int32_t* kt = keys + p_tile;
   t.key = kt[k];
   t.key_nxt = kt[kn];
-  t.e = perm ? (uint32_t)(perm + p_tile)[k] : (uint32_t)(p_tile + k);
+  t.e = PERM ? (uint32_t)(perm + p_tile)[k] : (uint32_t)(p_tile + k);
   return t;
 }
+template <bool EXTRA>
 __device__ __forceinline__ TIn load_rec(const uint32_t* rec, const float* extra, const TIds& id, int g) {
   TIn t;
   const uint32_t* r = rec + (uint64_t)id.e * 8;
   t.recw = r[g];
   t.g_e = __builtin_bit_cast(float, r[4]);
-  t.w_e = extra ? extra[id.e] : 0.f;
+  t.w_e = EXTRA ? extra[id.e] : 0.f;
   t.key = id.key;
   t.key_nxt = id.key_nxt;
   return t;
 }
 
+// PERM / EXTRA: permutation given, skip feature given — compile-time, so that the loads of the loop body sit in
+// straight-line code (as runtime-uniform branches they cut it into ~20 basic blocks).  Whether dL/db2 is wanted stays
+// a runtime branch: as a template parameter the scheduler's longer reach costs its 16 accumulators 17 spills.
+template <bool PERM, bool EXTRA>
 __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     const uint32_t* __restrict__ rec, const int32_t* __restrict__ perm, const int32_t* __restrict__ keys,
     const float* __restrict__ extra, const float* __restrict__ w2, const float* __restrict__ w3, int64_t E,
@@ -843,7 +849,7 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
   __syncthreads();
   const int wfrag0 = c * 128 + ((g ^ wsw(c)) << 4), wfrag1 = wfrag0 ^ 64;
   const int colp = 16 * (((g & 1) << 1) | (g >> 1)) + c;
-  const bool has_extra = extra != nullptr;
+  constexpr bool has_extra = EXTRA;
   const bool run = rs.part != nullptr;
   float gcv[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 gb2a[4];                           // per (j = 16 jb + 4 g + i, edge slot c): sum of g_e m2[j][e] over tiles
@@ -857,8 +863,8 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
   TIds ids_nxt[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    cur[h] = load_rec(rec, extra, load_ids(perm, keys, E, tile, n_tiles, h, c), g);
-    ids_nxt[h] = load_ids(perm, keys, E, tile + stride, n_tiles, h, c);
+    cur[h] = load_rec<EXTRA>(rec, extra, load_ids<PERM>(perm, keys, E, tile, n_tiles, h, c), g);
+    ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile + stride, n_tiles, h, c);
   }
   int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile] : 0;
   for (; tile < n_tiles; tile += stride) {
@@ -869,8 +875,8 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     TIn nxt[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      nxt[h] = load_rec(rec, extra, ids_nxt[h], g);
-      ids_nxt[h] = load_ids(perm, keys, E, tile + 2 * stride, n_tiles, h, c);
+      nxt[h] = load_rec<EXTRA>(rec, extra, ids_nxt[h], g);
+      ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile + 2 * stride, n_tiles, h, c);
     }
     bf16x8 a2[2][2];
 #pragma unroll
@@ -1205,8 +1211,12 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
   const D16Run rs{part_buf, part_off};
   float* cv_slabs = g_cvec ? static_cast<float*>(workspace) : nullptr;
   float* b2_slabs = g_b2 ? static_cast<float*>(workspace) + (size_t)grid * 64 : nullptr;
-  hipLaunchKernelGGL(decoder_dgrad16_kernel, dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, keys, extra, w2,
-                     w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles);
+#define PG_T(P, X)                                                                                                 \
+  hipLaunchKernelGGL((decoder_dgrad16_kernel<P, X>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, keys,    \
+                     extra, w2, w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles)
+  if (perm) { if (extra) PG_T(true, true); else PG_T(true, false); }
+  else { if (extra) PG_T(false, true); else PG_T(false, false); }
+#undef PG_T
   PG_CHECK_LAUNCH(who);
   for (int x = 0; x < 2; ++x) {
     float* out = x ? g_b2 : g_cvec;
