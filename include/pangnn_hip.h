@@ -217,7 +217,7 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  *   is set.  Outputs: the parameter gradients g_w2[D,D], g_w3[D], g_b3[1], g_cvec[D] (nullable) — dL/db2 comes
  *   out of the dgrad pass (it needs only the records; keeping its per-lane partial sums out of this kernel is
  *   what lets two waves share a SIMD without spilling),
- *   rec[E][8] uint32 (nullable): per edge {4 dwords of relu masks, dL/dlogit_e, 3 unused} for the dgrad pass,
+ *   rec[E][8] uint32 (required): per edge {4 dwords of relu masks, dL/dlogit_e, 3 unused} for the dgrad pass,
  *   part_buf / part_off (both NULL or both set; edge list sorted by source): sums of dL/dh1 over every
  *   (32-edge tile, source) run, as in pangnn_decoder_mlp_bwd_f32.
  *   Arithmetic: every product on the bf16 matrix pipe with fp32 accumulation and fp32-exact operand handling —

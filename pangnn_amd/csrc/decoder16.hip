@@ -577,12 +577,12 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
     const int poff_nxt = (RUNSUM && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
     const int live_lim = (int)min((int64_t)31, a.E - 1 - tile * 32);   // uniform: positions <= live_lim are real edges
-    uint32_t* rec_tile = rec ? rec + tile * 256 : nullptr;             // 8 dwords per edge
-    float* logit_tile = logits ? logits + tile * 32 : nullptr;
+    uint32_t* rec_tile = rec + tile * 256;                             // 8 dwords per edge (rec is required)
+    float* logit_tile = logits + tile * 32;                            // (required with the fused loss, optional otherwise)
 #pragma unroll 1
     for (int hx = 0; hx < 2; ++hx) {
       // ids of the next half tile (this tile's second half, or the first half of the wave's next tile)
-      const HalfIn in_nxt = hx == 0 ? load_half<EXTRA>(a, auxp, tile, n_tiles, 1, c) : load_half<EXTRA>(a, auxp, tile + stride, n_tiles, 0, c);
+      const HalfIn in_nxt = load_half<EXTRA>(a, auxp, hx == 0 ? tile : tile + stride, n_tiles, hx ^ 1, c);    // one load site
       const int pos = 16 * hx + c;
       const bool live = pos <= live_lim;
 
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
         g_e = live ? in_cur.aux : 0.f;
       }
       gb3p += g_e;
-      if (logit_tile != nullptr && g == 0 && live) logit_tile[pos] = xv;
+      if ((FUSED_LOSS || logits != nullptr) && g == 0 && live) logit_tile[pos] = xv;
 
       // ---- m2 = [h2 > 0] as bf16 0/1 (A operand of P2 and, transposed through LDS, of P3); gw3 partials
       bf16x8 a2[2];
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       *reinterpret_cast<uint32_t*>(wv + WV_REC + 16 * c + 4 * g) = recw;
       *reinterpret_cast<float*>(wv + WV_GL + 4 * c) = g_e;               // the four lane groups write the same value
       if (has_extra) *reinterpret_cast<float*>(wv + WV_WL + 4 * c) = in_cur.w_e;
-      if (rec_tile != nullptr && live) {
+      if (live) {
         uint32_t* r = rec_tile + pos * 8;
         r[g] = recw;
         if (g == 0) r[4] = __builtin_bit_cast(uint32_t, g_e);
@@ -1146,7 +1146,7 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
                  who);
     PG_CHECK_ARG(aligned16(p) && aligned16(q) && aligned16(w2), PANGNN_E_ALIGN, "%s: p / q / w2 must be 16-byte aligned",
                  who);
-    PG_CHECK_ARG(!rec || aligned16(rec), PANGNN_E_ALIGN, "%s: rec must be 16-byte aligned", who);
+    PG_CHECK_ARG(rec && aligned16(rec), PANGNN_E_ALIGN, "%s: rec is required and must be 16-byte aligned", who);
     const uint32_t esz = pq16 ? 2u : 4u;
     D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
     const D16Loss lp{y, pos_weight, y ? 1.0f / (float)denom : 0.f};
