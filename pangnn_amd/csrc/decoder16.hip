@@ -596,8 +596,11 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       // the rows of the next half tile fly during the epilogue and the other two products
       issue_half_rows(a, in_nxt, g, rows);
 
-      // ---- loss, g_e
-      float g_e;
+      // ---- loss, g_e.  A lane past the end of the list looks at the list's last edge again (clamped ids): g_raw is
+      // that edge's dL/dlogit, bit-identical to what its own lane computes, so records and logits are stored by
+      // every lane without a predicate (a dead lane rewrites the last edge's values); only g_e, which feeds the sums,
+      // is zeroed.  No divergent store, hence no branch, in the loop body.
+      float g_e, g_raw;
       if (FUSED_LOSS) {
         const float y_e = in_cur.aux;
         const float scale = live ? lp.inv_denom : 0.f;
@@ -607,17 +610,20 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
         float ru = __builtin_amdgcn_rcpf(u);
         ru = ru * (2.f - u * ru);                     // 1 / (1 + t): one Newton step on the hardware reciprocal
         const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
-        g_e = ((1.f - y_e) - lw * sig_neg) * scale;
+        g_raw = ((1.f - y_e) - lw * sig_neg) * lp.inv_denom;
+        g_e = live ? g_raw : 0.f;
         const float um1 = u - 1.f;                    // log1p(t) = log(u) t / (u - 1), = t when u == 1
         float rm = __builtin_amdgcn_rcpf(um1);
         rm = rm * (2.f - um1 * rm);
         const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
         lossp = fmaf((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f)), scale, lossp);
       } else {
-        g_e = live ? in_cur.aux : 0.f;
+        g_raw = in_cur.aux;
+        g_e = live ? g_raw : 0.f;
       }
       gb3p += g_e;
-      if ((FUSED_LOSS || logits != nullptr) && g == 0 && live) logit_tile[pos] = xv;
+      const int posc = min(pos, live_lim);
+      if (FUSED_LOSS || logits != nullptr) logit_tile[posc] = xv;         // four lane groups, same value
 
       // ---- m2 = [h2 > 0] as bf16 0/1 (A operand of P2 and, transposed through LDS, of P3); gw3 partials
       bf16x8 a2[2];
@@ -692,10 +698,10 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       *reinterpret_cast<uint32_t*>(wv + WV_REC + 16 * c + 4 * g) = recw;
       *reinterpret_cast<float*>(wv + WV_GL + 4 * c) = g_e;               // the four lane groups write the same value
       if (has_extra) *reinterpret_cast<float*>(wv + WV_WL + 4 * c) = in_cur.w_e;
-      if (live) {
-        uint32_t* r = rec_tile + pos * 8;
+      {
+        uint32_t* r = rec_tile + posc * 8;
         r[g] = recw;
-        if (g == 0) r[4] = __builtin_bit_cast(uint32_t, g_e);
+        r[4] = __builtin_bit_cast(uint32_t, g_raw);                       // four lane groups, same value
       }
       wave_sync();
       p3_block(1);
