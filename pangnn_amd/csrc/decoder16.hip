@@ -838,7 +838,7 @@ __device__ __forceinline__ TIn load_rec(const uint32_t* rec, const float* extra,
 // PERM / EXTRA: permutation given, skip feature given — compile-time, so that the loads of the loop body sit in
 // straight-line code (as runtime-uniform branches they cut it into ~20 basic blocks).  Whether dL/db2 is wanted stays
 // a runtime branch: as a template parameter the scheduler's longer reach costs its 16 accumulators 17 spills.
-template <bool PERM, bool EXTRA>
+template <bool PERM, bool EXTRA, bool RUN>
 __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     const uint32_t* __restrict__ rec, const int32_t* __restrict__ perm, const int32_t* __restrict__ keys,
     const float* __restrict__ extra, const float* __restrict__ w2, const float* __restrict__ w3, int64_t E,
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
   const int wfrag0 = c * 128 + ((g ^ wsw(c)) << 4), wfrag1 = wfrag0 ^ 64;
   const int colp = 16 * (((g & 1) << 1) | (g >> 1)) + c;
   constexpr bool has_extra = EXTRA;
-  const bool run = rs.part != nullptr;
+  constexpr bool run = RUN;                 // run sums wanted (false: the parameter sums alone)
   float gcv[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 gb2a[4];                           // per (j = 16 jb + 4 g + i, edge slot c): sum of g_e m2[j][e] over tiles
 #pragma unroll
@@ -1228,8 +1228,14 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
   float* cv_slabs = g_cvec ? static_cast<float*>(workspace) : nullptr;
   float* b2_slabs = g_b2 ? static_cast<float*>(workspace) + (size_t)grid * 64 : nullptr;
 #define PG_T(P, X)                                                                                                 \
-  hipLaunchKernelGGL((decoder_dgrad16_kernel<P, X>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, keys,    \
-                     extra, w2, w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles)
+  do {                                                                                                             \
+    if (part_buf)                                                                                                  \
+      hipLaunchKernelGGL((decoder_dgrad16_kernel<P, X, true>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, \
+                         keys, extra, w2, w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles);                         \
+    else                                                                                                           \
+      hipLaunchKernelGGL((decoder_dgrad16_kernel<P, X, false>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec,      \
+                         perm, keys, extra, w2, w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles);                   \
+  } while (0)
   if (perm) { if (extra) PG_T(true, true); else PG_T(true, false); }
   else { if (extra) PG_T(false, true); else PG_T(false, false); }
 #undef PG_T
