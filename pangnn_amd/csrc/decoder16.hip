@@ -640,7 +640,8 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
             const uint32_t ta = min(__builtin_bit_cast(uint32_t, h2a), one), tb = min(__builtin_bit_cast(uint32_t, h2b), one);
             const uint32_t t2 = ta | (tb << 16);                      // the pair as two 0/1 halves
             m2 = (m2 << 1) | t2;
-            aw[jb >> 1][2 * (jb & 1) + pr] = t2 * 0x3f80u;             // bf16 1.0 / 0.0
+            aw[jb >> 1][2 * (jb & 1) + pr] = __umul24(t2, 0x3f80u);    // bf16 1.0 / 0.0 (v_mul_u32_u24: full rate; the
+                                                                      // optimiser cannot see t2 < 2^17 behind `one`)
           }
         a2[0] = __builtin_bit_cast(bf16x8, aw[0]);
         a2[1] = __builtin_bit_cast(bf16x8, aw[1]);
