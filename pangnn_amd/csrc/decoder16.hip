@@ -1022,8 +1022,10 @@ __global__ __launch_bounds__(I_WAVES * 64) void decoder_infer16_kernel(D16Params
     issue_half_rows(a, nxt, g, rows);                       // next tile's rows fly during the product
     f32x4 acc[4];
     const float xv = p1_logit<true>(lds, h, wfrag0, wfrag1, g, b3v, acc);
+    // no predicate (no branch in the loop body): a lane past the end looks at the last edge again (clamped ids) and
+    // rewrites its bit-identical logit; the four lane groups store the same value
     const int64_t e = tile * 16 + c;
-    if (g == 0 && e < a.E) logits[e] = xv;
+    logits[e < a.E ? e : a.E - 1] = xv;
     cur = nxt;
     nxt = nn;
   }
