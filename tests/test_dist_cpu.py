@@ -203,6 +203,16 @@ def test_partitioned_model_on_unequal_node_ranges(flags):
         assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(3))
 
 
+@pytest.mark.parametrize("uneven", [False, True], ids=["equal-ranges", "unequal-ranges"])
+def test_partitioned_model_on_eight_ranks(uneven):
+    """the rank count the 8-GPU node runs (gloo on the CPU): halo plans with empty sides, 100-node shards, both halo
+    exchanges of the decoder under its two passes"""
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "rdzv")
+        mp.spawn(_worker, args=(8, init_file, dict(skip_connections=True), d, "halo", True, uneven), nprocs=8, join=True)
+        assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(8))
+
+
 @pytest.mark.parametrize("flags", [dict(), dict(union_edge_weights=True)], ids=["default", "union"])
 def test_partitioned_model_allgather_exchange(flags):
     with tempfile.TemporaryDirectory() as d:
