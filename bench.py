@@ -299,6 +299,11 @@ def main():
 
     t_prop, t_dec, t_dgr = _avg("sim.fwd"), _avg("dec.bwd"), _avg("dec.dgrad")
     n_dgr = len(timer.get("dec.dgrad", [])) // max(args.steps, 1)
+    # launches of the S kernel per step: 1 on a whole graph, 2 on a shard (own-source edges, then halo-source edges);
+    # the roofline figures below are per STEP's worth of S launches (all of the rank's edges), not per launch
+    n_dec = max(len(timer.get("dec.bwd", [])) // max(args.steps, 1), 1)
+    if t_dec:
+        t_dec *= n_dec
 
     # ---- outside the headline: (i) the transposed conv_in propagate (removed from the default step by the fused
     # embedding operator: config 5's --categorical_node puts it back), timed on a fuse_embedding=False model;
@@ -388,9 +393,10 @@ def main():
                 "fp32_equivalent_tflops": 24576.0 * e_local / t_dec / 1e12,
                 "hbm": {"alg_bytes_per_launch": b_dec, "achieved": b_dec / t_dec / 1e9, "peak": HBM_PEAK / 1e9,
                         "achievable_peak": 6300.0, "unit": "GB/s", "frac": b_dec / t_dec / HBM_PEAK},
-                "avg_launch_ms": t_dec * 1e3, "share_of_step": t_dec / step_s,
-                "what_binds": "vector-instruction issue (~820 VALU + LDS + MFMA instructions per 16 edges at ~4 cycles "
-                              "each per SIMD; profiles/r02*_pmc_sq_*.txt), not the matrix pipe (30 % busy) nor HBM"}
+                "avg_launch_ms": t_dec * 1e3, "launches_per_step": n_dec, "share_of_step": t_dec / step_s,
+                "avg_launch_note": "duration of the step's S launches together (all of this rank's edges)" if n_dec > 1 else None,
+                "what_binds": "vector-instruction issue (611 vector incl. 84 MFMA + 88 LDS + 46 scalar instructions per 16 "
+                              "edges at two waves per SIMD; profiles/r02*_pmc_sq_*.txt), not the matrix pipe (36 % busy) nor HBM"}
         if t_dgr:
             n_parts_d = 0
             st_sim = getattr(graph, "_pangnn_structs", {}).get("sim", (None, None))[1]
