@@ -304,6 +304,8 @@ def main():
     n_dec = max(len(timer.get("dec.bwd", [])) // max(args.steps, 1), 1)
     if t_dec:
         t_dec *= n_dec
+    if t_dgr:
+        t_dgr *= max(n_dgr, 1)               # likewise for the T kernel (own-source / halo-source ranges on a shard)
 
     # ---- outside the headline: (i) the transposed conv_in propagate (removed from the default step by the fused
     # embedding operator: config 5's --categorical_node puts it back), timed on a fuse_embedding=False model;
