@@ -10,8 +10,10 @@ Workload (BASELINE.json: the config the metric is quoted on): `--simulate_datase
 (N = 1e6 genes, ~7.4e7 directed similarity edges, 3e6 neighbour edges), node_dim 64, hidden_dim 128,
 fp32, the whole graph as one batch.  A step = zero_grad -> forward -> BCEWithLogits(pos_weight) ->
 backward -> Adam; inputs are resident in HBM before the timed region; no host sync inside it.
-At N > 1 the same graph is destination-partitioned over the ranks (strong scaling) with RCCL
-all-gather / reduce-scatter of node embeddings (pangnn_amd/dist.py).
+At N > 1 the same graph is destination-partitioned over the ranks (strong scaling: node ranges with equal expected
+in-edge counts, rank-local generation) and the boundary-node rows travel by RCCL all-to-all-v — per step only the
+decoder's P halo and its gradient (on a side stream, under the decoder passes), two 1-row neighbour-graph halos and
+one flat 216 KB gradient all-reduce (pangnn_amd/dist.py; `exchange="allgather"` is the dense-halo alternative).
 
 One JSON line on rank 0: value = supervised similarity edges per second over the whole job.
 """
@@ -47,11 +49,61 @@ WORKLOADS = {
 }
 CFG5 = {"cfg5", "cfg5slice"}
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# what limits the S kernel (profiles/*_pmc_sq_decoder16.txt; updated with the kernel)
+S_BINDS = ("vector-instruction issue (611 vector incl. 84 MFMA + 88 LDS + 46 scalar instructions per 16 edges at two waves "
+           "per SIMD; profiles/r02zz_pmc_sq_decoder16.txt), not the matrix pipe (36 % busy) nor HBM")
 
 
 def spmm_alg_bytes(e, n, f, s=4):
     """B_spmm(E,N,F) = E*(4 + 4 + F*s) + N*F*s + (N+1)*8"""
     return e * (8 + f * s) + n * f * s + (n + 1) * 8
+
+
+def step_alg_bytes(n, e, e_nb, d, h, parts_s, parts_t, s_rows=4):
+    """Algorithmic HBM bytes of ONE default-topology train step as built (one term per kernel launch,
+    every gathered row counted once per edge, no cache credit), fp32 rows.  `parts_s` / `parts_t`: run-part rows the
+    S / T decoder kernels write (one per (32-edge tile, key) run).  The SURVEY.md §8d B_step (159 GB) describes the
+    layer-by-layer step of the reference; this step has no [E, 2D] tensors, no transposed conv_in propagate and
+    propagates on the 64-wide side."""
+    f = min(d, h)
+    lin = lambda k, m, gate=0: n * 4 * (k + m + gate)           # noqa: E731   node-level dense layer: read K, write M
+    t = {
+        "embed_h0": n * (4 + 4 * d),                                         # x [N] -> h0 [N, D]
+        "conv_in_propagate": spmm_alg_bytes(e, n, f, s_rows),                # the * kernel
+        "conv_in_linear": lin(d, h),
+        "conv_out_linear": lin(h, d),                                        # ELU folded in
+        "conv_out_propagate": spmm_alg_bytes(e_nb, n, d, s_rows),
+        "decoder_pq_linear": lin(d, 2 * d),
+        "decoder_S": e * 556 + parts_s * 4 * d,                              # ids 16 + P 256 + Q 256 + y 4 + logit 4 + record 20
+        "decoder_S_part_sum": parts_s * 4 * d + n * 4 * d + (n + 1) * 8,
+        "decoder_T": e * 28 + parts_t * 4 * d,                               # perm 4 + key 4 + record 20
+        "decoder_T_part_sum": parts_t * 4 * d + n * 4 * d + (n + 1) * 8,
+        "decoder_pq_dgrad": lin(2 * d, d, d),                                # + gate (pre-activation)
+        "decoder_pq_wgrad": lin(2 * d, d),
+        "conv_out_propagate_T": spmm_alg_bytes(e_nb, n, d, s_rows),
+        "conv_out_bias_sum": n * 4 * d,
+        "conv_out_dgrad": lin(d, h, h),
+        "conv_out_wgrad": lin(d, h),
+        "conv_in_dgrad": lin(h, d),
+        "conv_in_wgrad": lin(h, d),
+        "embedding_colsum": n * (4 * f + 8),
+    }
+    return t
+
+
+# kernel-name substrings of the three kernels whose counter traffic profiles/traffic.json holds (tools/update_traffic.py)
+TRAFFIC_KERNELS = {"decoder_train": "decoder_train16_kernel", "decoder_dgrad": "decoder_dgrad16_kernel",
+                   "spmm_fwd": "spmm_row_kernel<64, 4, false, false>"}
+
+
+def traffic_entry(prof, key, workload, world, e_sim):
+    """the profiles/traffic.json entry of kernel `key` IF it was collected on this workload, GPU count, edge count and
+    kernel name — otherwise None (the line then carries "traffic": null instead of a stale figure)"""
+    for ent in prof.get("entries", []):
+        if ent.get("key") == key and ent.get("workload") == workload and ent.get("n_gpus") == world \
+                and ent.get("sim_edges") == e_sim and TRAFFIC_KERNELS[key] in ent.get("kernel", ""):
+            return ent
+    return None
 
 
 def cpu_baseline(args, d, h):
@@ -71,7 +123,7 @@ def cpu_baseline(args, d, h):
     while steps < args.cpu_steps:
         go.train_step(m, opt, g, g.y, g.class_balance)
         steps += 1
-        if time.perf_counter() - t0 > 45.0:
+        if steps >= 3 and time.perf_counter() - t0 > 45.0:
             break
     dt = time.perf_counter() - t0
     e = g.edge_index.shape[1]
@@ -137,8 +189,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--genes", type=int, default=None, help="override genes per genome (debug)")
-    ap.add_argument("--cpu-genes", type=int, default=5000, help="genes per genome of the CPU-baseline sample (1/10 of cfg 4)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-genes", type=int, default=2500, help="genes per genome of the CPU-baseline sample (1/20 of cfg 4)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the strict-fp32 step and the transposed-propagate timing")
     ap.add_argument("--seed", type=int, default=0)
@@ -312,6 +364,7 @@ def main():
     # (ii) the strict-fp32 step (every decoder product on f32 MFMA: PANGNN_DECODER_PRECISION=0)
     extra = {}
     if world == 1 and not force_dist and not args.no_extras and not cfg5:
+        old_mode = PF.DECODER_PRECISION
         try:
             PF.KERNEL_TIMER = {"sim.bwd": []}
             m2 = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h], fuse_embedding=False)
@@ -322,7 +375,7 @@ def main():
             extra["bwd_avg_launch_ms"] = _avg("sim.bwd", PF.KERNEL_TIMER) * 1e3
             del m2, o2
             PF.KERNEL_TIMER = None
-            old_mode, PF.DECODER_PRECISION = PF.DECODER_PRECISION, 0
+            PF.DECODER_PRECISION = 0
             for _ in range(2):
                 step_fn()
             torch.cuda.synchronize()
@@ -332,7 +385,6 @@ def main():
                 step_fn()
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
-            PF.DECODER_PRECISION = old_mode
             extra["strict_fp32"] = {
                 "what": "the same step with every decoder product on v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains, "
                         "PANGNN_DECODER_PRECISION=0; [E,64] dL/dh1 round trip of round 1)",
@@ -340,6 +392,8 @@ def main():
                 "unit": "edges/s"}
         except Exception as ex:                                   # never lose the headline over an extra
             extra["extras_error"] = repr(ex)
+        finally:                                                  # whatever happened, the process is back in the mode
+            PF.DECODER_PRECISION = old_mode                       # the emitted line describes
             PF.KERNEL_TIMER = None
 
     if rank == 0:
@@ -353,8 +407,13 @@ def main():
                 prof = json.load(open(tf))
             except Exception:
                 prof = {}
-        key = f"{args.workload}_n{world}"
+        src_note = str(prof.get("_source", "profiles/"))
         step_s = dt / args.steps
+        # run-part rows written by the decoder's S (by source) and T (by target) kernels on this graph
+        st_sim = getattr(graph, "_pangnn_structs", {}).get("sim", (None, None))[1]
+        n_parts_s = getattr(getattr(st_sim, "_runsum", None), "n_parts", 0) if st_sim is not None else 0
+        pl = getattr(st_sim, "_csr_plans", {}).get("dst") if st_sim is not None else None
+        n_parts_d = pl.n_parts if pl is not None else 0
         line = {
             "metric": "edges/sec in GNN forward+backward (link-pred train step)",
             "value": e_sim * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
@@ -372,52 +431,65 @@ def main():
                        "arithmetic": "fp32 storage and accumulation everywhere; the three per-edge decoder products run on the bf16 "
                                      "matrix pipe with fp32-exact operand handling (W2 h1: both operands split into three bf16 terms, "
                                      "six partial products; dL/dh1 and dL/dW2: the relu mask is the exact bf16 operand, the other "
-                                     "operand is split three ways): logits within 2e-5 of an fp64 evaluation, gradients 1e-6 relative "
-                                     "(tests/test_hip_parity.py::test_decoder_training_kernels_vs_fp64); strict_fp32 = the f32-MFMA step",
+                                     "operand is split three ways): logits within 1.6e-5 of an fp64 evaluation, gradients within 1e-6 "
+                                     "of their scale (asserted: tests/test_hip_parity.py::test_decoder_training_kernels_vs_fp64); "
+                                     "strict_fp32 = the f32-MFMA step",
                        "graph_build_s": round(t_gen, 3), "warmup_incl_structure_s": round(t_struct, 3),
                        "final_loss": float(loss.item())},
         }
+        if world == 1 and not partitioned and not cfg5:
+            # step-level check: the per-kernel algorithmic bytes of the step AS BUILT, summed (DESIGN.md §4 formulas)
+            terms = step_alg_bytes(n, e_sim, e_nb, d, h, n_parts_s, n_parts_d)
+            tot = float(sum(terms.values()))
+            line["step_alg_bytes"] = tot
+            line["step_hbm_frac"] = tot / step_s / HBM_PEAK
+            line["step_alg_bytes_terms"] = terms
+            line["step_alg_bytes_note"] = ("sum over the step's kernel launches of their algorithmic bytes (every gathered row "
+                                           "counted once per edge, no cache credit; run-part rows: S " + str(n_parts_s) + ", T " +
+                                           str(n_parts_d) + "); step_hbm_frac = step_alg_bytes / ms_per_step / 8 TB/s")
         if t_dec:
-            # Dominant kernel of the step: decoder_train16_kernel (csrc/decoder16.hip; S in DESIGN.md §4).  Executed
-            # matrix-pipe work per 16 edges: 72 v_mfma_f32_16x16x32_bf16 + 12 v_mfma_f32_32x32x16_bf16 = 1 572 864 flop
-            # (fp32-equivalent: 3 products x 2*64*64 = 24 576 flop per edge).  Algorithmic bytes per edge: ids 16 +
-            # P row 256 + Q row 256 + label 4 + logit 4 + record 20, plus 256 B per (32-edge tile, source) part row.
-            n_parts_s = getattr(getattr(graph, "_pangnn_structs", {}).get("sim", (None, None))[1], "_runsum", None)
-            n_parts_s = getattr(n_parts_s, "n_parts", 0) if n_parts_s else 0
-            flop = 1572864.0 / 16.0 * e_local
+            # Dominant kernel of the step: decoder_train16_kernel (csrc/decoder16.hip; S in DESIGN.md §4).
+            # Algorithmic bytes per edge: ids 16 + P row 256 + Q row 256 + label 4 + logit 4 + record 20, plus 256 B per
+            # (32-edge tile, source) part row.  Matrix-pipe work per 16 edges: 72 v_mfma_f32_16x16x32_bf16 + 12
+            # v_mfma_f32_32x32x16_bf16 = 1 572 864 flop ISSUED, of which 3 products x 2*64*64 = 24 576 flop per edge
+            # are useful (the rest is the three-way exact operand split).
+            flop_issued = 1572864.0 / 16.0 * e_local
+            flop_useful = 24576.0 * e_local
             b_dec = e_local * 556.0 + n_parts_s * 256.0
+            ent = traffic_entry(prof, "decoder_train", args.workload, world, e_sim)
             line["roofline"] = {
-                "bound": "mfma", "kernel": "decoder_train16_kernel<fused loss, run sums> (largest kernel of the step)",
-                "achieved": flop / t_dec / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flop / t_dec / 1e12 / 2500.0,
-                "traffic": prof.get(key + "_decoder_train_bytes"),
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE of " + str(prof.get("_source", "profiles/")) +
-                                ", not this run; L2-fabric bytes, Infinity-Cache hits included",
-                "fp32_equivalent_tflops": 24576.0 * e_local / t_dec / 1e12,
-                "hbm": {"alg_bytes_per_launch": b_dec, "achieved": b_dec / t_dec / 1e9, "peak": HBM_PEAK / 1e9,
-                        "achievable_peak": 6300.0, "unit": "GB/s", "frac": b_dec / t_dec / HBM_PEAK},
+                "bound": "hbm", "kernel": "decoder_train16_kernel<fused loss, run sums> (largest kernel of the step)",
+                "achieved": b_dec / t_dec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": b_dec / t_dec / HBM_PEAK,
+                "frac_note": "algorithmic bytes per step's worth of S launches / launch time / 8 TB/s: HBM is the nearer of the "
+                             "kernel's two roofs (useful matrix flops are at mfma.useful_frac of the bf16 peak)",
+                "alg_bytes_per_launch": b_dec, "achievable_peak": 6300.0,
+                "traffic": ent["bytes_fetch_doubled"] if ent else None,
+                "traffic_note": ("rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE of " + src_note + ", same workload / "
+                                 "edge count / kernel name, not this run; L2-fabric bytes, Infinity-Cache hits included") if ent
+                else "no counter collection in profiles/traffic.json matches this workload, edge count and kernel name",
+                "mfma": {"peak_tflops": 2500.0, "useful_tflops": flop_useful / t_dec / 1e12,
+                         "useful_frac": flop_useful / t_dec / 1e12 / 2500.0,
+                         "issued_tflops": flop_issued / t_dec / 1e12, "issued_mfma_frac": flop_issued / t_dec / 1e12 / 2500.0,
+                         "note": "useful = 3 products x 2*64*64 flop per edge; issued = the bf16 MFMAs executed (x4: exact "
+                                 "three-term operand splits)"},
                 "avg_launch_ms": t_dec * 1e3, "launches_per_step": n_dec, "share_of_step": t_dec / step_s,
                 "avg_launch_note": "duration of the step's S launches together (all of this rank's edges)" if n_dec > 1 else None,
-                "what_binds": "vector-instruction issue (611 vector incl. 84 MFMA + 88 LDS + 46 scalar instructions per 16 "
-                              "edges at two waves per SIMD; profiles/r02*_pmc_sq_*.txt), not the matrix pipe (36 % busy) nor HBM"}
+                "what_binds": S_BINDS}
         if t_dgr:
-            n_parts_d = 0
-            st_sim = getattr(graph, "_pangnn_structs", {}).get("sim", (None, None))[1]
-            pl = getattr(st_sim, "_csr_plans", {}).get("dst") if st_sim is not None else None
-            n_parts_d = pl.n_parts if pl is not None else 0
             b_dg = e_local * 28.0 + n_parts_d * 256.0        # perm 4 + key 4 + record 20 per edge, part rows written
+            ent = traffic_entry(prof, "decoder_dgrad", args.workload, world, e_sim)
             line["roofline_dgrad"] = {
                 "bound": "hbm", "kernel": "decoder_dgrad16_kernel (dL/dh1 run sums by target from the per-edge records)",
                 "launches_per_step": n_dgr, "avg_launch_ms": t_dgr * 1e3, "alg_bytes_per_launch": b_dg,
                 "achieved": b_dg / t_dgr / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": b_dg / t_dgr / HBM_PEAK,
                 "mfma_tflops": 24 * 16384.0 / 16.0 * e_local / t_dgr / 1e12,
-                "traffic": prof.get(key + "_decoder_dgrad_bytes_fetch_undoubled"),
+                "traffic": ent["bytes_fetch_raw"] if ent else None,
                 "traffic_note": "FETCH_SIZE NOT doubled here (random 32-byte record gathers: the raw counter is one 64-B "
-                                "sector per edge) + WRITE_SIZE, " + str(prof.get("_source", "profiles/")) + ", not this run; "
-                                "both halves of a 32-edge tile share every W2' fragment read (its matrix phase ran the LDS array "
-                                "at its 256 B/clk limit with one fragment per MFMA) and the gathers run two stages ahead"}
+                                "sector per edge) + WRITE_SIZE, " + src_note + ", not this run"}
         if t_prop:
             b_alg = spmm_alg_bytes(e_local, rows_local, f_spmm)
-            traffic = prof.get(key + "_spmm_fwd_bytes")
+            ent = traffic_entry(prof, "spmm_fwd", args.workload, world, e_sim)
+            traffic = ent["bytes_fetch_doubled"] if ent else None
             line["roofline_propagate"] = {
                 "bound": "hbm", "kernel": f"spmm_row_kernel<{f_spmm}> (conv_in propagate fwd, the * kernel of SURVEY.md §8)",
                 "achieved": b_alg / t_prop / 1e9, "peak": HBM_PEAK / 1e9, "achievable_peak": 6300.0, "unit": "GB/s",
@@ -426,7 +498,7 @@ def main():
                              "the 8 TB/s spec; > 1 because the 256 MB source table is served from L2 / Infinity Cache",
                 "traffic": traffic,
                 "traffic_note": "L2-fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from " +
-                                str(prof.get("_source", "profiles/")) + ", not this run",
+                                src_note + ", same workload / edge count / kernel name, not this run",
                 "fabric_rate_GBps": (traffic / t_prop / 1e9) if traffic else None,
                 "fabric_rate_note": "7.4-7.9 TB/s is the guide's gather ceiling for a table of this size "
                                     "(MI355X_MICROARCH.md, indexed rows): the kernel sits at it",

@@ -59,7 +59,11 @@ constexpr int S_LDS = LDS_WAVE0 + S_WAVES * WV_BYTES;
 // s_setprio around every run of matrix instructions: with two to four waves per SIMD the arbiter otherwise lets a
 // wave in its vector phase starve the one feeding the matrix pipe; raised priority for the MFMA issuer keeps the
 // pipe busy while the other waves fill the issue slots in between (measured: -4 % on the S kernel).
+#ifdef PANGNN_D16_PROBE_NOPRIO          // tools/slp_probe.sh: diagnostic builds only
+#define D16_SETPRIO(x) ((void)0)
+#else
 #define D16_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 
 struct Split3 { bf16x8 hi, mid, lo; };
 // x = hi + mid + lo EXACTLY: three bf16 terms by truncation (8 + 8 + 8 significand bits, all of the sign of x).
@@ -204,9 +208,38 @@ __device__ __forceinline__ void stage_weights16(const float* w2, const float* b2
 
 // epilogue of P2: times g_e, masked by m1 (the record bits of the 16 edges in LDS)
 __device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl, int c, int g, f32x4 (&v)[4]) {
-  const f32x4 ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
   const int bitpos = 16 * (c & 1) + 7 - ((c & 7) >> 1);
   const char* rrow = recl + 64 * g + 4 * (c >> 3);      // edge 4 g + i at + 16 i; dwords (c >> 3) and 2 + (c >> 3)
+#if defined(PANGNN_D16_PROBE_GE_SCALAR) || defined(PANGNN_D16_PROBE_WAIT0)
+  // diagnostic builds (tools/slp_probe.sh): the same arithmetic with (a) g_e read as four dwords instead of one
+  // ds_read_b128, (b) every LDS operand of the epilogue landed (lgkmcnt(0) + idle cycles) before the first product
+  f32x4 ge4;
+#ifdef PANGNN_D16_PROBE_GE_SCALAR
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ge4[i] = *reinterpret_cast<const volatile float*>(gl + 16 * g + 4 * i);
+#else
+  ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
+#endif
+  uint32_t dd[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dd[i][0] = *reinterpret_cast<const uint32_t*>(rrow + 16 * i);
+    dd[i][1] = *reinterpret_cast<const uint32_t*>(rrow + 16 * i + 8);
+  }
+#ifdef PANGNN_D16_PROBE_WAIT0
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(ge4), "+v"(dd[0][0]), "+v"(dd[1][0]), "+v"(dd[2][0]), "+v"(dd[3][0]),
+               "+v"(dd[0][1]), "+v"(dd[1][1]), "+v"(dd[2][1]), "+v"(dd[3][1]) :: "memory");
+#endif
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int keep = __builtin_amdgcn_sbfe((int)dd[i][kb & 1], bitpos - 4 * (kb >> 1), 1);
+      const float val = v[kb][i] * ge4[i];
+      v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
+    }
+#else
+  const f32x4 ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i);          // kb even
@@ -219,6 +252,7 @@ __device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl,
       v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
     }
   }
+#endif
 }
 
 // ---- P2 + its epilogue + run sums, shared by S and T.  Lane (c = lane & 15, g = lane >> 4).

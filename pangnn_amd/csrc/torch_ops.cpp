@@ -7,6 +7,7 @@
 // torch.compile see ordinary dispatcher ops.  Built by csrc/Makefile into pangnn_amd/libpangnn_torch.so (g++ against
 // the torch headers; contains no device code).
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -23,6 +24,36 @@ const at::Tensor& on_gpu(const at::Tensor& t, const char* name) {
   return t;
 }
 
+// Every implementation forwards raw data_ptr()s to a kernel launched on `ref`'s device: each operand must live
+// there (a host pointer would be a GPU memory fault, not an exception) and have the dtype the C ABI reads it as.
+using DeviceGuard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
+
+void operand(const char* op, const char* name, const at::Tensor& t, const at::Tensor& ref, at::ScalarType dtype) {
+  TORCH_CHECK(t.defined(), "pangnn::", op, ": ", name, " is undefined");
+  TORCH_CHECK(t.is_cuda() && t.device() == ref.device(), "pangnn::", op, ": ", name, " is on ", t.device(),
+              " but the kernel runs on ", ref.device(), " (every operand must be on that GPU)");
+  TORCH_CHECK(t.scalar_type() == dtype, "pangnn::", op, ": ", name, " must be ", dtype, ", got ", t.scalar_type());
+  TORCH_CHECK(t.is_contiguous(), "pangnn::", op, ": ", name, " must be contiguous");
+}
+
+void operand_any_float(const char* op, const char* name, const c10::optional<at::Tensor>& t, const at::Tensor& ref) {
+  if (!t.has_value() || !t->defined()) return;
+  TORCH_CHECK(t->is_cuda() && t->device() == ref.device(), "pangnn::", op, ": ", name, " is on ", t->device(),
+              " but the kernel runs on ", ref.device(), " (every operand must be on that GPU)");
+  TORCH_CHECK(t->is_floating_point(), "pangnn::", op, ": ", name, " must be a floating-point tensor");
+}
+
+// CSR triple of one order: rowptr int64 [>= n_rows + 1], ids int32 [E]; E and the row pointer's last entry are the
+// caller's contract (graph.build_csr validates them once per graph; reading rowptr back here would be a host sync)
+void csr_operands(const char* op, const at::Tensor& rowptr, const at::Tensor& ids, const char* ids_name,
+                  const at::Tensor& ref, int64_t n_rows) {
+  operand(op, "rowptr", rowptr, ref, at::kLong);
+  operand(op, ids_name, ids, ref, at::kInt);
+  TORCH_CHECK(rowptr.dim() == 1 && ids.dim() == 1, "pangnn::", op, ": rowptr and ", ids_name, " must be 1-D");
+  TORCH_CHECK(n_rows >= 0 && rowptr.size(0) >= n_rows + 1, "pangnn::", op, ": rowptr has ", rowptr.size(0),
+              " entries for ", n_rows, " rows");
+}
+
 template <typename T>
 const T* opt_ptr(const c10::optional<at::Tensor>& t) {
   return (t.has_value() && t->defined()) ? t->data_ptr<T>() : nullptr;
@@ -34,6 +65,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> csr_from_coo(const at::Tensor& ed
   on_gpu(edge_index, "edge_index");
   TORCH_CHECK(edge_index.scalar_type() == at::kLong && edge_index.dim() == 2 && edge_index.size(0) == 2,
               "pangnn::csr_from_coo: edge_index must be int64 [2, E]");
+  TORCH_CHECK(num_nodes >= 0 && (group_by == 0 || group_by == 1), "pangnn::csr_from_coo: num_nodes >= 0, group_by in {0, 1}");
+  const DeviceGuard guard(edge_index.device());
   const at::Tensor ei = edge_index.contiguous();
   const int64_t e = ei.size(1);
   auto rowptr = at::empty({num_nodes + 1}, ei.options());
@@ -52,7 +85,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> csr_from_coo(const at::Tensor& ed
 std::tuple<at::Tensor, at::Tensor, at::Tensor> gcn_norm(const at::Tensor& rowptr, const at::Tensor& other,
                                                        const at::Tensor& perm, const c10::optional<at::Tensor>& w) {
   on_gpu(rowptr, "rowptr");
+  TORCH_CHECK(rowptr.dim() == 1 && rowptr.size(0) >= 1, "pangnn::gcn_norm: rowptr must be [N + 1]");
   const int64_t n = rowptr.size(0) - 1, e = other.size(0);
+  csr_operands("gcn_norm", rowptr, other, "other", rowptr, n);
+  operand("gcn_norm", "perm", perm, rowptr, at::kInt);
+  TORCH_CHECK(perm.dim() == 1 && perm.size(0) == e, "pangnn::gcn_norm: perm has ", perm.size(0), " entries for ", e, " edges");
+  operand_any_float("gcn_norm", "edge_weight", w, rowptr);
+  const DeviceGuard guard(rowptr.device());
   c10::optional<at::Tensor> wc;
   if (w.has_value() && w->defined()) {
     TORCH_CHECK(w->dim() == 1 && w->size(0) >= e, "pangnn::gcn_norm: edge_weight must be [E]");
@@ -74,8 +113,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> gcn_norm(const at::Tensor& rowptr
 at::Tensor spmm(const at::Tensor& rowptr, const at::Tensor& other, const c10::optional<at::Tensor>& val,
                 const at::Tensor& x, const c10::optional<at::Tensor>& bias, int64_t n_rows) {
   on_gpu(x, "x");
-  TORCH_CHECK(x.dim() == 2, "pangnn::spmm: x must be [n_src, F]");
-  TORCH_CHECK(rowptr.size(0) >= n_rows + 1, "pangnn::spmm: rowptr shorter than n_rows + 1");
+  TORCH_CHECK(x.dim() == 2 && x.is_floating_point(), "pangnn::spmm: x must be a floating-point [n_src, F]");
+  csr_operands("spmm", rowptr, other, "other", x, n_rows);
+  operand_any_float("spmm", "val", val, x);
+  operand_any_float("spmm", "bias", bias, x);
+  TORCH_CHECK(!(val.has_value() && val->defined()) || (val->dim() == 1 && val->size(0) == other.size(0)),
+              "pangnn::spmm: val must have one entry per CSR entry (", other.size(0), ")");
+  TORCH_CHECK(!(bias.has_value() && bias->defined()) || bias->numel() == x.size(1), "pangnn::spmm: bias must be [F]");
+  const DeviceGuard guard(x.device());
   const int64_t f = x.size(1);
   const bool bf16 = x.scalar_type() == at::kBFloat16 && (f == 32 || f == 64 || f == 128 || f == 256);
   at::Tensor xc = bf16 ? x.contiguous() : x.to(at::kFloat).contiguous();
@@ -102,7 +147,14 @@ at::Tensor spmm(const at::Tensor& rowptr, const at::Tensor& other, const c10::op
 at::Tensor propagate(const at::Tensor& rowptr, const at::Tensor& other, const at::Tensor& val, const at::Tensor& rowptr_t,
                      const at::Tensor& other_t, const at::Tensor& val_t, const at::Tensor& x,
                      const c10::optional<at::Tensor>& bias) {
-  (void)rowptr_t; (void)other_t; (void)val_t;
+  on_gpu(x, "x");
+  TORCH_CHECK(rowptr.dim() == 1 && rowptr.size(0) >= 1 && rowptr_t.dim() == 1 && rowptr_t.size(0) >= 1,
+              "pangnn::propagate: row pointers must be [N + 1]");
+  // the transposed triple is only used by the backward formula, but it is saved from here: fail now, not there
+  csr_operands("propagate", rowptr_t, other_t, "other_t", x, rowptr_t.size(0) - 1);
+  operand("propagate", "val_t", val_t, x, at::kFloat);
+  TORCH_CHECK(val_t.size(0) == other_t.size(0) && other_t.size(0) == other.size(0),
+              "pangnn::propagate: the two CSR orders hold different edge counts");
   return spmm(rowptr, other, val, x, bias, rowptr.size(0) - 1);
 }
 
@@ -112,6 +164,12 @@ at::Tensor edge_gather_concat(const at::Tensor& z, const at::Tensor& edge_index,
   on_gpu(edge_index, "edge_index");
   TORCH_CHECK(z.dim() == 2 && edge_index.dim() == 2 && edge_index.size(0) == 2 && edge_index.scalar_type() == at::kLong,
               "pangnn::edge_gather_concat: z [N, D], edge_index int64 [2, E]");
+  TORCH_CHECK(edge_index.device() == z.device(), "pangnn::edge_gather_concat: edge_index is on ", edge_index.device(),
+              " but the kernel runs on ", z.device());
+  operand_any_float("edge_gather_concat", "extra", extra, z);
+  TORCH_CHECK(!(extra.has_value() && extra->defined()) || extra->numel() >= edge_index.size(1),
+              "pangnn::edge_gather_concat: extra must have one entry per edge");
+  const DeviceGuard guard(z.device());
   const at::Tensor zc = z.to(at::kFloat).contiguous(), ei = edge_index.contiguous();
   c10::optional<at::Tensor> ex;
   if (extra.has_value() && extra->defined()) ex = extra->to(at::kFloat).contiguous();
@@ -129,6 +187,9 @@ at::Tensor segment_sum_rows(const at::Tensor& rowptr, const at::Tensor& perm, co
                             int64_t f, int64_t n_rows) {
   on_gpu(m, "m");
   TORCH_CHECK(m.dim() == 2 && col_off >= 0 && col_off + f <= m.size(1), "pangnn::segment_sum_rows: bad column window");
+  csr_operands("segment_sum_rows", rowptr, perm, "perm", m, n_rows);
+  TORCH_CHECK(perm.size(0) <= m.size(0), "pangnn::segment_sum_rows: perm addresses ", perm.size(0), " rows, m has ", m.size(0));
+  const DeviceGuard guard(m.device());
   const at::Tensor mc = m.to(at::kFloat).contiguous();
   auto out = at::empty({n_rows, f}, mc.options());
   check_rc(pangnn_segment_sum_rows_f32(rowptr.data_ptr<int64_t>(), perm.data_ptr<int32_t>(), mc.data_ptr<float>(),
@@ -142,6 +203,10 @@ at::Tensor segment_sum_rows(const at::Tensor& rowptr, const at::Tensor& perm, co
 std::tuple<at::Tensor, at::Tensor> segment_max_rows(const at::Tensor& rowptr, const at::Tensor& perm, const at::Tensor& m,
                                                     int64_t n_rows) {
   on_gpu(m, "m");
+  TORCH_CHECK(m.dim() == 2, "pangnn::segment_max_rows: m must be [E, F]");
+  csr_operands("segment_max_rows", rowptr, perm, "perm", m, n_rows);
+  TORCH_CHECK(perm.size(0) <= m.size(0), "pangnn::segment_max_rows: perm addresses ", perm.size(0), " rows, m has ", m.size(0));
+  const DeviceGuard guard(m.device());
   const at::Tensor mc = m.to(at::kFloat).contiguous();
   auto out = at::empty({n_rows, mc.size(1)}, mc.options());
   auto arg = at::empty({n_rows, mc.size(1)}, mc.options().dtype(at::kInt));
@@ -155,6 +220,12 @@ std::tuple<at::Tensor, at::Tensor> segment_max_rows(const at::Tensor& rowptr, co
 // segment_max_bwd(g f32[n_rows, F], arg i32[n_rows, F], rowptr, num_edges) -> f32 [E, F]
 at::Tensor segment_max_bwd(const at::Tensor& g, const at::Tensor& arg, const at::Tensor& rowptr, int64_t num_edges) {
   on_gpu(g, "g");
+  TORCH_CHECK(g.dim() == 2 && num_edges >= 0, "pangnn::segment_max_bwd: g must be [n_rows, F]");
+  operand("segment_max_bwd", "arg", arg, g, at::kInt);
+  operand("segment_max_bwd", "rowptr", rowptr, g, at::kLong);
+  TORCH_CHECK(arg.sizes() == g.sizes() && rowptr.size(0) >= g.size(0) + 1,
+              "pangnn::segment_max_bwd: arg must have g's shape and rowptr n_rows + 1 entries");
+  const DeviceGuard guard(g.device());
   const at::Tensor gc = g.to(at::kFloat).contiguous();
   auto gm = at::zeros({num_edges, gc.size(1)}, gc.options());
   check_rc(pangnn_segment_max_bwd_f32(gc.data_ptr<float>(), arg.data_ptr<int32_t>(), rowptr.data_ptr<int64_t>(),

@@ -4,8 +4,10 @@ One process per GPU (`torch.distributed`, backend "nccl" = RCCL).  The reference
 multi-device graph mode at all; this is the partitioning BASELINE.json's north
 star asks for, for the simulated graphs that do not need to — or cannot — sit on one GPU.
 
-Layout.  Nodes are split into `world` contiguous, equally sized ranges (the last one padded with
-isolated rows so that every collective is a fixed-size all-gather / reduce-scatter).  Rank r owns
+Layout.  Nodes are split into `world` contiguous ranges: by default (`bounds=balanced_bounds(...)`, what bench.py
+uses) ranges with equal EXPECTED in-edge counts, exchanged by halo all-to-all-v; equal node ranges (the last one
+padded with isolated rows) when `bounds` is None — the only layout the fixed-size all-gather / reduce-scatter
+exchange accepts.  Rank r owns
   * the rows [lo, hi) of every node tensor,
   * every edge whose TARGET it owns (similarity and neighbour graphs alike): a CSR over local target
     rows with GLOBAL source ids, so the propagate kernel reads an all-gathered source table and
@@ -176,7 +178,13 @@ class HaloPlan:
         self.group = group
         # A source-sorted list is [sources of lower ranks | own sources | sources of higher ranks]: the middle range
         # needs no exchanged row, so the decoder can run on it while the halo rows travel (decoder_loss_overlapped)
-        self.sorted_by_src = bool((new_src[1:] >= new_src[:-1]).all()) if new_src.numel() > 1 else True
+        sorted_here = bool((new_src[1:] >= new_src[:-1]).all()) if new_src.numel() > 1 else True
+        # Whether the collectives run at all, and which decoder path issues them, must be the SAME decision on every
+        # rank (a rank without boundary edges that skipped its all-to-all would leave the others' sequence numbers
+        # behind — and hang a back end that implements all-to-all as a true collective): both flags are global.
+        flag = torch.tensor([[0 if sorted_here else 1]], dtype=torch.int64, device=dev)
+        self.sorted_by_src = int(_all_gather_rows(flag, group).sum()) == 0      # MIN over ranks of "sorted here"
+        self.any_exchange = bool(int(all_counts.sum()) > 0)                      # anyone needs any row of anyone
         self.e_lo = int((new_src < self.n_low).sum())
         self.e_hi = int((new_src < self.n_low + n_local).sum())
         self._split_cache = {}
@@ -217,8 +225,8 @@ class HaloGather(torch.autograd.Function):
     def forward(ctx, x, plan: HaloPlan, accumulate_back):
         ctx.plan, ctx.acc = plan, accumulate_back
         x = x.contiguous()
-        if plan.n_halo == 0 and plan.send_idx.numel() == 0:
-            return x.view_as(x)                                 # nothing to exchange (one rank): the table IS the block
+        if not plan.any_exchange:
+            return x.view_as(x)                                 # no rank exchanges anything (one rank): the table IS the block
         send = x.index_select(0, plan.send_idx)
         recv = torch.empty((plan.n_halo,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         _all_to_all_v(recv, send, plan.recv_splits, plan.send_splits, plan.group)
@@ -228,7 +236,7 @@ class HaloGather(torch.autograd.Function):
     def backward(ctx, g):
         plan = ctx.plan
         g = g.contiguous()
-        if plan.n_halo == 0 and plan.send_idx.numel() == 0:
+        if not plan.any_exchange:
             return g, None, None
         g_halo = torch.cat([g[: plan.n_low], g[plan.n_low + plan.n_local:]], dim=0)
         back = torch.empty((plan.send_idx.numel(),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
@@ -471,7 +479,10 @@ class HipOps:
 
 
 class DistAlternateGCN(AlternateGCN):
-    """AlternateGCN (same parameters / state_dict) evaluated on a destination-partitioned shard."""
+    """AlternateGCN evaluated on a destination-partitioned shard.  Same parameters / state_dict as AlternateGCN (and the
+    reference, src/gnn.py:93-116) EXCEPT under `categorical_nodes=True`, where `embedding.weight` holds only the rows of
+    the nodes this rank owns: `full_state_dict()` / `load_full_state_dict()` convert to and from the reference layout
+    (`embedding.weight [N, D]`), `torch.save(model.state_dict())` of one rank alone is NOT a checkpoint then."""
 
     def __init__(self, device=None, dims=(64, 128), part=None, group=None, ops=None, exchange="halo",
                  categorical_nodes: bool = False, **kw):
@@ -485,6 +496,12 @@ class DistAlternateGCN(AlternateGCN):
             if part is None:
                 raise ValueError("categorical_nodes=True needs part= (the shard whose rows the embedding covers)")
             self.embedding = torch.nn.Embedding(int(part.n_local), dims[0])
+            # nn.Embedding draws N(0, 1) rows from the global generator, which every rank seeds alike: node i of every
+            # shard would start from the same vector.  Re-draw from a generator keyed on (seed, first owned node).
+            gen = torch.Generator().manual_seed((int(torch.initial_seed()) * 1000003 + int(part.lo) + 1) % (2 ** 63 - 1))
+            with torch.no_grad():
+                self.embedding.weight.copy_(torch.randn(self.embedding.weight.shape, generator=gen))
+            self._rows = (int(part.lo), int(part.hi), int(part.n_global))
             self.categorical_nodes = True
             if device is not None:
                 self.embedding.to(device)
@@ -543,7 +560,7 @@ class DistAlternateGCN(AlternateGCN):
         if isinstance(self.ops, HipOps) and PF.DECODER_PRECISION != 1:
             return False
         plan = self._plan(shard, "sim")
-        return plan.sorted_by_src and (plan.n_halo > 0 or plan.send_idx.numel() > 0)
+        return plan.sorted_by_src and plan.any_exchange           # both agreed over all ranks (HaloPlan.__init__)
 
     def _table(self, x_local, shard, name):
         """rows of every node this rank's `name` edges read: [own | halo] or the all-gathered [N_pad]"""
@@ -666,6 +683,40 @@ class DistAlternateGCN(AlternateGCN):
                                          pos_weight, shard.e_sim_total)
         out = self.decode_mlp(self.activation_fct(z) if fold else z, shard)
         return self.ops.bce_sum_over(out, labels, pos_weight, shard.e_sim_total), out.detach()
+
+    def full_state_dict(self):
+        """state_dict in the reference layout on EVERY rank: with a sharded categorical embedding the owned rows
+        (pad rows excluded) of all ranks are gathered into `embedding.weight [N, D]`; otherwise state_dict() itself"""
+        sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
+        if not self.sharded_embedding:
+            return sd
+        lo, hi, n = self._rows
+        w = self.embedding.weight.detach()
+        world = dist.get_world_size(self.group)
+        cnt = torch.zeros(world, dtype=torch.int64, device=w.device)
+        cnt[dist.get_rank(self.group)] = hi - lo
+        _all_reduce_sum_(cnt, self.group)
+        mx = int(cnt.max())
+        buf = w.new_zeros((mx, w.shape[1]))
+        buf[: hi - lo] = w[: hi - lo]
+        allb = _all_gather_rows(buf, self.group).view(world, mx, -1)
+        sd["embedding.weight"] = torch.cat([allb[r, : int(cnt[r])] for r in range(world)], dim=0)
+        assert sd["embedding.weight"].shape[0] == n
+        return sd
+
+    def load_full_state_dict(self, sd, strict: bool = True):
+        """inverse of full_state_dict: takes a reference-layout state_dict (`embedding.weight [N, D]`) and keeps this
+        rank's rows of the categorical embedding"""
+        if self.sharded_embedding:
+            lo, hi, n = self._rows
+            full = sd["embedding.weight"]
+            if full.shape[0] != n:
+                raise ValueError(f"embedding.weight has {full.shape[0]} rows, the graph has {n} nodes")
+            sd = dict(sd)
+            own = self.embedding.weight.detach().clone()
+            own[: hi - lo] = full[lo:hi].to(own)
+            sd["embedding.weight"] = own
+        return self.load_state_dict(sd, strict=strict)
 
     def sync_gradients(self):
         """one flat all-reduce (sum) of every parameter gradient: 216 KB at default dims"""

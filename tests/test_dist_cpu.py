@@ -111,11 +111,21 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=Tru
     # the exchange hides under the decoder exactly when there is one (halo exchange, source-sorted shard)
     assert model._overlap_ok(shard) == (overlap and exchange == "halo" and canonical)
     sd = oracle.state_dict()
-    if categorical:                                              # a rank holds the embedding rows of its own nodes
-        rows = torch.zeros(shard.n_local, 64)
-        rows[: shard.hi - shard.lo] = sd["embedding.weight"][shard.lo:shard.hi]
-        sd = dict(sd, **{"embedding.weight": rows})
-    model.load_state_dict(sd)
+    if categorical:
+        # ranks draw DIFFERENT rows at construction although every rank seeds alike (keyed on the first owned node)
+        first = model.embedding.weight[0].detach().clone()
+        others = [torch.zeros_like(first) for _ in range(world)]
+        dist.all_gather(others, first)
+        assert not torch.equal(others[0], others[1])
+    # reference-layout checkpoint in, this rank's rows of the categorical embedding kept (a rank holds the embedding
+    # rows of its own nodes); and back out: every rank reassembles the reference's [N, D] table
+    model.load_full_state_dict(sd)
+    if categorical:
+        assert torch.equal(model.embedding.weight[: shard.hi - shard.lo], sd["embedding.weight"][shard.lo:shard.hi])
+    back = model.full_state_dict()
+    assert list(back) == list(sd)
+    for k in sd:
+        assert torch.equal(back[k], sd[k]), k
     assert (shard.n_pad is None if uneven else shard.n_pad == shard.n_local * world)
     assert shard.e_sim_total == g.edge_index.shape[1] and shard.n_local == shard.hi - shard.lo or not uneven
     pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))

@@ -171,11 +171,9 @@ FLAG_SETS = [dict(), dict(skip_connections=True), dict(base_model=True), dict(un
              dict(union_edge_weights=True, neighbours=4), dict(decoder="cosine"), dict(decoder="dot")]
 
 
-@pytest.mark.parametrize("name,dims", [("sim_200x4", (64, 128)), ("cfg1_2genomes", (64, 128)),
-                                        ("cfg2_sim_1000x5", (64, 64)), ("cfg3_5genomes", (64, 128))])
-@pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k}={v}" for k, v in f.items()) or "default")
-def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
-    g, gd, oracle, model = _pair(name, dims, flags)
+def _check_logits_loss_grads_against_oracle(g, gd, oracle, model):
+    """HIP logits within 1e-4 of the fp32 oracle (north star), loss 1e-5, parameter gradients adjudicated against an
+    fp64 run of the same oracle"""
     ref = oracle(g)
     out = model(gd)
     assert out.shape == ref.shape == (g.edge_index.shape[1],)
@@ -196,6 +194,7 @@ def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
     g64_.edge_attr = g.edge_attr.double()
     torch.nn.functional.binary_cross_entropy_with_logits(o64(g64_), g.y.double(), pos_weight=pw.double()).backward()
     p64 = dict(o64.named_parameters())
+    worst = {}
     for k, p in model.named_parameters():
         if po[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
@@ -210,11 +209,48 @@ def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
         # for embedding.weight of sim_200x4 with skip connections, where fma(w, c, p + q) and (p + q) + w c round
         # differently), so that is the floor of the bound.
         scale = float(po[k].grad.abs().max()) + 1e-12
-        assert close(p.grad, po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), k
         g64 = p64[k].grad
         e_hip = float((p.grad.detach().cpu().double() - g64).abs().max()) / scale
         e_o32 = float((po[k].grad.double() - g64).abs().max()) / scale
+        worst[k] = (e_hip, e_o32)
         assert e_hip <= max(4.0 * e_o32 + 2e-5, 5e-4), (k, e_hip, e_o32)
+        # the direct fp32-vs-fp32 bound only where the fp32 ORACLE is itself a sound reference for it: on the 1.5e6-edge
+        # config-4-law graph its own sums (one fp32 chain per output over all edges) are up to 2e-3 of the scale from
+        # fp64, further than the HIP sums, and the fp64 adjudication above is the whole statement
+        if e_o32 <= 2.5e-4:
+            assert close(p.grad, po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), (k, e_hip, e_o32)
+    print("gradient distance to the fp64 oracle, of the tensor's scale (HIP, fp32 oracle):",
+          {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in worst.items()})
+    return out, ref, worst
+
+
+@pytest.mark.parametrize("name,dims", [("sim_200x4", (64, 128)), ("cfg1_2genomes", (64, 128)),
+                                        ("cfg2_sim_1000x5", (64, 64)), ("cfg3_5genomes", (64, 128))])
+@pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k}={v}" for k, v in f.items()) or "default")
+def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
+    g, gd, oracle, model = _pair(name, dims, flags)
+    _check_logits_loss_grads_against_oracle(g, gd, oracle, model)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True)], ids=["default", "skip"])
+def test_config4_edge_law_matches_oracle(flags):
+    """BASELINE config 4's own edge law at 1/50 scale — `--simulate_dataset 1000 20 0.2 100 20` (src/simulate.py:120-190:
+    m = 38 negatives per gene, negative-binomial in-degree tail >= 1 000; N = 20 000, E ~ 1.5e6) — against the oracle:
+    logits 1e-4, loss 1e-5, gradients adjudicated against the fp64 oracle.  (The golden graphs stop at E = 45 k and an
+    in-degree of a few hundred; the full-size run below can only check oracle-free invariants.)"""
+    from pangnn_amd import simulate
+    g = simulate.simulate_graph(1000, 20, 0.2, 100, 20, seed=3, device="cpu")
+    n, e = g.num_nodes, g.edge_index.shape[1]
+    indeg = torch.bincount(g.edge_index[1], minlength=n)
+    assert n == 20000 and 1.2e6 < e < 1.8e6 and int(indeg.max()) >= 600, (n, e, int(indeg.max()))
+    g, gd, oracle, model = _pair(g, (64, 128), flags)
+    out, ref, _ = _check_logits_loss_grads_against_oracle(g, gd, oracle, model)
+    # the one-pass training form (what bench.py times) on the same graph: same logits, same loss
+    model.zero_grad()
+    pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
+    loss, logits = model.loss_and_logits(gd, gd.y, pw.to(dev()))
+    assert close(logits, ref)
+    assert close(loss, torch.nn.functional.binary_cross_entropy_with_logits(ref, g.y, pos_weight=pw), atol=1e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("skip", [False, True])
@@ -798,15 +834,22 @@ def test_decoder_training_kernels_vs_fp64(e, skip, mode):
         out2 = PF.decoder_mlp(gl2[0], gl2[1], st, extra.to(dev()) if skip else None, gl2[6] if skip else None,
                               gl2[2], gl2[3], gl2[4], gl2[5])
         torch.nn.functional.binary_cross_entropy_with_logits(out2, y.to(dev()), pos_weight=pw.to(dev())).backward()
-    assert close(logits, ref, atol=2e-5, rtol=2e-5)                    # tighter than the 1e-4 gate
+    # Bounds = what the exact three-term operand split delivers (tools/check_decoder16.py prints logits 2e-6 .. 1e-5,
+    # gradients 6e-8 .. 2.5e-7 of the tensor's scale from 1 000 edges up) times 2 - 4, so that a dropped split term —
+    # round 1's two-term dL/dh1 / hi+mid-only dL/dW2 sat at 2 - 5e-6 — FAILS here.  Below 1 000 edges a gradient is a
+    # handful of terms whose common factor dL/dlogit carries the logit's own 2e-6 error (E = 1: every gradient 1.7e-6),
+    # and b3's is a cancelling sum (E = 33: 4e-6), so those keep a looser bound.
+    assert close(logits, ref, atol=1.6e-5, rtol=2e-6)                  # |logit| <= ~60 here; the gate is 1e-4
     assert close(loss, lref, atol=1e-6, rtol=1e-5)
+    tol = 1e-6 if e >= 1000 else 8e-6
     for i, name in enumerate(["P", "Q", "W2", "b2", "w3", "b3", "cvec"]):
         if name == "cvec" and not skip:
             continue
         rg = lv[i].grad
-        scale = float(rg.abs().max()) + 1e-12
-        assert close(gl[i].grad, rg, atol=1e-4 * scale + 1e-9, rtol=1e-3), name
-        assert close(gl2[i].grad, rg, atol=1e-4 * scale + 1e-9, rtol=1e-3), name
+        scale = float(rg.abs().max()) + 1e-30
+        for got in (gl[i].grad, gl2[i].grad):
+            err = float((got.detach().cpu().double() - rg).abs().max()) / scale
+            assert err <= tol, (name, err, tol)
 
 
 def test_bf16x3_mode_whole_model_and_f32_mode_agree():
@@ -1027,7 +1070,11 @@ def test_config5_slice_skip_connections_categorical_bf16_autocast():
     decoder in fp32-level arithmetic, so it must (i) agree with the autocast oracle to bf16 resolution, (ii) be at
     least as close to the fp32 oracle as the autocast oracle is, (iii) train: three steps lower the loss like the
     oracle's."""
-    g, gd, oracle, model = _pair("cfg2_sim_1000x5", (64, 64), dict(skip_connections=True), categorical=True)
+    _check_config5_flags_against_autocast_oracle(
+        *_pair("cfg2_sim_1000x5", (64, 64), dict(skip_connections=True), categorical=True))
+
+
+def _check_config5_flags_against_autocast_oracle(g, gd, oracle, model):
     pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
     exact = oracle(g)
     with torch.autocast("cpu", dtype=torch.bfloat16):
@@ -1054,6 +1101,84 @@ def test_config5_slice_skip_connections_categorical_bf16_autocast():
             l2, _ = go.train_step(oracle, opt_o, g, g.y, pw)
         lo.append(float(l2))
     assert lm[-1] < lm[0] and abs(lm[-1] - lo[-1]) < 5e-2 * abs(lo[0])
+
+
+def test_config5_edge_law_matches_autocast_oracle():
+    """BASELINE config 5's own edge law (`--simulate_dataset 200000 50 0.1 500 50`: m = floor(49 / 2 * 9) = 220 negatives
+    per gene towards the next genome, src/simulate.py:120-133) on 1 000 genes x 6 genomes, with config 5's flags
+    (`--skip_connections --categorical_node`, src/gnn.py:93,111,173) and hidden_dim 128 under bf16 autocast, against the
+    oracle under CPU bf16 autocast — the checks of the test above on the graph law the flags are quoted with."""
+    from pangnn_amd import simulate
+    g = simulate.simulate_graph(1000, 6, 0.1, 500, 50, seed=5, device="cpu", mean_neg=220, adjacent_only=True)
+    n, e = g.num_nodes, g.edge_index.shape[1]
+    assert n == 6000 and 1.5e6 < e < 3.0e6, (n, e)                       # ~ 2 * 5 * 1000 * 220 directed negatives
+    assert float(g.y.mean()) < 0.02
+    _check_config5_flags_against_autocast_oracle(
+        *_pair(g, (64, 128), dict(skip_connections=True), categorical=True))
+
+
+def test_full_size_config5_slice_invariants():
+    """One GPU's share of BASELINE config 5 at full size (`bench.py --workload cfg5slice`: 6 of the 50 genomes, 200 000
+    genes each, m = 220: N = 1.2e6, E ~ 4.4e8) with `--skip_connections --categorical_node` under bf16 autocast —
+    properties that need no oracle run (the pattern of test_full_size_config4_invariants):
+      * structure: rowptr ends at E, ascending edge ids inside a row, perm is a permutation (both CSR orders)
+      * only adjacent genomes are connected (what the 8-way partition's one-genome halo relies on)
+      * propagate on bfloat16-stored rows: <A x, y> == <x, A^T y>
+      * one-pass training decoder == forward + criterion + backward; everything finite"""
+    import pangnn_amd
+    from pangnn_amd import functional as PF
+    from pangnn_amd import simulate
+    from pangnn_amd.graph import structure_of
+    from pangnn_amd.train import criterion
+    g = simulate.simulate_graph(200000, 6, 0.1, 500, 50, seed=0, device=dev(), mean_neg=220, adjacent_only=True)
+    n, e = g.num_nodes, g.edge_index.shape[1]
+    assert n == 1_200_000 and 4.0e8 < e < 4.8e8 and g.neighbour_edge_index.shape[1] == 3 * n - 2
+    gs, gt = g.genome_of[g.edge_index[0]], g.genome_of[g.edge_index[1]]
+    assert bool(((gs - gt).abs() == 1).all())
+    del gs, gt
+    st = structure_of(g.edge_index, n, holder=g, name="sim")
+    for csr in (st.by_dst, st.by_src):
+        assert int(csr.rowptr[0]) == 0 and int(csr.rowptr[-1]) == e
+        assert bool((csr.rowptr[1:] >= csr.rowptr[:-1]).all())
+        inner = torch.ones(e, dtype=torch.bool, device=dev())
+        inner[csr.rowptr[:-1][csr.rowptr[:-1] < e]] = False            # first edge of each row
+        assert bool((csr.perm[1:] > csr.perm[:-1])[inner[1:]].all())    # ascending original id inside a row
+        del inner
+        seen = torch.zeros(e, dtype=torch.uint8, device=dev())
+        seen[csr.perm.long()] = 1
+        assert int(seen.sum(dtype=torch.int64)) == e                    # a permutation of the edge ids
+        del seen
+    nrm = st.gcn_norm(g.edge_attr)
+    x = torch.randn(n, 64, device=dev()).bfloat16()
+    y = torch.randn(n, 64, device=dev()).bfloat16()
+    ax = PF.spmm_csr(st.by_dst, nrm.by_dst, x, n)                       # pangnn_spmm_csr_bf16: rows gathered as stored
+    aty = PF.spmm_csr(st.by_src, nrm.by_src, y, n)
+    assert ax.dtype == torch.float32
+    l, r = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
+    assert abs(l - r) <= 1e-6 * max(abs(l), abs(r), 1.0)
+    del x, y, ax, aty
+    torch.manual_seed(0)
+    model = pangnn_amd.AlternateGCN(dev(), None, True, dims=[64, 128], num_nodes=n, skip_connections=True)
+    g.x = torch.arange(n, device=dev())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(g)
+        lu = criterion(out, g.y, g.class_balance)
+    lu.backward()
+    gu = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lf, logits = model.loss_and_logits(g, g.y, g.class_balance)
+    lf.backward()
+    assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(lf))
+    # Under autocast the two forms are not bit-identical: the training form folds the last ELU into the P|Q layer
+    # (in-kernel expm1), the forward form applies torch's ELU first — an fp32 ulp apart, which now and then flips the
+    # bf16 rounding of a stored P|Q element (2^-8 of the element).  Bound = a fraction of bf16 resolution.
+    assert close(logits, out, atol=1e-3, rtol=1e-3) and close(lf, lu, atol=1e-5, rtol=1e-4)
+    assert float((logits - out).abs().mean()) < 2e-5
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert bool(torch.isfinite(p.grad).all()), k
+            assert close(p.grad, gu[k], atol=2e-3 * (float(gu[k].abs().max()) + 1e-12) + 1e-10, rtol=1e-2), k
 
 
 # ---------------------------------------------------------------- bf16-storage modes (config 5: bf16 mixed precision)

@@ -75,6 +75,48 @@ def test_dispatcher_propagate_equals_ctypes_path_and_oracle():
 
 
 @pytest.mark.gpu
+def test_dispatcher_ops_reject_operands_on_another_device_or_of_the_wrong_type():
+    """the implementations forward raw data_ptr()s: an index / weight tensor left on the host (or of the wrong dtype,
+    or of the wrong length) must raise before any kernel sees its pointer (csrc/torch_ops.cpp: operand checks)"""
+    from pangnn_amd.graph import EdgeStructure
+    dev = torch.device("cuda:0")
+    n, e, f = 50, 400, 64
+    ei, w = random_graph(n, e, seed=5)
+    st = EdgeStructure(ei.to(dev), n)
+    norm = st.gcn_norm(w.to(dev))
+    d, s_ = st.by_dst, st.by_src
+    x = torch.randn(n, f, device=dev)
+    ops = torch.ops.pangnn
+    good = ops.spmm(d.rowptr, d.other, norm.by_dst, x, None, n)
+    bad_calls = [
+        lambda: ops.spmm(d.rowptr.cpu(), d.other, norm.by_dst, x, None, n),              # rowptr on the host
+        lambda: ops.spmm(d.rowptr, d.other.cpu(), norm.by_dst, x, None, n),              # ids on the host
+        lambda: ops.spmm(d.rowptr, d.other, norm.by_dst.cpu(), x, None, n),              # weights on the host
+        lambda: ops.spmm(d.rowptr, d.other, norm.by_dst, x, torch.zeros(f), n),          # bias on the host
+        lambda: ops.spmm(d.rowptr, d.other.long(), norm.by_dst, x, None, n),             # ids of the wrong dtype
+        lambda: ops.spmm(d.rowptr.int(), d.other, norm.by_dst, x, None, n),              # rowptr of the wrong dtype
+        lambda: ops.spmm(d.rowptr, d.other, norm.by_dst[:-1], x, None, n),               # one weight short
+        lambda: ops.spmm(d.rowptr, d.other, norm.by_dst, x, None, n + 1),                # more rows than rowptr holds
+        lambda: ops.propagate(d.rowptr, d.other, norm.by_dst, s_.rowptr, s_.other.cpu(), norm.by_src, x, None),
+        lambda: ops.propagate(d.rowptr, d.other, norm.by_dst, s_.rowptr, s_.other, norm.by_src.cpu(), x, None),
+        lambda: ops.gcn_norm(d.rowptr, d.other.cpu(), d.perm, None),
+        lambda: ops.gcn_norm(d.rowptr, d.other, d.perm.cpu(), None),
+        lambda: ops.gcn_norm(d.rowptr, d.other, d.perm, w),                               # weights on the host
+        lambda: ops.segment_sum_rows(d.rowptr, d.perm.cpu(), torch.randn(e, f, device=dev), 0, f, n),
+        lambda: ops.segment_max_rows(d.rowptr.cpu(), d.perm, torch.randn(e, 8, device=dev), n),
+        lambda: ops.segment_max_bwd(torch.randn(n, 8, device=dev), torch.zeros(n, 8, dtype=torch.int32), d.rowptr, e),
+        lambda: ops.edge_gather_concat(x, ei, None),                                      # edge_index on the host
+        lambda: ops.edge_gather_concat(x, ei.to(dev), w),                                 # extra on the host
+    ]
+    for i, call in enumerate(bad_calls):
+        with pytest.raises(RuntimeError):
+            call()
+            pytest.fail(f"bad call {i} did not raise")
+    torch.cuda.synchronize()
+    assert torch.equal(good, ops.spmm(d.rowptr, d.other, norm.by_dst, x, None, n))      # the GPU is still healthy
+
+
+@pytest.mark.gpu
 def test_autocast_policy_and_compile():
     from pangnn_amd import torch_ops
     from pangnn_amd.graph import EdgeStructure
