@@ -35,7 +35,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int D16 = 64;
 constexpr int SLAB16 = 64 * 64 + 64 + 64 + 64 + 16;   // gW2 | gb2 | gw3 | gcvec | gb3, loss (+pad): layout of decoder.hip
+#ifdef PANGNN_D16_PROBE_ONE_WAVE        // tools/slp_probe.sh: diagnostic builds only (one wave per SIMD)
+constexpr int S_WAVES = 4;
+#else
 constexpr int S_WAVES = 8;                            // 512 threads, one workgroup per CU, two waves per SIMD
+#endif
 constexpr int T_WAVES = 16;                           // dgrad kernel: four waves per SIMD (128 registers each): its record gathers are latency bound
 
 // ---- LDS images.  Rows of 64 bf16 = 128 B = 8 chunks of 16 B, unpadded; chunk ch of row r sits at
@@ -248,7 +252,10 @@ __device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl,
     for (int kb = 0; kb < 4; ++kb) {
       const uint32_t d = (kb & 1) ? d1 : d0;
       const int keep = __builtin_amdgcn_sbfe((int)d, bitpos - 4 * (kb >> 1), 1);     // 0 or -1
-      const float val = v[kb][i] * ge4[i];
+      float val = v[kb][i] * ge4[i];
+#ifdef PANGNN_D16_PROBE_OPAQUE_EPI
+      asm volatile("" : "+v"(val));
+#endif
       v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
     }
   }
@@ -337,7 +344,16 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], unsigned m16, floa
     // no boundary before the last edge: one run (open or closing at edge 15)
     float x[4];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) x[kb] = (v[kb][0] + v[kb][1]) + (v[kb][2] + v[kb][3]);
+    for (int kb = 0; kb < 4; ++kb) {
+#ifdef PANGNN_D16_PROBE_OPAQUE_RUNSUM
+      float t0 = v[kb][0] + v[kb][1], t1 = v[kb][2] + v[kb][3];
+      asm volatile("" : "+v"(t0), "+v"(t1));
+      x[kb] = t0 + t1;
+      asm volatile("" : "+v"(x[kb]));
+#else
+      x[kb] = (v[kb][0] + v[kb][1]) + (v[kb][2] + v[kb][3]);
+#endif
+    }
     const float s = carry + red4(x[0], x[1], x[2], x[3]);
     if (m16 & 0x8000u) {
       part[pidx * D16 + colp] = s;
@@ -359,6 +375,9 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], unsigned m16, floa
         const bool first = 4 * g + i <= bnd;
         a[kb] += first ? v[kb][i] : 0.f;
         b[kb] += first ? 0.f : v[kb][i];
+#ifdef PANGNN_D16_PROBE_OPAQUE_RUNSUM
+        asm volatile("" : "+v"(a[kb]), "+v"(b[kb]));
+#endif
       }
     }
     const float lo = carry + red4(a[0], a[1], a[2], a[3]);
@@ -760,7 +779,12 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], v[kb][i], gcv[kb]);
+            for (int i = 0; i < 4; ++i) {
+              gcv[kb] = fmaf(w4[i], v[kb][i], gcv[kb]);
+#ifdef PANGNN_D16_PROBE_OPAQUE_GCV
+              asm volatile("" : "+v"(gcv[kb]));
+#endif
+            }
         }
         if (RUNSUM) {
           const bool closes = in_cur.key != in_cur.key_nxt || pos == 31;

@@ -708,6 +708,53 @@ def test_full_size_config4_invariants():
             assert close(p.grad, gu[k], atol=1e-4 * (float(gu[k].abs().max()) + 1e-12) + 1e-10, rtol=1e-3), k
 
 
+@pytest.mark.parametrize("skip", [False, True], ids=["default", "skip"])
+def test_full_size_S_and_T_kernels_agree_on_by_source_sums(skip):
+    """BASELINE config 4 at full size, the two decoder kernels against EACH OTHER: dL/dP summed by source comes (i) out of
+    the S kernel's own second product (per-(tile, source) run parts) and (ii) out of the T kernel's second product over
+    the per-edge records S wrote, taken in by-source order.  Two kernels, two schedules, the same arithmetic in the same
+    order: the [N, 64] results must be BIT-identical.  2.3e6 tiles per run — this is the check that exposes an
+    intermittent per-tile miscompute (round 2's SLP build of the S kernel: dL/dh1 = v * (+0) for one edge of ~2 % of the
+    half tiles in the skip-connection instances; tools/check_isa.py) that 1e4-tile unit cases miss."""
+    from pangnn_amd import functional as PF
+    from pangnn_amd import simulate
+    from pangnn_amd.graph import structure_of
+    g = simulate.simulate_graph(50000, 20, 0.2, 100, 20, seed=0, device=dev())
+    n, e = g.num_nodes, g.edge_index.shape[1]
+    st = structure_of(g.edge_index, n, holder=g, name="sim")
+    assert st.runsum_plan() is not None                                   # canonical (source-sorted) order
+    torch.manual_seed(1)
+    P, Q = torch.randn(n, 64, device=dev()), torch.randn(n, 64, device=dev())
+    W2, b2 = torch.randn(64, 64, device=dev()) / 8, torch.randn(64, device=dev())
+    w3, b3 = torch.randn(64, device=dev()), torch.randn(1, device=dev())
+    cv = torch.randn(64, device=dev()) if skip else None
+    ex = (g.edge_attr / 40).contiguous() if skip else None
+    pw = g.class_balance.reshape(1).float().contiguous()
+    loss, logits, gp_s, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = PF._decoder_train16(P, Q, st, ex, cv, W2, b2, w3, b3, y=g.y, pw=pw,
+                                                                              denom=e)
+    assert bool(torch.isfinite(loss).all()) and bool(torch.isfinite(gp_s).all())
+    # the same sums from the records, through the T kernel over the by-source CSR (identity permutation here, but the
+    # kernel gathers through it all the same) — and once more through S for run-to-run reproducibility
+    rec = torch.empty(e, 8, dtype=torch.int32, device=dev())
+    lib = PF._lib.load()
+    plan = st.runsum_plan()
+    parts = torch.empty(plan.n_parts, 64, device=dev())
+    outs = [torch.empty_like(W2), torch.empty_like(w3), torch.empty_like(b3)]
+    ws = torch.empty(lib.pangnn_decoder_train_workspace_bytes(), dtype=torch.uint8, device=dev())
+    lg, ls = torch.empty(e, device=dev()), torch.empty(1, device=dev())
+    PF._lib.check(lib.pangnn_decoder_train_mixed(
+        P.data_ptr(), 64, Q.data_ptr(), 64, 0, n, st.edge_index.data_ptr(), e, e, PF._lib.ptr(ex), PF._lib.ptr(cv),
+        W2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), 64, g.y.data_ptr(), pw.data_ptr(), e, None, lg.data_ptr(),
+        ls.data_ptr(), rec.data_ptr(), parts.data_ptr(), plan.part_off.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
+        outs[2].data_ptr(), None if cv is None else torch.empty_like(cv).data_ptr(), ws.data_ptr(), ws.numel(),
+        PF._lib.stream_ptr()), "pangnn_decoder_train_mixed")
+    gp_s2 = PF._sum_parts(plan, parts, n, torch.empty(n, 64, device=dev()))
+    assert torch.equal(gp_s2, gp_s) and torch.equal(lg, logits)
+    gp_t = PF._dgrad_sum(rec, st, "src", W2, w3, n)
+    bad = (gp_t != gp_s).any(1)
+    assert not bool(bad.any()), f"{int(bad.sum())} of {n} source rows differ between the S and the T kernel"
+
+
 # ---------------------------------------------------------------- edge cases of the whole module
 def test_model_on_degenerate_graphs():
     """no similarity edges at all; a single node; isolated nodes; E not a multiple of the 32-edge tile"""
@@ -1178,7 +1225,8 @@ def test_full_size_config5_slice_invariants():
     for k, p in model.named_parameters():
         if p.grad is not None:
             assert bool(torch.isfinite(p.grad).all()), k
-            assert close(p.grad, gu[k], atol=2e-3 * (float(gu[k].abs().max()) + 1e-12) + 1e-10, rtol=1e-2), k
+            # gradients of bf16-stored tensors are bf16 (one ulp = 2^-8 of the element), rounded at different points
+            assert close(p.grad, gu[k], atol=1e-2 * (float(gu[k].abs().max()) + 1e-12) + 1e-12, rtol=5e-2), k
 
 
 # ---------------------------------------------------------------- bf16-storage modes (config 5: bf16 mixed precision)

@@ -20,3 +20,10 @@ build slp_nopk "-Xclang -target-feature -Xclang -packed-fp32-ops"    # SLP on, p
 build slp_gescalar "-DPANGNN_D16_PROBE_GE_SCALAR"                    # SLP on, g_e read as 4 dwords
 build slp_wait0 "-DPANGNN_D16_PROBE_WAIT0"                           # SLP on, LDS operands landed + 16 idle cycles before the products
 build slp_noprio "-DPANGNN_D16_PROBE_NOPRIO"                         # SLP on, no s_setprio
+build slp_opq_epi "-DPANGNN_D16_PROBE_OPAQUE_EPI"                    # SLP on, the epilogue's products opaque (not packable)
+build slp_opq_runsum "-DPANGNN_D16_PROBE_OPAQUE_RUNSUM"              # SLP on, the run sums' partial sums opaque
+build slp_opq_gcv "-DPANGNN_D16_PROBE_OPAQUE_GCV"                    # SLP on, the skip-feature gradient accumulation opaque
+build slp_onewave "-DPANGNN_D16_PROBE_ONE_WAVE"                      # SLP on, one wave per SIMD (256-thread workgroups)
+build noslp_onewave "-fno-slp-vectorize -DPANGNN_D16_PROBE_ONE_WAVE" # control for the tile -> wave mapping of that build
+build noslp_dbg "-fno-slp-vectorize -DPANGNN_D16_DEBUG"              # dL/dh1 rows dumped (tools/slp_probe_rows.py): control
+build slp_dbg   "-DPANGNN_D16_DEBUG"                                 # dL/dh1 rows dumped, SLP on
