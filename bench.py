@@ -65,12 +65,11 @@ def step_alg_bytes(n, e, e_nb, d, h, parts_s, parts_t, s_rows=4):
     S / T decoder kernels write (one per (32-edge tile, key) run).  The SURVEY.md §8d B_step (159 GB) describes the
     layer-by-layer step of the reference; this step has no [E, 2D] tensors, no transposed conv_in propagate and
     propagates on the 64-wide side."""
-    f = min(d, h)
     lin = lambda k, m, gate=0: n * 4 * (k + m + gate)           # noqa: E731   node-level dense layer: read K, write M
     t = {
-        "embed_h0": n * (4 + 4 * d),                                         # x [N] -> h0 [N, D]
-        "conv_in_propagate": spmm_alg_bytes(e, n, f, s_rows),                # the * kernel
-        "conv_in_linear": lin(d, h),
+        # conv_in(embedding(x)) by linearity (functional._EmbedConvIn): r a^T + s c^T + b_in written once; the similarity-
+        # graph propagate (the * kernel) runs once per GRAPH for r = A_hat x, s = A_hat 1, not per step
+        "conv_in_rank2_rows": n * (8 + 4 * h),
         "conv_out_linear": lin(h, d),                                        # ELU folded in
         "conv_out_propagate": spmm_alg_bytes(e_nb, n, d, s_rows),
         "decoder_pq_linear": lin(d, 2 * d),
@@ -84,9 +83,7 @@ def step_alg_bytes(n, e, e_nb, d, h, parts_s, parts_t, s_rows=4):
         "conv_out_bias_sum": n * 4 * d,
         "conv_out_dgrad": lin(d, h, h),
         "conv_out_wgrad": lin(d, h),
-        "conv_in_dgrad": lin(h, d),
-        "conv_in_wgrad": lin(h, d),
-        "embedding_colsum": n * (4 * f + 8),
+        "conv_in_colsum3": n * (4 * h + 8),                                  # [r s 1]^T dL/dh1pre: all of the layer's backward
     }
     return t
 
@@ -359,20 +356,23 @@ def main():
     if t_dgr:
         t_dgr *= max(n_dgr, 1)               # likewise for the T kernel (own-source / halo-source ranges on a shard)
 
-    # ---- outside the headline: (i) the transposed conv_in propagate (removed from the default step by the fused
-    # embedding operator: config 5's --categorical_node puts it back), timed on a fuse_embedding=False model;
+    # ---- outside the headline: (i) the conv_in propagate and its transpose — the * kernel of SURVEY.md §8.  The default
+    # step evaluates conv_in(embedding(x)) by linearity and runs that propagate once per graph, not per step (config 5's
+    # --categorical_node, the union / hidden layers and every mini-batch run it per step): timed here on a layer-by-layer
+    # (fuse_embedding=False) model over the same graph;
     # (ii) the strict-fp32 step (every decoder product on f32 MFMA: PANGNN_DECODER_PRECISION=0)
     extra = {}
     if world == 1 and not force_dist and not args.no_extras and not cfg5:
         old_mode = PF.DECODER_PRECISION
         try:
-            PF.KERNEL_TIMER = {"sim.bwd": []}
+            PF.KERNEL_TIMER = {"sim.fwd": [], "sim.bwd": []}
             m2 = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h], fuse_embedding=False)
             o2 = make_optimizer(m2)
-            for _ in range(3):
+            for _ in range(4):
                 train_step(m2, o2, graph, labels, pos_weight)
             torch.cuda.synchronize()
             extra["bwd_avg_launch_ms"] = _avg("sim.bwd", PF.KERNEL_TIMER) * 1e3
+            extra["prop_fwd_s"] = _avg("sim.fwd", PF.KERNEL_TIMER)
             del m2, o2
             PF.KERNEL_TIMER = None
             PF.DECODER_PRECISION = 0
@@ -434,6 +434,12 @@ def main():
                                      "operand is split three ways): logits within 1.6e-5 of an fp64 evaluation, gradients within 1e-6 "
                                      "of their scale (asserted: tests/test_hip_parity.py::test_decoder_training_kernels_vs_fp64); "
                                      "strict_fp32 = the f32-MFMA step",
+                       "first_layer": "conv_in(embedding(x)) evaluated by linearity: A_hat (x w^T + 1 b^T) W^T + b_in = r a^T + s c^T + "
+                                      "b_in; the node vectors r = A_hat x, s = A_hat 1 come from ONE similarity-graph propagate per graph "
+                                      "(in the warm-up, cached like gcn_norm), per step the layer is one [N, H] write and one pass over "
+                                      "its gradient; same logits / gradients as the layer-by-layer form up to fp32 re-association "
+                                      "(tests/test_hip_parity.py::test_fused_embedding_layer_equals_layerwise_form_and_oracle)"
+                                      if not cfg5 else "categorical embedding: layer by layer (propagate every step)",
                        "graph_build_s": round(t_gen, 3), "warmup_incl_structure_s": round(t_struct, 3),
                        "final_loss": float(loss.item())},
         }
@@ -486,6 +492,9 @@ def main():
                 "traffic": ent["bytes_fetch_raw"] if ent else None,
                 "traffic_note": "FETCH_SIZE NOT doubled here (random 32-byte record gathers: the raw counter is one 64-B "
                                 "sector per edge) + WRITE_SIZE, " + src_note + ", not this run"}
+        per_step_prop = bool(t_prop)
+        if not t_prop:
+            t_prop = extra.get("prop_fwd_s")
         if t_prop:
             b_alg = spmm_alg_bytes(e_local, rows_local, f_spmm)
             ent = traffic_entry(prof, "spmm_fwd", args.workload, world, e_sim)
@@ -502,7 +511,11 @@ def main():
                 "fabric_rate_GBps": (traffic / t_prop / 1e9) if traffic else None,
                 "fabric_rate_note": "7.4-7.9 TB/s is the guide's gather ceiling for a table of this size "
                                     "(MI355X_MICROARCH.md, indexed rows): the kernel sits at it",
-                "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_prop * 1e3, "share_of_step": t_prop / step_s,
+                "alg_bytes_per_launch": b_alg, "avg_launch_ms": t_prop * 1e3,
+                "share_of_step": (t_prop / step_s) if per_step_prop else 0.0,
+                "in_step": "every step" if per_step_prop else
+                           "once per graph (r = A_hat x, s = A_hat 1: conv_in(embedding(x)) = r a^T + s c^T + b_in by linearity, "
+                           "functional._EmbedConvIn); timed here on the layer-by-layer model, outside the headline",
                 "bwd_avg_launch_ms": extra.get("bwd_avg_launch_ms", (_avg("sim.bwd") or 0) * 1e3 or None)}
         for k_ in ("strict_fp32", "extras_error"):
             if k_ in extra:

@@ -332,6 +332,23 @@ int    pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const float* r, c
                                   pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The first GCN layer of the scalar-feature model as a rank-2 matrix (replaces, for `conv_in(embedding(x))`
+ * of src/gnn.py:97,125,156-158 / :143-146 / :128-131, the embedding Linear(1, D), the propagate and GCNConv.lin):
+ *   h0 = x w^T + 1 b^T (one scalar x per node)  =>  A_hat (h0) W^T + b_in = r a^T + s c^T + b_in,
+ *   r = A_hat x, s = A_hat 1 (node vectors, once per graph: pangnn_spmm_csr_f32 on a 2-column table),
+ *   a = W w, c = W b (H-vectors, per step; propagate and dense layer commute, so the same holds for D >= H).
+ * pangnn_rank2_rows:       out[n, :] = r[n] a + s[n] c + bias   (out [N, F] stored as f32 or bf16, F % 4 == 0)
+ * pangnn_weighted_colsum3: out[0] = sum_n r[n] g[n,:], out[1] = sum_n s[n] g[n,:], out[2] = sum_n g[n,:]  (out [3, F]):
+ *   everything the layer's backward needs — dL/da, dL/dc, dL/db_in — from which dL/dW = dL/da w^T + dL/dc b^T,
+ *   dL/dw = W^T dL/da, dL/db = W^T dL/dc.  g stored as f32 or bf16; reproducible two-stage sum.
+ * ---------------------------------------------------------------------------------------- */
+int    pangnn_rank2_rows(const float* r, const float* s, const float* a, const float* c, const float* bias, void* out,
+                         int32_t out_dtype, int64_t ldo, int64_t n, int32_t F, pangnn_stream_t stream);
+size_t pangnn_weighted_colsum3_workspace_bytes(int32_t F);
+int    pangnn_weighted_colsum3(const void* g, int32_t g_dtype, int64_t ldg, const float* r, const float* s, int64_t n,
+                               int32_t F, float* out, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * BCEWithLogitsLoss(pos_weight), mean reduction (pangnn.py:98,203), loss and dL/dlogits in one pass:
  *   loss[0]     = 1/denom * sum_i (1-y_i) x_i + (1 + (pw-1) y_i) softplus(-x_i)
  *   g_logits[i] = 1/denom * ((1-y_i) - (1 + (pw-1) y_i) sigmoid(-x_i))

@@ -281,6 +281,83 @@ __global__ __launch_bounds__(kSumThreads) void colsum_finish_kernel(const float*
   if (threadIdx.x < kWave && i < 2 * F) out[i] = t;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// First GCN layer of the scalar-feature model by linearity (src/gnn.py:97,125,158: h0 = x w^T + 1 b^T, one scalar per
+// node):  conv_in(embedding(x)) = A_hat (x w^T + 1 b^T) W^T + b_in = r a^T + s c^T + b_in  with the node vectors
+// r = A_hat x, s = A_hat 1 (once per graph) and a = W w, c = W b (per step, H-vectors).  rank2_rows_kernel writes
+// that [N, H] matrix (HBM-write bound); its backward needs only [r s 1]^T g = three weighted column sums of g.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TY>
+__global__ __launch_bounds__(kBlock) void rank2_rows_kernel(const float* __restrict__ r, const float* __restrict__ sv,
+                                                            const float* __restrict__ a, const float* __restrict__ c,
+                                                            const float* __restrict__ bias, TY* __restrict__ out,
+                                                            int64_t ldo, int64_t n, int F) {
+  const int lpr = F / 4;                           // lanes per row (4 adjacent columns each)
+  const int col = 4 * (threadIdx.x % lpr), rg = threadIdx.x / lpr, groups = kBlock / lpr;
+  const float4 av = *reinterpret_cast<const float4*>(a + col), cv = *reinterpret_cast<const float4*>(c + col);
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t row = (int64_t)blockIdx.x * groups + rg; row < n; row += (int64_t)gridDim.x * groups) {
+    const float rv = r[row], sw = sv[row];
+    const float v0 = fmaf(rv, av.x, fmaf(sw, cv.x, bv.x)), v1 = fmaf(rv, av.y, fmaf(sw, cv.y, bv.y));
+    const float v2 = fmaf(rv, av.z, fmaf(sw, cv.z, bv.z)), v3 = fmaf(rv, av.w, fmaf(sw, cv.w, bv.w));
+    if constexpr (sizeof(TY) == 4) {
+      *reinterpret_cast<float4*>(out + row * ldo + col) = make_float4(v0, v1, v2, v3);
+    } else {
+      __bf16 o[4] = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};            // round to nearest even
+      *reinterpret_cast<uint2*>(out + row * ldo + col) = *reinterpret_cast<const uint2*>(o);
+    }
+  }
+}
+
+// out[0] = sum_n r[n] g[n,:], out[1] = sum_n s[n] g[n,:], out[2] = sum_n g[n,:]; g stored as f32 or bf16 (4 adjacent
+// columns per thread).  Two-stage fixed-order sum like weighted_colsum_kernel.
+template <typename TG>
+__global__ __launch_bounds__(kBlock) void weighted_colsum3_kernel(const TG* __restrict__ g, int64_t ldg,
+                                                                  const float* __restrict__ r,
+                                                                  const float* __restrict__ sv, int64_t n, int F,
+                                                                  float* __restrict__ partial) {
+  __shared__ float red[3][kBlock * 4];
+  const int lpr = F / 4;
+  const int c = threadIdx.x % lpr, rg = threadIdx.x / lpr, groups = kBlock / lpr;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t row = (int64_t)blockIdx.x * groups + rg; row < n; row += (int64_t)gridDim.x * groups) {
+    float v[4];
+    if constexpr (sizeof(TG) == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(g + row * ldg + 4 * c);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      const uint2 t = *reinterpret_cast<const uint2*>(g + row * ldg + 4 * c);
+      v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+      v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+    const float rv = r[row], sw = sv[row];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a0[k] = fmaf(rv, v[k], a0[k]); a1[k] = fmaf(sw, v[k], a1[k]); a2[k] += v[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][rg * F + 4 * c + k] = a0[k];
+    red[1][rg * F + 4 * c + k] = a1[k];
+    red[2][rg * F + 4 * c + k] = a2[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < F) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < groups; ++k) {
+      t0 += red[0][k * F + threadIdx.x]; t1 += red[1][k * F + threadIdx.x]; t2 += red[2][k * F + threadIdx.x];
+    }
+    float* p = partial + (int64_t)blockIdx.x * 3 * F;
+    p[threadIdx.x] = t0; p[F + threadIdx.x] = t1; p[2 * F + threadIdx.x] = t2;
+  }
+}
+
+__global__ __launch_bounds__(kSumThreads) void colsum3_finish_kernel(const float* __restrict__ partial, int nblocks,
+                                                                     int F, float* __restrict__ out) {
+  const int i = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const float t = ordered_parts_sum(partial, nblocks, 3 * F, i, 3 * F);
+  if (threadIdx.x < kWave && i < 3 * F) out[i] = t;
+}
+
 static inline unsigned grid_for(int64_t total) {
   int64_t b = (total + kBlock - 1) / kBlock;
   const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
@@ -523,6 +600,65 @@ extern "C" int pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const flo
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((2 * F + kWave - 1) / kWave), dim3(kSumThreads), 0, st,
                      static_cast<const float*>(workspace), blocks, (int)F, out);
   PG_CHECK_LAUNCH("pangnn_weighted_colsum_f32(finish)");
+  return 0;
+}
+
+extern "C" int pangnn_rank2_rows(const float* r, const float* s, const float* a, const float* c, const float* bias,
+                                 void* out, int32_t out_dtype, int64_t ldo, int64_t n, int32_t F, pangnn_stream_t stream) {
+  const char* who = "pangnn_rank2_rows";
+  PG_CHECK_ARG(n >= 0 && F > 0 && F % 4 == 0 && F <= 4 * kBlock && (4 * kBlock) % F == 0 && ldo >= F && ldo % 4 == 0,
+               PANGNN_E_BADARG, "%s: F must be a multiple of 4 dividing 1024, ldo >= F and a multiple of 4 (got %d)", who, (int)F);
+  PG_CHECK_ARG(out_dtype == PANGNN_DTYPE_F32 || out_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
+               "%s: out_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  if (n == 0) return 0;
+  PG_CHECK_ARG(r && s && a && c && out, PANGNN_E_BADARG, "%s: null pointer", who);
+  PG_CHECK_ARG(aligned16(a) && aligned16(c) && (!bias || aligned16(bias)) &&
+                   (out_dtype == PANGNN_DTYPE_F32 ? aligned16(out) : (reinterpret_cast<uintptr_t>(out) & 7u) == 0),
+               PANGNN_E_ALIGN, "%s: a / c / bias / out rows must be 16-byte (bf16 out: 8-byte) aligned", who);
+  const int groups = kBlock / (F / 4);
+  int64_t blocks = (n + groups - 1) / groups;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (out_dtype == PANGNN_DTYPE_F32)
+    hipLaunchKernelGGL(rank2_rows_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r, s, a, c, bias,
+                       static_cast<float*>(out), ldo, n, (int)F);
+  else
+    hipLaunchKernelGGL(rank2_rows_kernel<unsigned short>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r, s, a,
+                       c, bias, static_cast<unsigned short*>(out), ldo, n, (int)F);
+  PG_CHECK_LAUNCH(who);
+  return 0;
+}
+
+extern "C" size_t pangnn_weighted_colsum3_workspace_bytes(int32_t F) {
+  return (size_t)kColsumBlocks * 3 * (size_t)(F > 0 ? F : 1) * sizeof(float);
+}
+
+extern "C" int pangnn_weighted_colsum3(const void* g, int32_t g_dtype, int64_t ldg, const float* r, const float* s,
+                                       int64_t n, int32_t F, float* out, void* workspace, size_t workspace_bytes,
+                                       pangnn_stream_t stream) {
+  const char* who = "pangnn_weighted_colsum3";
+  PG_CHECK_ARG(n >= 0 && F > 0 && F % 4 == 0 && F <= kBlock && (4 * kBlock) % F == 0 && ldg >= F && ldg % 4 == 0,
+               PANGNN_E_BADARG, "%s: F must be a multiple of 4 dividing 1024, at most 256; ldg >= F and a multiple of 4 (got %d)", who, (int)F);
+  PG_CHECK_ARG(g_dtype == PANGNN_DTYPE_F32 || g_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
+               "%s: g_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  PG_CHECK_ARG(out && workspace && workspace_bytes >= pangnn_weighted_colsum3_workspace_bytes(F) && (n == 0 || (g && r && s)),
+               PANGNN_E_BADARG, "%s: null pointer / workspace", who);
+  PG_CHECK_ARG(n == 0 || (g_dtype == PANGNN_DTYPE_F32 ? aligned16(g) : (reinterpret_cast<uintptr_t>(g) & 7u) == 0),
+               PANGNN_E_ALIGN, "%s: g rows must be 16-byte (bf16: 8-byte) aligned", who);
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = kBlock / (F / 4);
+  int blocks = (int)((n + 4 * groups - 1) / (4 * groups));
+  if (blocks > kColsumBlocks) blocks = kColsumBlocks;
+  if (blocks < 1) blocks = 1;
+  if (g_dtype == PANGNN_DTYPE_F32)
+    hipLaunchKernelGGL(weighted_colsum3_kernel<float>, dim3(blocks), dim3(kBlock), 0, st, static_cast<const float*>(g), ldg, r,
+                       s, n, (int)F, static_cast<float*>(workspace));
+  else
+    hipLaunchKernelGGL(weighted_colsum3_kernel<unsigned short>, dim3(blocks), dim3(kBlock), 0, st,
+                       static_cast<const unsigned short*>(g), ldg, r, s, n, (int)F, static_cast<float*>(workspace));
+  PG_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL(colsum3_finish_kernel, dim3((3 * F + kWave - 1) / kWave), dim3(kSumThreads), 0, st,
+                     static_cast<const float*>(workspace), blocks, (int)F, out);
+  PG_CHECK_LAUNCH("pangnn_weighted_colsum3(finish)");
   return 0;
 }
 

@@ -441,6 +441,9 @@ class HipOps:
     def embed_propagate(self, x_tab, w, b, st, norm, tag=None):
         return PF.embed_propagate(x_tab, w, b, st, norm, tag)
 
+    def embed_conv_in(self, x_tab, w, b, w_in, b_in, st, norm):
+        return PF.embed_conv_in(x_tab, w, b, w_in, b_in, st, norm)
+
     def decoder(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3):
         return PF.decoder_mlp(p_full, q_local, st, extra, cvec, w2, b2, w3, b3)
 
@@ -606,13 +609,17 @@ class DistAlternateGCN(AlternateGCN):
         if self.sharded_embedding:
             # rows of the owned nodes are the parameter itself; the exchange of the first layer carries the halo rows
             return self._conv(conv, self.embedding.weight, shard, name, weight, "w", name)
-        if conv.in_channels < conv.out_channels and self.fuse_embedding and hasattr(self.ops, "embed_propagate"):
+        rank2 = self.fuse_embedding and self.fuse_embedding != "propagate" and hasattr(self.ops, "embed_conv_in")
+        if rank2 or (conv.in_channels < conv.out_channels and self.fuse_embedding and hasattr(self.ops, "embed_propagate")):
             cache = shard.__dict__.setdefault("_dist_xtab", {})
             key = (name, self.exchange)
             if key not in cache:
                 with torch.no_grad():
                     cache[key] = self._table(shard.x.float().view(-1, 1), shard, name).view(-1).contiguous()
             st, norm = self._st(shard, name), self._norm(shard, name, weight, "w")
+            if rank2:      # the whole layer by linearity (functional._EmbedConvIn): r = A_hat x, s = A_hat 1 of the OWN rows
+                return self.ops.embed_conv_in(cache[key], self.embedding.weight, self.embedding.bias, conv.lin.weight,
+                                              conv.bias, st, norm)
             agg = self.ops.embed_propagate(cache[key], self.embedding.weight, self.embedding.bias, st, norm, name)
             return self._linear(agg, conv.lin.weight, conv.bias)
         h = shard.x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias

@@ -728,6 +728,24 @@ def bce_with_logits(logits, y, pos_weight=None, denom=None):
     return _BCEWithLogits.apply(logits, y, pos_weight, logits.shape[0] if denom is None else denom)
 
 
+def _node_actions(x_tab, st, norm):
+    """(r, s) = (A_hat x, A_hat 1): the two node vectors through which a scalar-feature embedding acts after one
+    propagate.  Computed once per (graph, normalisation, feature tensor) with the real propagate kernel on a 16-column
+    table and cached on the norm object (like the normalisation itself: static for a static graph)."""
+    xv = x_tab.detach().to(torch.float32).reshape(-1)
+    cache = norm.__dict__.setdefault("_node_actions", {})
+    key = (x_tab.data_ptr(), x_tab._version, tuple(x_tab.shape))
+    if key not in cache:
+        x16 = torch.zeros(xv.shape[0], 16, dtype=torch.float32, device=xv.device)
+        x16[:, 0] = xv
+        x16[:, 1] = 1.0
+        rs = spmm_csr(st.by_dst, norm.by_dst, x16, st.num_nodes)
+        cache.clear()
+        cache[key] = (rs[:, 0].contiguous(), rs[:, 1].contiguous(), x_tab)   # x_tab kept alive: key is its address
+    r, s, _ = cache[key]
+    return r, s
+
+
 class _EmbedPropagate(torch.autograd.Function):
     """agg = A_hat (x w^T + 1 b^T): the scalar-feature embedding (nn.Linear(1, D), gnn.py:97) followed by the
     first GCN layer's propagate (gnn.py:158; GCNConv with in < out propagates before its dense layer).
@@ -735,7 +753,8 @@ class _EmbedPropagate(torch.autograd.Function):
     rows, exchanged once since x never changes — this layer then needs no per-step exchange at all).
     Forward runs the real propagate kernel on h0.  Backward needs only the two parameter gradients, which by
     linearity are (A_hat x)^T g and (A_hat 1)^T g; the transposed propagate is skipped exactly as autograd
-    skips gradients of inputs that require none.  A_hat x and A_hat 1 are cached on the norm object."""
+    skips gradients of inputs that require none.  A_hat x and A_hat 1 are cached on the norm object.
+    (Round 2's form, `fuse_embedding="propagate"`; the default is _EmbedConvIn below.)"""
 
     @staticmethod
     def forward(ctx, x_tab, w, b, st, norm, tag):
@@ -743,16 +762,7 @@ class _EmbedPropagate(torch.autograd.Function):
         xv = x_tab.detach().to(torch.float32).reshape(-1)
         h0 = torch.addcmul(b.detach().reshape(1, -1), xv.unsqueeze(1), w.detach().reshape(1, -1))
         agg = spmm_csr(st.by_dst, norm.by_dst, h0, st.num_nodes, tag=None if tag is None else tag + ".fwd")
-        cache = norm.__dict__.setdefault("_node_actions", {})
-        key = (x_tab.data_ptr(), x_tab._version, tuple(x_tab.shape))
-        if key not in cache:
-            x16 = torch.zeros(xv.shape[0], 16, dtype=torch.float32, device=xv.device)
-            x16[:, 0] = xv
-            x16[:, 1] = 1.0
-            rs = spmm_csr(st.by_dst, norm.by_dst, x16, st.num_nodes)
-            cache.clear()
-            cache[key] = (rs[:, 0].contiguous(), rs[:, 1].contiguous(), x_tab)   # x_tab kept alive: key is its address
-        r, s, _ = cache[key]
+        r, s = _node_actions(x_tab, st, norm)
         ctx.save_for_backward(r, s)
         ctx.d = w.shape[0]
         return agg
@@ -775,3 +785,57 @@ class _EmbedPropagate(torch.autograd.Function):
 
 def embed_propagate(x_tab, w, b, st, norm, tag=None):
     return _EmbedPropagate.apply(x_tab, w, b, st, norm, tag)
+
+
+class _EmbedConvIn(torch.autograd.Function):
+    """conv_in(embedding(x)) for the scalar-feature model (gnn.py:97,125 + GCNConv at :131 / :146 / :158) by linearity:
+
+        A_hat (x w^T + 1 b^T) W^T + b_in  =  r a^T + s c^T + b_in,     r = A_hat x, s = A_hat 1, a = W w, c = W b.
+
+    r and s are node vectors computed once per graph by the propagate kernel (`_node_actions`, cached like gcn_norm);
+    per step the layer is ONE pass that writes the [N, H] rows (pangnn_rank2_rows) — no propagate, no dense product —
+    and its backward ONE pass over dL/dout (pangnn_weighted_colsum3: [r s 1]^T g), from which
+    dL/dW = (r^T g) w^T + (s^T g) b^T, dL/dw = W^T (r^T g), dL/db = W^T (s^T g), dL/db_in = 1^T g.
+    The propagate and the dense layer commute, so this is also GCNConv's linear-then-propagate order (in >= out).
+    Exact algebra (no approximation): the result differs from the layer-by-layer evaluation by fp32 re-association
+    only.  `x_tab` as in _EmbedPropagate (own + halo rows on a shard)."""
+
+    @staticmethod
+    def forward(ctx, x_tab, w, b, w_in, b_in, st, norm, out_dtype):
+        lib = _lib.load()
+        _lib.require_device(x_tab, w, b, w_in, b_in)
+        r, s = _node_actions(x_tab, st, norm)
+        wv, bv, win = w.detach().reshape(-1).float(), b.detach().reshape(-1).float(), w_in.detach().float()
+        ac = (win @ torch.stack([wv, bv], dim=1)).t().contiguous()             # [2, H]: a = W w, c = W b
+        n, h = st.num_nodes, win.shape[0]
+        bias = None if b_in is None else _f32c(b_in.detach())
+        out = torch.empty(n, h, dtype=out_dtype or torch.float32, device=r.device)
+        with torch.cuda.device(r.device):
+            _lib.check(lib.pangnn_rank2_rows(r.data_ptr(), s.data_ptr(), ac[0].data_ptr(), ac[1].data_ptr(), _lib.ptr(bias),
+                                             out.data_ptr(), _dt(out), out.stride(0), n, h, _lib.stream_ptr()),
+                       "pangnn_rank2_rows")
+        ctx.save_for_backward(r, s, wv, bv, win)
+        ctx.has_bias = b_in is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        r, s, wv, bv, win = ctx.saved_tensors
+        g = _rows_any(g)
+        n, h = g.shape
+        sums = torch.empty(3, h, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            ws_bytes = lib.pangnn_weighted_colsum3_workspace_bytes(h)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+            _lib.check(lib.pangnn_weighted_colsum3(g.data_ptr(), _dt(g), g.stride(0), r.data_ptr(), s.data_ptr(), n, h,
+                                                   sums.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
+                       "pangnn_weighted_colsum3")
+        ga_gc = sums[:2]                                                       # dL/da, dL/dc  [2, H]
+        g_emb = ga_gc @ win                                                    # [2, D]: dL/dw, dL/db
+        g_win = ga_gc.t() @ torch.stack([wv, bv], dim=0)                       # [H, D] = dL/da w^T + dL/dc b^T
+        return (None, g_emb[0].reshape(-1, 1), g_emb[1], g_win, sums[2] if ctx.has_bias else None, None, None, None)
+
+
+def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):
+    return _EmbedConvIn.apply(x_tab, w, b, w_in, b_in, st, norm, out_dtype)

@@ -16,10 +16,13 @@ P[src] + Q[dst] (+ w*c) with P = z W_a^T, Q = z W_b^T + b — identical algebra,
 multiply-adds and no [E, 2D] intermediate (pangnn_edge_pair_add_f32).  `fused_decoder=False`
 selects the literal gather-concat-Linear form (pangnn_edge_gather_concat_f32).
 
-First layer: `conv_in(embedding(x))` with the scalar node feature is one operator
-(functional._EmbedPropagate): forward is the ordinary propagate of h0 = x w^T + b; backward produces
-the embedding's gradients as (A_hat x)^T g, (A_hat 1)^T g instead of running the transposed
-propagate (nothing else consumes dL/dh0).  `fuse_embedding=False` keeps the layer-by-layer form.
+First layer: `conv_in(embedding(x))` with the scalar node feature is one operator evaluated by linearity
+(functional._EmbedConvIn): A_hat (x w^T + 1 b^T) W^T + b_in = r a^T + s c^T + b_in with the node vectors
+r = A_hat x, s = A_hat 1 computed once per graph by the propagate kernel and a = W w, c = W b per step — one
+[N, H] write forward, three weighted column sums of dL/dout backward, no per-step propagate or dense product.
+`fuse_embedding="propagate"` = round 2's form (per-step propagate of h0, embedding gradients by linearity),
+`fuse_embedding=False` the layer-by-layer form (what the reference executes); all three are tested against
+each other and the oracle.
 
 Activations: every `h = ELU(layer(...))` of the encoder is consumed by exactly one dense layer, so the ELU runs
 inside that layer's kernels (`functional.linear(..., in_act=1)`); `fold_activation=False` applies it as its own
@@ -97,15 +100,21 @@ class AlternateGCN(nn.Module):
         _lib.require_device(x)
         if self.categorical_nodes:
             return conv(self.embedding(x.long().view(-1)), ei, graph.edge_attr, graph=graph, name=name)
-        if conv.in_channels < conv.out_channels and self.fuse_embedding:
-            # embedding + propagate as one operator whose backward yields the embedding's two parameter
-            # gradients without the transposed propagate (functional._EmbedPropagate)
+        if self.fuse_embedding and (self.fuse_embedding != "propagate" or conv.in_channels < conv.out_channels):
             st = structure_of(ei, x.shape[0], holder=graph, name=name)
             w = graph.edge_attr
             if w is not None and w.shape[0] != st.num_edges:
                 raise ValueError(f"edge_weight has {w.shape[0]} entries for {st.num_edges} edges")
+            out_dtype = torch.bfloat16 if PF.autocast_bf16(x) else None
+            if self.fuse_embedding != "propagate":
+                # the whole layer by linearity: r a^T + s c^T + b_in, r = A_hat x and s = A_hat 1 cached per graph
+                # (functional._EmbedConvIn) — one [N, H] write per step, one pass over its gradient in backward
+                return PF.embed_conv_in(x, self.embedding.weight, self.embedding.bias, conv.lin.weight, conv.bias, st,
+                                        st.gcn_norm(w), out_dtype)
+            # round 2's form: embedding + propagate as one operator whose backward yields the embedding's two parameter
+            # gradients without the transposed propagate (functional._EmbedPropagate), then the dense layer
             agg = PF.embed_propagate(x, self.embedding.weight, self.embedding.bias, st, st.gcn_norm(w), tag=name)
-            return PF.linear(agg, conv.lin.weight, conv.bias, 0, torch.bfloat16 if PF.autocast_bf16(agg) else None)
+            return PF.linear(agg, conv.lin.weight, conv.bias, 0, out_dtype)
         # Linear(1, D) on a [N,1] column is an outer product; as a GEMM its weight gradient is a
         # 64 x 1 x N problem that the BLAS library runs at < 0.1 TB/s
         h = x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias

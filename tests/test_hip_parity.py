@@ -944,33 +944,91 @@ def test_weighted_colsum_kernel(F, n):
                                                   out.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr()), "colsum")
 
 
-@pytest.mark.parametrize("flags", [dict(), dict(base_model=True), dict(union_edge_weights=True)],
-                         ids=["default", "base", "union"])
-def test_fused_embedding_layer_equals_layerwise_form_and_oracle(flags):
-    """non-constant scalar node feature: A_hat x and A_hat 1 differ, both embedding gradients are exercised"""
+@pytest.mark.parametrize("F", [64, 128])
+@pytest.mark.parametrize("n", [0, 1, 5, 1000, 300007])
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_rank2_rows_and_weighted_colsum3_kernels(F, n, bf16):
+    """pangnn_rank2_rows: out = r a^T + s c^T + bias (stored f32 / bf16); pangnn_weighted_colsum3: [r s 1]^T g"""
+    from pangnn_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(F + n)
+    r, s_ = torch.randn(n, generator=gen), torch.rand(n, generator=gen) + 0.5
+    a, c, b = torch.randn(F, generator=gen), torch.randn(F, generator=gen), torch.randn(F, generator=gen)
+    g = torch.randn(n, F, generator=gen)
+    rd, sd, ad, cd, bd = (t.to(dev()) for t in (r, s_, a, c, b))
+    dt = torch.bfloat16 if bf16 else torch.float32
+    out = torch.full((n, F), float("nan"), dtype=dt, device=dev())
+    with torch.cuda.device(dev()):
+        _lib.check(lib.pangnn_rank2_rows(rd.data_ptr(), sd.data_ptr(), ad.data_ptr(), cd.data_ptr(), bd.data_ptr(),
+                                         out.data_ptr(), int(bf16), F, n, F, _lib.stream_ptr()), "rank2_rows")
+    ref = r.double()[:, None] * a.double() + s_.double()[:, None] * c.double() + b.double()
+    assert close(out.float(), ref, atol=(4e-2 if bf16 else 1e-5), rtol=(8e-3 if bf16 else 1e-6))
+    if bf16 and n:      # exactly the f32 result rounded once (round to nearest even)
+        o32 = torch.empty(n, F, device=dev())
+        with torch.cuda.device(dev()):
+            _lib.check(lib.pangnn_rank2_rows(rd.data_ptr(), sd.data_ptr(), ad.data_ptr(), cd.data_ptr(), bd.data_ptr(),
+                                             o32.data_ptr(), 0, F, n, F, _lib.stream_ptr()), "rank2_rows")
+        assert torch.equal(out, o32.to(torch.bfloat16))
+    gd = g.to(dev()).to(dt)
+    sums = torch.full((3, F), float("nan"), device=dev())
+    outs = []
+    for _ in range(2):
+        with torch.cuda.device(dev()):
+            nb = lib.pangnn_weighted_colsum3_workspace_bytes(F)
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev())
+            _lib.check(lib.pangnn_weighted_colsum3(gd.data_ptr(), int(bf16), gd.stride(0), rd.data_ptr(), sd.data_ptr(), n, F,
+                                                   sums.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr()), "colsum3")
+        outs.append(sums.clone())
+    assert torch.equal(outs[0], outs[1])                                   # reproducible
+    g64 = gd.double().cpu()
+    ref3 = torch.stack([(r.double()[:, None] * g64).sum(0), (s_.double()[:, None] * g64).sum(0), g64.sum(0)])
+    scale = float(ref3.abs().max()) + 1e-12
+    assert close(outs[0], ref3, atol=1e-5 * scale + 1e-7, rtol=1e-4)
+    with pytest.raises(_lib.PangnnHipError):
+        _lib.check(lib.pangnn_rank2_rows(rd.data_ptr(), sd.data_ptr(), ad.data_ptr(), cd.data_ptr(), None, out.data_ptr(),
+                                         int(bf16), 48 + 2, max(n, 1), 50, _lib.stream_ptr()), "rank2_rows")
+
+
+@pytest.mark.parametrize("flags,dims", [(dict(), (64, 128)), (dict(base_model=True), (64, 128)),
+                                        (dict(union_edge_weights=True), (64, 128)), (dict(), (64, 64)), (dict(), (128, 64))],
+                         ids=["default", "base", "union", "default-64x64", "default-128x64"])
+def test_fused_embedding_layer_equals_layerwise_form_and_oracle(flags, dims):
+    """conv_in(embedding(x)) in its three forms — by linearity as r a^T + s c^T + b_in (default), round 2's per-step
+    propagate of h0 with the embedding gradients by linearity ("propagate"), layer by layer (False: what the reference
+    executes) — against each other and the oracle.  Non-constant scalar node feature: A_hat x and A_hat 1 differ, both
+    embedding gradients are exercised; dims with D < H (propagate first) and D >= H (dense layer first)."""
     import pangnn_amd
-    g, gd, oracle, model = _pair("cfg2_sim_1000x5", (64, 128), flags, seed=5)
+    g, gd, oracle, model = _pair("cfg2_sim_1000x5", dims, flags, seed=5)
     gen = torch.Generator().manual_seed(9)
     g.x = torch.randn(g.x.shape[0], 1, generator=gen)
     gd.x = g.x.to(dev())
-    plain = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], fuse_embedding=False, **flags)
-    plain.load_state_dict(model.state_dict())
+    assert model.fuse_embedding is True
+    forms = {"rank2": model}
+    for name, mode in (("propagate", "propagate"), ("layerwise", False)):
+        forms[name] = pangnn_amd.AlternateGCN(dev(), None, False, dims=list(dims), fuse_embedding=mode, **flags)
+        forms[name].load_state_dict(model.state_dict())
     pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
-    lr = torch.nn.functional.binary_cross_entropy_with_logits(oracle(g), g.y, pos_weight=pw)
+    ref_logits = oracle(g)
+    lr = torch.nn.functional.binary_cross_entropy_with_logits(ref_logits, g.y, pos_weight=pw)
     lr.backward()
-    grads = []
-    for m in (model, plain):
+    grads = {}
+    for name, m in forms.items():
         gm = copy_graph(g, dev())
         loss, out = m.loss_and_logits(gm, gm.y, pw.to(dev()))
         loss.backward()
-        assert close(loss, lr, atol=1e-5, rtol=1e-5)
-        grads.append({k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+        assert close(out, ref_logits), name                                 # the 1e-4 logit gate, every form
+        assert close(loss, lr, atol=1e-5, rtol=1e-5), name
+        grads[name] = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     po = dict(oracle.named_parameters())
-    for k in ("embedding.weight", "embedding.bias", "conv_in.lin.weight", "conv_in.bias"):
-        scale = float(po[k].grad.abs().max()) + 1e-12
-        assert close(grads[0][k], po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), k
-        assert close(grads[0][k], grads[1][k], atol=1e-3 * scale + 1e-7, rtol=1e-3), k
+    for k, q in po.items():
+        if q.grad is None:
+            continue
+        scale = float(q.grad.abs().max()) + 1e-12
+        for name in forms:
+            assert close(grads[name][k], q.grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), (name, k)
+        assert close(grads["rank2"][k], grads["layerwise"][k], atol=1e-3 * scale + 1e-7, rtol=1e-3), k
     # the cached A_hat x is keyed on the feature tensor: an in-place change must be seen
+    plain = forms["layerwise"]
     gm = copy_graph(g, dev())
     model.zero_grad()
     l1, _ = model.loss_and_logits(gm, gm.y, pw.to(dev())); l1.backward()
@@ -984,6 +1042,9 @@ def test_fused_embedding_layer_equals_layerwise_form_and_oracle(flags):
     scale = float(plain.embedding.weight.grad.abs().max()) + 1e-12
     assert close(model.embedding.weight.grad, plain.embedding.weight.grad, atol=1e-3 * scale + 1e-7, rtol=1e-3)
     assert not torch.equal(g1, model.embedding.weight.grad)
+    # inference form (no autograd) through the same operator
+    with torch.no_grad():
+        assert close(model(copy_graph(g, dev())), ref_logits)
 
 
 # ---------------------------------------------------------------- dense layer with the preceding ELU folded in
