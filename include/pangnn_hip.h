@@ -332,6 +332,19 @@ int    pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const float* r, c
                                   pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Propagate over the positional-neighbour graph of a whole genome set (src/dataset.py:356-361: edges (i, j) for
+ * j in [i - k, i + k] within [0, N), self loops included, unit weights — a band matrix; GCNConv at src/gnn.py:165):
+ *   out[t, :] = bias + sum_{s = t-k .. t+k} dis[s] dis[t] x[s, :]       dis = deg^-1/2 (pangnn_gcn_norm_f32)
+ * The same sums in the same order as pangnn_spmm_csr_f32 over that edge list (bit-identical), without index / weight
+ * arrays.  The band is symmetric: the transposed propagate is the same call.  colsum (optional, [F]): column sums of
+ * x — the bias gradient when x is the upstream gradient (backward of the layer in one pass).  x f32 or bf16 rows.
+ * ---------------------------------------------------------------------------------------- */
+size_t pangnn_band_propagate_workspace_bytes(int32_t F);
+int    pangnn_band_propagate(const void* x, int32_t x_dtype, int64_t ldx, const float* dis, const float* bias, float* out,
+                             int64_t ldo, int64_t n, int32_t F, int32_t k, float* colsum, void* workspace,
+                             size_t workspace_bytes, pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * The first GCN layer of the scalar-feature model as a rank-2 matrix (replaces, for `conv_in(embedding(x))`
  * of src/gnn.py:97,125,156-158 / :143-146 / :128-131, the embedding Linear(1, D), the propagate and GCNConv.lin):
  *   h0 = x w^T + 1 b^T (one scalar x per node)  =>  A_hat (h0) W^T + b_in = r a^T + s c^T + b_in,

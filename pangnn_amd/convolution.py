@@ -142,12 +142,13 @@ class GCNConv(MessagePassing):
         if self.in_channels < self.out_channels:
             # A_hat (x W^T) == (A_hat x) W^T: propagate on the narrower side (half the gather bytes for
             # 64 -> 128), then the dense layer with the bias fused
-            agg = PF.propagate(x.to(torch.bfloat16) if rows_bf16 else x, None, st, norm, tag=name or None)
+            agg = PF.propagate_any(x.to(torch.bfloat16) if rows_bf16 else x, None, st, norm, edge_weight is None,
+                                   tag=name or None)
             # the autocast Linear's output is a bf16 tensor (src/gnn.py:111 under mixed precision): stored as such
             return PF.linear(agg, self.lin.weight, self.bias, 0, torch.bfloat16 if rows_bf16 else None)
         # dense part first: under bf16 autocast its result is WRITTEN as bfloat16 by the linear kernel (no separate cast)
         xw = self.lin(x, 1 if in_elu else 0, torch.bfloat16 if rows_bf16 else None)
-        return PF.propagate(xw, self.bias, st, norm, tag=name or None)
+        return PF.propagate_any(xw, self.bias, st, norm, edge_weight is None, tag=name or None)
 
     def message(self, x_j, edge_weight):            # kept for API parity; forward() is fused
         return edge_weight.view(-1, 1) * x_j

@@ -131,6 +131,13 @@ __device__ __forceinline__ float red4(float s0, float s1, float s2, float s3) {
   return u + w;
 }
 
+// [x.lo16 != 0] | [x.hi16 != 0] << 16 as ONE v_pk_min_u16 (`one2` = 0x00010001 in a register the optimiser cannot see
+// through: against a literal it rewrites the minimum as two compares + selects)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t nz16x2(uint32_t x, uint32_t one2) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, one2)));
+}
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -477,9 +484,12 @@ __device__ __forceinline__ void issue_half_rows(const D16Params& a, const HalfIn
 // PIPE: the W2 terms of step (ks, jb) are read one step ahead of their MFMAs (12 more registers: the inference
 // kernel has them, the training kernel at 256 registers does not and lets its SIMD partner cover the LDS latency;
 // the MFMA order, hence the result, is the same).
-template <bool PIPE>
+// M1: also pack the relu mask of h1 into `m1` — element s = 2 qd + half of K-step ks at bit 16 half + 7 - (4 ks + qd) — from
+// the split's hi terms (the packed top halves of two neighbours: non-zero exactly when the element is a positive
+// normal float), one v_pk_min_u16 + one shift-or per pair.
+template <bool PIPE, bool M1 = false>
 __device__ __forceinline__ float p1_logit(const char* lds, const float (&h)[2][8], int wfrag0, int wfrag1, int g,
-                                          float b3v, f32x4 (&acc)[4]) {
+                                          float b3v, f32x4 (&acc)[4], uint32_t one2 = 0u, uint32_t* m1 = nullptr) {
   const float* b2l = reinterpret_cast<const float*>(lds + LDS_VEC);
   const float* w3l = b2l + 64;
 #pragma unroll
@@ -494,7 +504,14 @@ __device__ __forceinline__ float p1_logit(const char* lds, const float (&h)[2][8
 #pragma unroll
   for (int st = 0; st < 8; ++st) {
     const int ks = st >> 2, jb = st & 3;
-    if (jb == 0) hbk = split8(h[ks]);
+    if (jb == 0) {
+      hbk = split8(h[ks]);
+      if (M1) {
+        const u32x4 hw = __builtin_bit_cast(u32x4, hbk.hi);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) *m1 = (*m1 << 1) | nz16x2(hw[qd], one2);
+      }
+    }
     if (PIPE) {
       if (st < 7) {
         const int off = LDS_W2 + (((st + 1) >> 2) ? wfrag1 : wfrag0) + ((st + 1) & 3) * 2048;
@@ -615,8 +632,8 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   const float pw = (FUSED_LOSS && lp.pos_weight) ? lp.pos_weight[0] : 1.f;
   constexpr bool has_extra = EXTRA;              // skip connections: compile-time, like the other shape switches
   const float* auxp = FUSED_LOSS ? lp.y : g_logits;
-  uint32_t one = 1u;                       // opaque to the optimiser: min(bits, one) stays ONE v_min_u32 (a literal 1 is
-  asm volatile("" : "+v"(one));            // rewritten as compare + select); the statement emits no instruction
+  uint32_t one2 = 0x00010001u;             // opaque to the optimiser: the packed min against it stays ONE v_pk_min_u16 (a
+  asm volatile("" : "+v"(one2));           // literal is rewritten as compares + selects); the statement emits no instruction
 
   const int64_t stride = (int64_t)gridDim.x * S_WAVES;
   int64_t tile = (int64_t)blockIdx.x * S_WAVES + wave;
@@ -645,7 +662,8 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 
       // ---- P1: C[j][e] = b2[j] + sum_k W2[j][k] h1[e][k]
       f32x4 acc[4];
-      const float xv = p1_logit<false>(lds, h, wfrag0, wfrag1, g, b3v, acc);
+      uint32_t m1 = 0;                     // relu mask bits of h1 (packed inside the first product, off its split terms)
+      const float xv = p1_logit<false, true>(lds, h, wfrag0, wfrag1, g, b3v, acc, one2, &m1);
       // the rows of the next half tile fly during the epilogue and the other two products
       issue_half_rows(a, in_nxt, g, rows);
 
@@ -690,11 +708,13 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
             const float h2a = acc[jb][2 * pr], h2b = acc[jb][2 * pr + 1];
             gw3a[jb][2 * pr] = fmaf(g_e, h2a, gw3a[jb][2 * pr]);
             gw3a[jb][2 * pr + 1] = fmaf(g_e, h2b, gw3a[jb][2 * pr + 1]);
-            const uint32_t ta = min(__builtin_bit_cast(uint32_t, h2a), one), tb = min(__builtin_bit_cast(uint32_t, h2b), one);
-            const uint32_t t2 = ta | (tb << 16);                      // the pair as two 0/1 halves
+            // the pair as two 0/1 halves: top halves packed by one v_perm_b32, [!= 0] by one v_pk_min_u16 (h2 >= 0 after
+            // the relu: its top half is non-zero exactly for a positive normal float)
+            const uint32_t t2 = nz16x2(__builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h2b), __builtin_bit_cast(uint32_t, h2a),
+                                                             0x07060302u), one2);
             m2 = (m2 << 1) | t2;
             aw[jb >> 1][2 * (jb & 1) + pr] = __umul24(t2, 0x3f80u);    // bf16 1.0 / 0.0 (v_mul_u32_u24: full rate; the
-                                                                      // optimiser cannot see t2 < 2^17 behind `one`)
+                                                                      // optimiser cannot see t2 < 2^17 behind `one2`)
           }
         a2[0] = __builtin_bit_cast(bf16x8, aw[0]);
         a2[1] = __builtin_bit_cast(bf16x8, aw[1]);
@@ -730,24 +750,13 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
             acc3[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mb], bh, acc3[mb][nb], 0, 0, 0);
         }
       };
-      // relu mask bits of h1: element s = 2 qd + half of K-step ks lands at bit 16 half + 7 - (4 ks + qd)   (h >= 0: bits != 0 <=> h > 0)
-      uint32_t m1 = 0;
-      auto m1_bits = [&](int ks) {
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const uint32_t b0 = __builtin_bit_cast(uint32_t, h[ks][2 * qd]), b1 = __builtin_bit_cast(uint32_t, h[ks][2 * qd + 1]);
-          m1 = (m1 << 1) | min(b0, one) | (min(b1, one) << 16);
-        }
-      };
       write_hg(0);
-      m1_bits(0);
       wave_sync();
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) am[mb] = ld_tr8(wv + WV_M2, tr3h[0] ^ (mb << 6), tr3h[1] ^ (mb << 6));
       D16_SETPRIO(1);
       p3_block(0);
       write_hg(1);
-      m1_bits(1);
       const uint32_t recw = (m1 & 0x00ff00ffu) | ((m2 & 0x00ff00ffu) << 8);
       *reinterpret_cast<uint32_t*>(wv + WV_REC + 16 * c + 4 * g) = recw;
       *reinterpret_cast<float*>(wv + WV_GL + 4 * c) = g_e;               // the four lane groups write the same value

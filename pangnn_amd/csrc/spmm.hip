@@ -235,6 +235,92 @@ static int launch_thin(const int64_t* rowptr, const int32_t* idx, const float* v
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Propagate over the positional-neighbour graph of a whole genome set (src/dataset.py:356-361: edges (i, j) for
+// j in [i - k, i + k] ∩ [0, N), self loop included, unit weights): a BAND matrix — row t gathers rows t - k .. t + k.
+//   out[t] = bias + sum_{s = t-k .. t+k} (dis[s] * dis[t]) x[s]        dis = deg^-1/2 (GcnNorm.deg_inv_sqrt)
+// No index or weight arrays, rows read as a contiguous window: the same sums in the same order as the generic
+// kernel over that edge list (bit-identical), at streaming speed.  The band is symmetric, so the transposed
+// propagate is this kernel too; COLSUM also emits per-workgroup column sums of x (the bias gradient when x is the
+// upstream gradient), finished in fixed order by band_colsum_finish_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int F, typename TX, bool COLSUM>
+__global__ __launch_bounds__(kBlock) void band_propagate_kernel(const TX* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ dis,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                int64_t ldo, int64_t n, int k,
+                                                                float* __restrict__ colsum_partial) {
+  constexpr int G = F / 4;              // lanes per row (4 adjacent columns each)
+  constexpr int RPB = kBlock / G;       // rows per workgroup pass
+  __shared__ float red[COLSUM ? kBlock * 4 : 4];
+  const int fl = threadIdx.x % G, rg = threadIdx.x / G;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) b = reinterpret_cast<const float4*>(bias)[fl];
+  for (int64_t t = (int64_t)blockIdx.x * RPB + rg; t < n; t += (int64_t)gridDim.x * RPB) {
+    const float dt = dis[t];
+    const int64_t lo = t - k < 0 ? 0 : t - k, hi = t + k >= n ? n - 1 : t + k;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t sidx = lo; sidx <= hi; ++sidx) {
+      float4 xv;
+      if constexpr (sizeof(TX) == 4) {
+        xv = *reinterpret_cast<const float4*>(x + sidx * ldx + 4 * fl);
+      } else {
+        const uint2 r = *reinterpret_cast<const uint2*>(x + sidx * ldx + 4 * fl);
+        xv = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                         __uint_as_float(r.y & 0xffff0000u));
+      }
+      const float v = dis[sidx] * dt;                       // gcn_norm: (dis[src] * 1) * dis[dst]
+      acc.x = fmaf(v, xv.x, acc.x);
+      acc.y = fmaf(v, xv.y, acc.y);
+      acc.z = fmaf(v, xv.z, acc.z);
+      acc.w = fmaf(v, xv.w, acc.w);
+      if (COLSUM && sidx == t) { cs.x += xv.x; cs.y += xv.y; cs.z += xv.z; cs.w += xv.w; }
+    }
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    *reinterpret_cast<float4*>(out + t * ldo + 4 * fl) = acc;
+  }
+  if (COLSUM) {
+    red[rg * F + 4 * fl + 0] = cs.x; red[rg * F + 4 * fl + 1] = cs.y;
+    red[rg * F + 4 * fl + 2] = cs.z; red[rg * F + 4 * fl + 3] = cs.w;
+    __syncthreads();
+    if (threadIdx.x < F) {
+      float s = 0.f;
+      for (int q = 0; q < RPB; ++q) s += red[q * F + threadIdx.x];
+      colsum_partial[(int64_t)blockIdx.x * F + threadIdx.x] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kSumThreads) void band_colsum_finish_kernel(const float* __restrict__ partial, int nblocks,
+                                                                         int F, float* __restrict__ out) {
+  const int i = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const float t = ordered_parts_sum(partial, nblocks, F, i, F);
+  if (threadIdx.x < kWave && i < F) out[i] = t;
+}
+
+constexpr int kBandBlocks = 2048;
+
+template <int F>
+static int launch_band(const void* x, int x_bf16, int64_t ldx, const float* dis, const float* bias, float* out, int64_t ldo,
+                       int64_t n, int k, float* colsum, float* ws, hipStream_t s) {
+  constexpr int RPB = kBlock / (F / 4);
+  int64_t blocks = (n + RPB - 1) / RPB;
+  if (blocks > kBandBlocks) blocks = kBandBlocks;
+  const dim3 g((unsigned)blocks), b(kBlock);
+#define PG_BAND(T, CS) hipLaunchKernelGGL((band_propagate_kernel<F, T, CS>), g, b, 0, s, static_cast<const T*>(x), ldx, dis, bias, out, ldo, n, k, ws)
+  if (x_bf16) { if (colsum) PG_BAND(unsigned short, true); else PG_BAND(unsigned short, false); }
+  else { if (colsum) PG_BAND(float, true); else PG_BAND(float, false); }
+#undef PG_BAND
+  PG_CHECK_LAUNCH("pangnn_band_propagate");
+  if (colsum) {
+    hipLaunchKernelGGL(band_colsum_finish_kernel, dim3((F + kWave - 1) / kWave), dim3(kSumThreads), 0, s, ws, (int)blocks, F,
+                       colsum);
+    PG_CHECK_LAUNCH("pangnn_band_propagate(colsum)");
+  }
+  return 0;
+}
+
 }  // namespace pangnn
 
 using namespace pangnn;
@@ -316,4 +402,36 @@ extern "C" int pangnn_spmm_csr_bf16(const int64_t* rowptr, const int32_t* idx, c
   }
   set_error("pangnn_spmm_csr_bf16: F must be 32, 64, 128 or 256 (got %d)", (int)F);
   return PANGNN_E_BADARG;
+}
+
+extern "C" size_t pangnn_band_propagate_workspace_bytes(int32_t F) {
+  return (size_t)kBandBlocks * (size_t)(F > 0 ? F : 1) * sizeof(float);
+}
+
+extern "C" int pangnn_band_propagate(const void* x, int32_t x_dtype, int64_t ldx, const float* dis, const float* bias,
+                                     float* out, int64_t ldo, int64_t n, int32_t F, int32_t k, float* colsum,
+                                     void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
+  const char* who = "pangnn_band_propagate";
+  PG_CHECK_ARG(n >= 0 && k >= 0 && (F == 64 || F == 128), PANGNN_E_BADARG, "%s: F must be 64 or 128, n >= 0, k >= 0 (F=%d k=%d)",
+               who, (int)F, (int)k);
+  PG_CHECK_ARG(x_dtype == PANGNN_DTYPE_F32 || x_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
+               "%s: x_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  PG_CHECK_ARG(!colsum || (workspace && workspace_bytes >= pangnn_band_propagate_workspace_bytes(F)), PANGNN_E_WORKSPACE,
+               "%s: colsum needs the workspace", who);
+  if (n == 0) {
+    if (colsum) {
+      hipError_t e = hipMemsetAsync(colsum, 0, (size_t)F * sizeof(float), (hipStream_t)stream);
+      PG_CHECK_ARG(e == hipSuccess, (int)e, "%s: memset failed", who);
+    }
+    return 0;
+  }
+  PG_CHECK_ARG(x && dis && out && ldx >= F && ldo >= F && ldx % 4 == 0 && ldo % 4 == 0, PANGNN_E_BADARG,
+               "%s: null pointer / leading dimension", who);
+  PG_CHECK_ARG((x_dtype == PANGNN_DTYPE_F32 ? aligned16(x) : (reinterpret_cast<uintptr_t>(x) & 7u) == 0) && aligned16(out) &&
+                   (!bias || aligned16(bias)),
+               PANGNN_E_ALIGN, "%s: rows must start on 16 bytes (bf16 x: 8)", who);
+  hipStream_t s = (hipStream_t)stream;
+  const int xb = x_dtype == PANGNN_DTYPE_BF16;
+  if (F == 64) return launch_band<64>(x, xb, ldx, dis, bias, out, ldo, n, (int)k, colsum, static_cast<float*>(workspace), s);
+  return launch_band<128>(x, xb, ldx, dis, bias, out, ldo, n, (int)k, colsum, static_cast<float*>(workspace), s);
 }

@@ -135,6 +135,60 @@ def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
     return _Propagate.apply(x, bias, st, norm, tag)
 
 
+class _BandPropagate(torch.autograd.Function):
+    """out = A_hat x + bias for the positional-neighbour band graph (EdgeStructure.band_width() = k > 0, unit weights):
+    pangnn_band_propagate — the sums of the generic propagate in the same order, no index arrays.  The band is
+    symmetric, so backward is the same kernel on the upstream gradient, which also emits the bias gradient (its column
+    sums) in the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, bias, dis, k):
+        ctx.k, ctx.has_bias, ctx.x_dtype = int(k), bias is not None, x.dtype
+        ctx.save_for_backward(dis)
+        return _band_call(x, None if bias is None else _f32c(bias), dis, int(k), False)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dis,) = ctx.saved_tensors
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        gx, gb = _band_call(_f32c(g), None, dis, ctx.k, want_b)
+        if not ctx.needs_input_grad[0]:
+            gx = None
+        elif gx.dtype != ctx.x_dtype:
+            gx = gx.to(ctx.x_dtype)
+        return gx, gb, None, None
+
+
+def _band_call(x, bias, dis, k, want_colsum):
+    lib = _lib.load()
+    _lib.require_device(x, bias, dis)
+    x = _rows_any(x)
+    n, f = x.shape
+    out = torch.empty(n, f, dtype=torch.float32, device=x.device)
+    cs = torch.empty(f, dtype=torch.float32, device=x.device) if want_colsum else None
+    with torch.cuda.device(x.device):
+        ws_bytes = lib.pangnn_band_propagate_workspace_bytes(f) if want_colsum else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if want_colsum else None
+        _lib.check(lib.pangnn_band_propagate(x.data_ptr(), _dt(x), x.stride(0), dis.data_ptr(), _lib.ptr(bias), out.data_ptr(),
+                                             out.stride(0), n, f, k, _lib.ptr(cs), _lib.ptr(ws), ws_bytes,
+                                             _lib.stream_ptr()), "pangnn_band_propagate")
+    return out, cs
+
+
+def band_propagate(x, bias, st: EdgeStructure, norm: GcnNorm):
+    """propagate over a band structure (st.band_width() > 0, unit weights, F in {64, 128})"""
+    return _BandPropagate.apply(x, bias, norm.deg_inv_sqrt, st.band_width())
+
+
+def propagate_any(x, bias, st: EdgeStructure, norm: GcnNorm, unit_weights: bool, tag=None):
+    """GCNConv's message passing: the band kernel when the structure is the positional-neighbour band with unit weights
+    (whole-graph mode of the reference), the general CSR kernels otherwise"""
+    if unit_weights and x.dim() == 2 and x.shape[1] in (64, 128) and st.num_src == st.num_nodes and st.band_width() > 0 \
+            and (KERNEL_TIMER is None or tag is None or (tag + ".fwd") not in KERNEL_TIMER):
+        return band_propagate(x, bias, st, norm)
+    return propagate(x, bias, st, norm, tag)
+
+
 class _EdgeGatherConcat(torch.autograd.Function):
     """cat(z[src], z[dst] [, extra]) per edge (gnn.py:173-175).  Backward = two segment sums."""
 

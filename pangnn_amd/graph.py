@@ -74,6 +74,7 @@ class EdgeStructure:
         self._by_src: Optional[CSR] = None
         self._norm: Dict[Tuple, Tuple["GcnNorm", Optional[torch.Tensor]]] = {}
         self._runsum = None
+        self._band: Optional[int] = None
 
     @property
     def by_dst(self) -> CSR:
@@ -90,6 +91,26 @@ class EdgeStructure:
             nmax = max(self.num_nodes, self.num_src)
             self._by_src = build_csr(self.edge_index, nmax, 0, validate=False, num_rows=self.num_src)
         return self._by_src
+
+    def band_width(self) -> int:
+        """k > 0 if this edge list IS the positional-neighbour graph of a whole genome set as the reference builds it
+        (dataset.py:356-361: edges (i, j), j in [i - k, i + k] within [0, N), self loops included, in nested-loop order) —
+        a band matrix, propagated without index arrays (pangnn_band_propagate); 0 for any other list.  Decided once per
+        structure by comparing with the generated pattern (one host sync)."""
+        if self._band is None:
+            self._band = 0
+            n, e = self.num_nodes, self.num_edges
+            if self.num_src == n and n > 0 and e > 0:
+                for k in range(1, 9):
+                    if k < n and e == n * (2 * k + 1) - k * (k + 1):
+                        dev = self.edge_index.device
+                        i = torch.arange(n, dtype=torch.int64, device=dev).repeat_interleave(2 * k + 1)
+                        j = i + torch.arange(-k, k + 1, dtype=torch.int64, device=dev).repeat(n)
+                        keep = (j >= 0) & (j < n)
+                        if torch.equal(self.edge_index, torch.stack([i[keep], j[keep]])):
+                            self._band = k
+                        break
+        return self._band
 
     @staticmethod
     def _plan_of_sorted_keys(keys: torch.Tensor, n_rows: int):

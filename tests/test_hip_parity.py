@@ -146,6 +146,64 @@ def test_gcnconv_module_matches_oracle_and_dense(weighted):
     assert close(out, go.gcn_conv_dense(x.double(), ei, w.double() if weighted else None, W.double(), b.double()))
 
 
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("F", [64, 128])
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 100003])
+def test_band_propagate_is_the_generic_propagate_bit_for_bit(k, F, n):
+    """the positional-neighbour graph of a whole genome set (dataset.py:356-361) is a band matrix: pangnn_band_propagate
+    must give the generic CSR kernels' sums in the same order — forward, transposed (backward) and bias gradient —
+    for f32 and bf16-stored rows"""
+    from pangnn_amd import construct, functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    if k >= n:
+        pytest.skip("band wider than the graph")
+    ei = construct.neighbour_edges(n, k, device=dev())
+    st = EdgeStructure(ei, n)
+    assert st.band_width() == k
+    norm = st.gcn_norm(None)
+    torch.manual_seed(n + k + F)
+    for dt in (torch.float32, torch.bfloat16):
+        x0 = torch.randn(n, F, device=dev()).to(dt)
+        b0 = torch.randn(F, device=dev())
+        go_ = torch.randn(n, F, device=dev())
+        res = []
+        for fn in (PF.band_propagate, PF.propagate):
+            x, b = x0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            y = fn(x, b, st, norm)
+            y.backward(go_)
+            res.append((y.detach(), x.grad, b.grad))
+        assert res[0][0].dtype == torch.float32 and res[0][1].dtype == dt
+        if dt == torch.float32:          # same sums, same order as the generic thin-row kernel
+            assert torch.equal(res[0][0], res[1][0]), ("forward", float((res[0][0] - res[1][0]).abs().max()))
+            assert torch.equal(res[0][1], res[1][1]), ("backward", float((res[0][1] - res[1][1]).abs().max()))
+        else:                            # the generic bf16-row kernel is the wave-per-row one (another association order)
+            assert close(res[0][0], res[1][0], atol=1e-5, rtol=1e-5) and close(res[0][1].float(), res[1][1].float(), atol=2e-2, rtol=2e-2)
+        # the generic path sums the bias gradient with torch (another association order)
+        assert close(res[0][2], res[1][2], atol=1e-5 * (float(res[1][2].abs().max()) + 1e-12) + 1e-6, rtol=1e-5)
+    ref = go.propagate_add(x0.float().cpu(), ei.cpu(), go.gcn_norm(ei.cpu(), None, n)) + b0.cpu()
+    assert close(res[0][0], ref)
+
+
+def test_band_detection_only_accepts_the_reference_pattern():
+    from pangnn_amd import construct
+    from pangnn_amd.graph import EdgeStructure
+    n = 50
+    ei = construct.neighbour_edges(n, 1, device=dev())
+    assert EdgeStructure(ei, n).band_width() == 1
+    assert EdgeStructure(construct.neighbour_edges(n, 3, device=dev()), n).band_width() == 3
+    perm = torch.randperm(ei.shape[1], device=dev())
+    assert EdgeStructure(ei[:, perm].contiguous(), n).band_width() == 0          # same edges, another order
+    other = ei.clone(); other[0, 5] = (other[0, 5] + 7) % n
+    assert EdgeStructure(other, n).band_width() == 0                              # same count, another edge
+    assert EdgeStructure(ei[:, :-1].contiguous(), n).band_width() == 0
+    # a sub-graph's neighbour graph (helper.py:366-417: no self loops, local ids) is not a band
+    sg = sub_graphs_from_golden("cfg1_2genomes", 3)[0]
+    assert EdgeStructure(sg.neighbour_edge_index.to(dev()), sg.x.shape[0]).band_width() == 0
+    # the whole-graph fixture the reference built IS one
+    g = whole_graph_from_golden("cfg1_2genomes")
+    assert EdgeStructure(g.neighbour_edge_index.to(dev()), g.x.shape[0]).band_width() == 1
+
+
 # ---------------------------------------------------------------- whole model on the golden graphs
 def _pair(name_or_graph, dims, flags, seed=0, categorical=False):
     import pangnn_amd
