@@ -411,9 +411,11 @@ def main():
         step_s = dt / args.steps
         # run-part rows written by the decoder's S (by source) and T (by target) kernels on this graph
         st_sim = getattr(graph, "_pangnn_structs", {}).get("sim", (None, None))[1]
-        n_parts_s = getattr(getattr(st_sim, "_runsum", None), "n_parts", 0) if st_sim is not None else 0
-        pl = getattr(st_sim, "_csr_plans", {}).get("dst") if st_sim is not None else None
-        n_parts_d = pl.n_parts if pl is not None else 0
+        ct = PF.d16_chunk()
+        pl_s = st_sim.runsum_plan(ct) if st_sim is not None else None
+        pl_d = st_sim.csr_plan("dst", ct) if st_sim is not None else None
+        n_parts_s = pl_s.n_parts if pl_s is not None else 0
+        n_parts_d = pl_d.n_parts if pl_d is not None else 0
         line = {
             "metric": "edges/sec in GNN forward+backward (link-pred train step)",
             "value": e_sim * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
@@ -451,7 +453,7 @@ def main():
             line["step_hbm_frac"] = tot / step_s / HBM_PEAK
             line["step_alg_bytes_terms"] = terms
             line["step_alg_bytes_note"] = ("sum over the step's kernel launches of their algorithmic bytes (every gathered row "
-                                           "counted once per edge, no cache credit; run-part rows: S " + str(n_parts_s) + ", T " +
+                                           "counted once per edge, no cache credit; run-part rows (one per (16-tile chunk, key) run): S " + str(n_parts_s) + ", T " +
                                            str(n_parts_d) + "); step_hbm_frac = step_alg_bytes / ms_per_step / 8 TB/s")
         if t_dec:
             # Dominant kernel of the step: decoder_train16_kernel (csrc/decoder16.hip; S in DESIGN.md §4).

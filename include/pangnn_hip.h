@@ -219,7 +219,11 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  *   what lets two waves share a SIMD without spilling),
  *   rec[E][8] uint32 (required): per edge {4 dwords of relu masks, dL/dlogit_e, 3 unused} for the dgrad pass,
  *   part_buf / part_off (both NULL or both set; edge list sorted by source): sums of dL/dh1 over every
- *   (32-edge tile, source) run, as in pangnn_decoder_mlp_bwd_f32.
+ *   (chunk, source) run, where a chunk is pangnn_decoder_chunk_tiles() (= 16) consecutive 32-edge tiles walked by
+ *   one wave with the open run carried from tile to tile: part_off[c] = index of chunk c's first part row, a new
+ *   part starts at every chunk start and at every change of the key (pangnn_decoder_mlp_bwd_f32 uses the same layout
+ *   with one-tile chunks).  Chunks are a property of the edge list, not of the launch: results do not depend on the
+ *   grid.
  *   Arithmetic: every product on the bf16 matrix pipe with fp32 accumulation and fp32-exact operand handling —
  *   W2 h1 with both operands split into three bf16 terms (6 partial products); dL/dh1 = m1 g_e (m2^T W2') and
  *   dL/dW2 = diag(w3) m2 (g_e h1) with the relu mask m2 as the EXACT bf16 operand and the other operand split
@@ -235,6 +239,7 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  *   alone.  workspace (with g_cvec or g_b2): pangnn_decoder_dgrad_workspace_bytes().
  * Both are reproducible (fixed-order sums, no float atomics).
  * ---------------------------------------------------------------------------------------- */
+int    pangnn_decoder_chunk_tiles(void);
 size_t pangnn_decoder_train_workspace_bytes(void);
 int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                              const int64_t* edge_index, int64_t ld, int64_t num_edges, const float* extra,

@@ -40,6 +40,19 @@ constexpr int S_WAVES = 4;
 #else
 constexpr int S_WAVES = 8;                            // 512 threads, one workgroup per CU, two waves per SIMD
 #endif
+// Run sums are taken per CHUNK of 2^D16_CHUNK_LOG consecutive 32-edge tiles: a wave walks the tiles of a chunk in order and
+// carries an open run from tile to tile, so a run only ends where its key changes or the chunk ends — one part row per
+// (chunk, key) run (N + E / 512 rows instead of one per (tile, key) run, N + E / 32), and most half tiles have no
+// boundary to handle at all.  Chunk boundaries depend on the edge list alone, never on the grid: results stay
+// independent of the number of workgroups.
+constexpr int D16_CHUNK_LOG = 4;
+constexpr int D16_CHUNK = 1 << D16_CHUNK_LOG;
+// the wave's next tile: the next one of its chunk, or the first of the chunk `cstride` chunks on
+__device__ __forceinline__ int64_t next_tile(int64_t tile, int64_t cstride, int64_t n_tiles, bool& last) {
+  const int64_t t1 = tile + 1;
+  last = (t1 & (D16_CHUNK - 1)) == 0 || t1 >= n_tiles;
+  return last ? ((tile >> D16_CHUNK_LOG) + cstride) << D16_CHUNK_LOG : t1;
+}
 constexpr int T_WAVES = 16;                           // dgrad kernel: four waves per SIMD (128 registers each): its record gathers are latency bound
 
 // ---- LDS images.  Rows of 64 bf16 = 128 B = 8 chunks of 16 B, unpadded; chunk ch of row r sits at
@@ -450,7 +463,8 @@ __device__ __forceinline__ HalfIn load_half(const D16Params& a, const float* aux
   const int64_t e_tile = tc * 32;
   const int64_t rest = a.E - 1 - e_tile;
   const int lim = (int)(rest < 31 ? rest : 31);            // uniform: last valid position inside the tile
-  const int k = min(16 * hx + c, lim), kn = min(k + 1, lim);
+  const int k = min(16 * hx + c, lim);
+  const int kn = (int)min((int64_t)k + 1, rest);           // the edge after k: position 32 = first edge of the next tile
   const int64_t* ei = a.ei + e_tile;
   const int64_t s = ei[k], d = ei[a.ld + k];
   h.key = (int)s;
@@ -635,24 +649,33 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   uint32_t one2 = 0x00010001u;             // opaque to the optimiser: the packed min against it stays ONE v_pk_min_u16 (a
   asm volatile("" : "+v"(one2));           // literal is rewritten as compares + selects); the statement emits no instruction
 
-  const int64_t stride = (int64_t)gridDim.x * S_WAVES;
-  int64_t tile = (int64_t)blockIdx.x * S_WAVES + wave;
+  const int64_t cstride = (int64_t)gridDim.x * S_WAVES;                // in chunks of D16_CHUNK tiles
+  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) >> D16_CHUNK_LOG;
+  int64_t tile = ((int64_t)blockIdx.x * S_WAVES + wave) << D16_CHUNK_LOG;
   HalfIn in_cur = load_half<EXTRA>(a, auxp, tile, n_tiles, 0, c);
   HalfRowsT<PQ16> rows;
   issue_half_rows(a, in_cur, g, rows);
-  int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile] : 0;
+  int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile >> D16_CHUNK_LOG] : 0;
+  float carry = 0.f;
+  int64_t pidx = 0;
 
-  for (; tile < n_tiles; tile += stride) {
-    float carry = 0.f;
-    int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
-    const int poff_nxt = (RUNSUM && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
+  while (tile < n_tiles) {
+    // chunk bookkeeping as selects (no branch in the loop body): a chunk's first tile starts from its part offset with
+    // no open run; the offset of the wave's next chunk is fetched every tile (one cached dword) and taken over at the end
+    const bool first_of_chunk = (tile & (D16_CHUNK - 1)) == 0;
+    carry = first_of_chunk ? 0.f : carry;
+    pidx = first_of_chunk ? (int64_t)__builtin_amdgcn_readfirstlane(poff_cur) : pidx;
+    bool last_tile;
+    const int64_t tile_nxt = next_tile(tile, cstride, n_tiles, last_tile);
+    const int64_t chunk_nxt = (tile >> D16_CHUNK_LOG) + cstride;
+    const int poff_nxt = RUNSUM ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
     const int live_lim = (int)min((int64_t)31, a.E - 1 - tile * 32);   // uniform: positions <= live_lim are real edges
     uint32_t* rec_tile = rec + tile * 256;                             // 8 dwords per edge (rec is required)
     float* logit_tile = logits + tile * 32;                            // (required with the fused loss, optional otherwise)
 #pragma unroll 1
     for (int hx = 0; hx < 2; ++hx) {
       // ids of the next half tile (this tile's second half, or the first half of the wave's next tile)
-      const HalfIn in_nxt = load_half<EXTRA>(a, auxp, hx == 0 ? tile : tile + stride, n_tiles, hx ^ 1, c);    // one load site
+      const HalfIn in_nxt = load_half<EXTRA>(a, auxp, hx == 0 ? tile : tile_nxt, n_tiles, hx ^ 1, c);    // one load site
       const int pos = 16 * hx + c;
       const bool live = pos <= live_lim;
 
@@ -796,7 +819,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
             }
         }
         if (RUNSUM) {
-          const bool closes = in_cur.key != in_cur.key_nxt || pos == 31;
+          const bool closes = in_cur.key != in_cur.key_nxt || (pos == 31 && last_tile);     // key change, or end of the chunk
           const unsigned long long bal = __ballot(closes);
           const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
           run_sums(v, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
@@ -805,7 +828,8 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       wave_sync();          // the next half tile overwrites the images / recl / gl
       in_cur = in_nxt;
     }
-    poff_cur = poff_nxt;
+    poff_cur = last_tile ? poff_nxt : poff_cur;
+    tile = tile_nxt;
   }
 
   // ---- finish: per-lane partials -> per-wave rows -> workgroup slab (fixed order)
@@ -884,7 +908,8 @@ __device__ __forceinline__ TIds load_ids(const int32_t* perm, const int32_t* key
   const int64_t p_tile = tc * 32;
   const int64_t rest = E - 1 - p_tile;
   const int lim = (int)(rest < 31 ? rest : 31);
-  const int k = min(16 * hx + c, lim), kn = min(k + 1, lim);
+  const int k = min(16 * hx + c, lim);
+  const int kn = (int)min((int64_t)k + 1, rest);           // position 32 = first position of the next tile
   const int32_t* kt = keys + p_tile;
   t.key = kt[k];
   t.key_nxt = kt[kn];
@@ -931,27 +956,37 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) gb2a[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int64_t stride = (int64_t)gridDim.x * T_WAVES;
-  int64_t tile = (int64_t)blockIdx.x * T_WAVES + wave;
+  const int64_t cstride = (int64_t)gridDim.x * T_WAVES;                // in chunks of D16_CHUNK tiles
+  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) >> D16_CHUNK_LOG;
+  int64_t tile = ((int64_t)blockIdx.x * T_WAVES + wave) << D16_CHUNK_LOG;
   // pipeline over the wave's tiles: records of tile n + 1 and ids of tile n + 2 in flight under tile n
   TIn cur[2];
   TIds ids_nxt[2];
+  bool last1;
+  int64_t tile1 = next_tile(tile, cstride, n_tiles, last1);            // the wave's next tile
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     cur[h] = load_rec<EXTRA>(rec, extra, load_ids<PERM>(perm, keys, E, tile, n_tiles, h, c), g);
-    ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile + stride, n_tiles, h, c);
+    ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile1, n_tiles, h, c);
   }
-  int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile] : 0;
-  for (; tile < n_tiles; tile += stride) {
-    float carry = 0.f;
-    int64_t pidx = __builtin_amdgcn_readfirstlane(poff_cur);
-    const int poff_nxt = (run && tile + stride < n_tiles) ? rs.part_off[tile + stride] : 0;
+  int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile >> D16_CHUNK_LOG] : 0;
+  float carry = 0.f;
+  int64_t pidx = 0;
+  while (tile < n_tiles) {
+    const bool first_of_chunk = (tile & (D16_CHUNK - 1)) == 0;
+    carry = first_of_chunk ? 0.f : carry;
+    pidx = first_of_chunk ? (int64_t)__builtin_amdgcn_readfirstlane(poff_cur) : pidx;
+    const bool last_tile = last1;                                      // this tile ends its chunk
+    const int64_t chunk_nxt = (tile >> D16_CHUNK_LOG) + cstride;
+    const int poff_nxt = run ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
     const int live_lim = (int)min((int64_t)31, E - 1 - tile * 32);
+    bool last2;
+    const int64_t tile2 = next_tile(tile1 < n_tiles ? tile1 : n_tiles - 1, cstride, n_tiles, last2);
     TIn nxt[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       nxt[h] = load_rec<EXTRA>(rec, extra, ids_nxt[h], g);
-      ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile + 2 * stride, n_tiles, h, c);
+      ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile2, n_tiles, h, c);
     }
     bf16x8 a2[2][2];
 #pragma unroll
@@ -992,7 +1027,7 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], v[h][kb][i], gcv[kb]);
         }
-        const bool closes = cur[h].key != cur[h].key_nxt || (h == 1 && c == 15);
+        const bool closes = cur[h].key != cur[h].key_nxt || (h == 1 && c == 15 && last_tile);   // key change, or end of the chunk
         const unsigned long long bal = __ballot(closes);
         const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
         run_sums(v[h], m16, carry, rs.part, pidx, wv, lane, c, g, colp);
@@ -1001,7 +1036,10 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     wave_sync();          // the next tile overwrites recl / gl / wl
 #pragma unroll
     for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
-    poff_cur = poff_nxt;
+    poff_cur = last_tile ? poff_nxt : poff_cur;
+    tile = tile1;
+    tile1 = tile2;
+    last1 = last2;
   }
   if (gcv_slabs != nullptr || gb2_slabs != nullptr) {
     // parameter-gradient partials of the workgroup in fixed wave order: [gcvec 64 | gb2 64]
@@ -1158,6 +1196,8 @@ extern "C" int pangnn_debug_set_v(float* ptr) {
 }
 #endif
 
+extern "C" int pangnn_decoder_chunk_tiles(void) { return D16_CHUNK; }
+
 extern "C" size_t pangnn_decoder_train_workspace_bytes(void) { return (size_t)cu_count() * SLAB16 * sizeof(float); }
 
 extern "C" int pangnn_decoder_mlp_infer_mixed(const void* p, int64_t ldp, const void* q, int64_t ldq, int32_t pq_dtype,
@@ -1207,7 +1247,8 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
                who);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (num_edges + 31) / 32;
-  int64_t grid = (n_tiles + S_WAVES - 1) / S_WAVES;
+  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) / D16_CHUNK;     // a wave takes whole chunks of tiles
+  int64_t grid = (n_chunks + S_WAVES - 1) / S_WAVES;
   const int cus = cu_count();
   if (grid > cus) grid = cus;
   if (grid < 1) grid = 1;
@@ -1289,7 +1330,8 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
   PG_CHECK_ARG(part_buf || g_b2 || g_cvec, PANGNN_E_BADARG, "%s: nothing to compute", who);
   PG_CHECK_ARG(!g_cvec || (extra && part_buf), PANGNN_E_BADARG, "%s: g_cvec needs extra and the run-sum pass", who);
   const int64_t n_tiles = (num_edges + 31) / 32;
-  int64_t grid = (n_tiles + T_WAVES - 1) / T_WAVES;
+  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) / D16_CHUNK;
+  int64_t grid = (n_chunks + T_WAVES - 1) / T_WAVES;
   const int cus = cu_count();
   if (grid > cus) grid = cus;
   PG_CHECK_ARG(!(g_cvec || g_b2) || (workspace && workspace_bytes >= (size_t)grid * 128 * sizeof(float)),

@@ -325,6 +325,17 @@ def segment_sum(msg, st: EdgeStructure):
     return _SegmentSum.apply(msg, st)
 
 
+_D16_CHUNK = None
+
+
+def d16_chunk() -> int:
+    """tiles per run-sum chunk of the S / T kernels (pangnn_decoder_chunk_tiles)"""
+    global _D16_CHUNK
+    if _D16_CHUNK is None:
+        _D16_CHUNK = int(_lib.load().pangnn_decoder_chunk_tiles())
+    return _D16_CHUNK
+
+
 def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor) -> torch.Tensor:
     """out[s] = sum of the consecutive part rows of source s (pangnn_spmm_csr_f32, idx = NULL)"""
     lib = _lib.load()
@@ -342,7 +353,7 @@ def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 
     (one call per step asks for it); by = None: the parameter sums alone."""
     lib = _lib.load()
     dev = rec.device
-    plan = st.csr_plan(by) if by else None
+    plan = st.csr_plan(by, d16_chunk()) if by else None
     csr = None if not by else (st.by_dst if by == "dst" else st.by_src)
     parts = None if plan is None else torch.empty(plan.n_parts, 64, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -379,7 +390,7 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
     g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
     g_cv = None if cv is None else torch.empty_like(cv)
     rec = torch.empty(max(e, 1), 8, dtype=torch.int32, device=dev)
-    plan = st.runsum_plan() if (need_p and e > 0) else None
+    plan = st.runsum_plan(d16_chunk()) if (need_p and e > 0) else None
     parts = None if plan is None else torch.empty(plan.n_parts, d, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         ws_bytes = lib.pangnn_decoder_train_workspace_bytes()

@@ -113,44 +113,51 @@ class EdgeStructure:
         return self._band
 
     @staticmethod
-    def _plan_of_sorted_keys(keys: torch.Tensor, n_rows: int):
-        """Layout of the per-(32-edge tile, key) partial rows for an edge order whose `keys` are non-decreasing:
-          part_off[t]    index of tile t's first part
+    def _plan_of_sorted_keys(keys: torch.Tensor, n_rows: int, chunk_tiles: int = 1):
+        """Layout of the per-(chunk, key) partial rows for an edge order whose `keys` are non-decreasing; a chunk is
+        `chunk_tiles` consecutive 32-edge tiles (1: the strict-fp32 kernels of decoder.hip; pangnn_decoder_chunk_tiles()
+        = 16: the S / T kernels of decoder16.hip, whose waves carry an open run from tile to tile inside a chunk):
+          part_off[c]    index of chunk c's first part
           part_rowptr[r] parts of row r are [part_rowptr[r], part_rowptr[r+1])   (consecutive: sorted)
           keys           int32 copy handed to the kernel"""
         from types import SimpleNamespace
         e = keys.shape[0]
-        flags = (torch.arange(e, device=keys.device) % 32) == 0
+        span = 32 * int(chunk_tiles)
+        flags = (torch.arange(e, device=keys.device) % span) == 0
         flags[1:] |= keys[1:] != keys[:-1]
         part_id = torch.cumsum(flags, 0) - 1
         n_parts = int(part_id[-1]) + 1
         part_rowptr = torch.searchsorted(keys[flags].contiguous(), torch.arange(n_rows + 1, device=keys.device))
-        return SimpleNamespace(n_parts=n_parts, part_off=part_id[::32].to(torch.int32).contiguous(),
-                               part_rowptr=part_rowptr.contiguous(), keys=keys.to(torch.int32).contiguous())
+        return SimpleNamespace(n_parts=n_parts, part_off=part_id[::span].to(torch.int32).contiguous(),
+                               part_rowptr=part_rowptr.contiguous(), keys=keys.to(torch.int32).contiguous(),
+                               chunk_tiles=int(chunk_tiles))
 
-    def csr_plan(self, by: str):
+    def csr_plan(self, by: str, chunk_tiles: int = 1):
         """run-sum plan of the CSR order `by` in {"dst", "src"} (pangnn_decoder_dgrad_f32: perm = that CSR's perm)"""
         cache = self.__dict__.setdefault("_csr_plans", {})
-        if by not in cache:
+        key = (by, int(chunk_tiles))
+        if key not in cache:
             csr = self.by_dst if by == "dst" else self.by_src
             n_rows = self.num_nodes if by == "dst" else self.num_src
             keys = self.edge_index[1 if by == "dst" else 0][csr.perm.long()] if self.num_edges else \
                 self.edge_index.new_empty(0)
-            cache[by] = self._plan_of_sorted_keys(keys, n_rows) if self.num_edges else None
-        return cache[by]
+            cache[key] = self._plan_of_sorted_keys(keys, n_rows, chunk_tiles) if self.num_edges else None
+        return cache[key]
 
-    def runsum_plan(self):
-        """If the caller's edge order is sorted by source: the layout of the per-(32-edge tile, source) partial
-        rows the decoder backward kernel can emit (include/pangnn_hip.h, `part_buf` / `part_off`), else None.
-          part_off[t]    index of tile t's first part
+    def runsum_plan(self, chunk_tiles: int = 1):
+        """If the caller's edge order is sorted by source: the layout of the per-(chunk, source) partial rows the decoder
+        training kernels can emit (include/pangnn_hip.h, `part_buf` / `part_off`), else None.
+          part_off[c]    index of chunk c's first part
           part_rowptr[s] parts of source s are [part_rowptr[s], part_rowptr[s+1])   (consecutive: sorted)"""
         if self._runsum is None:
             src, e = self.edge_index[0], self.num_edges
-            if e == 0 or not bool((src[1:] >= src[:-1]).all()):
-                self._runsum = False
-            else:
-                self._runsum = self._plan_of_sorted_keys(src, self.num_src)
-        return self._runsum or None
+            self._runsum = {} if (e > 0 and bool((src[1:] >= src[:-1]).all())) else False
+        if self._runsum is False:
+            return None
+        ct = int(chunk_tiles)
+        if ct not in self._runsum:
+            self._runsum[ct] = self._plan_of_sorted_keys(self.edge_index[0], self.num_src, ct)
+        return self._runsum[ct]
 
     def gcn_norm(self, edge_weight: Optional[torch.Tensor], gather_dis=None) -> "GcnNorm":
         """norm for this edge_weight tensor (None = unit weights); cached on tensor identity.

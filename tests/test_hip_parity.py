@@ -795,7 +795,7 @@ def test_full_size_S_and_T_kernels_agree_on_by_source_sums(skip):
     # kernel gathers through it all the same) — and once more through S for run-to-run reproducibility
     rec = torch.empty(e, 8, dtype=torch.int32, device=dev())
     lib = PF._lib.load()
-    plan = st.runsum_plan()
+    plan = st.runsum_plan(PF.d16_chunk())
     parts = torch.empty(plan.n_parts, 64, device=dev())
     outs = [torch.empty_like(W2), torch.empty_like(w3), torch.empty_like(b3)]
     ws = torch.empty(lib.pangnn_decoder_train_workspace_bytes(), dtype=torch.uint8, device=dev())
