@@ -871,7 +871,9 @@ class _EmbedConvIn(torch.autograd.Function):
         _lib.require_device(x_tab, w, b, w_in, b_in)
         r, s = _node_actions(x_tab, st, norm)
         wv, bv, win = w.detach().reshape(-1).float(), b.detach().reshape(-1).float(), w_in.detach().float()
-        ac = (win @ torch.stack([wv, bv], dim=1)).t().contiguous()             # [2, H]: a = W w, c = W b
+        with torch.autocast("cuda", enabled=False):      # H x D x 2 parameter algebra stays fp32 (the kernel reads floats)
+            ac = (win @ torch.stack([wv, bv], dim=1)).t().contiguous()         # [2, H]: a = W w, c = W b
+        assert ac.dtype == torch.float32
         n, h = st.num_nodes, win.shape[0]
         bias = None if b_in is None else _f32c(b_in.detach())
         out = torch.empty(n, h, dtype=out_dtype or torch.float32, device=r.device)
@@ -897,8 +899,9 @@ class _EmbedConvIn(torch.autograd.Function):
                                                    sums.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
                        "pangnn_weighted_colsum3")
         ga_gc = sums[:2]                                                       # dL/da, dL/dc  [2, H]
-        g_emb = ga_gc @ win                                                    # [2, D]: dL/dw, dL/db
-        g_win = ga_gc.t() @ torch.stack([wv, bv], dim=0)                       # [H, D] = dL/da w^T + dL/dc b^T
+        with torch.autocast("cuda", enabled=False):      # backward may run inside the caller's autocast region
+            g_emb = ga_gc @ win                                                # [2, D]: dL/dw, dL/db
+            g_win = ga_gc.t() @ torch.stack([wv, bv], dim=0)                   # [H, D] = dL/da w^T + dL/dc b^T
         return (None, g_emb[0].reshape(-1, 1), g_emb[1], g_win, sums[2] if ctx.has_bias else None, None, None, None)
 
 

@@ -1435,16 +1435,27 @@ def test_model_under_bf16_autocast_stores_linear_outputs_as_bf16():
         y = orig(ctx, x, w, bias, in_act, out_dtype)
         seen.append((x.dtype, tuple(w.shape), y.dtype))
         return y
+    orig_first = PF._EmbedConvIn.forward
+    first = []
+
+    def spy_first(ctx, *a):
+        y = orig_first(ctx, *a)
+        first.append(y.dtype)
+        return y
     PF._Linear.forward = staticmethod(spy)
+    PF._EmbedConvIn.forward = staticmethod(spy_first)
     try:
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss, logits = model.loss_and_logits(gd, gd.y, None)
             loss.backward()
     finally:
         PF._Linear.forward = staticmethod(orig)
+        PF._EmbedConvIn.forward = staticmethod(orig_first)
     bf, f32 = torch.bfloat16, torch.float32
-    # conv_in's dense part (agg f32 -> hidden pre-activation bf16), conv_out's (bf16 in -> bf16 rows), P|Q (f32 z -> bf16)
-    assert (f32, (128, 64), bf) in seen and (bf, (64, 128), bf) in seen and (f32, (128, 64), bf) in seen
+    # conv_in(embedding(x)) (the rank-2 operator writes the hidden pre-activation as bf16), conv_out's dense part (bf16 in
+    # -> bf16 rows), P|Q (f32 z -> bf16)
+    assert first == [bf]
+    assert (bf, (64, 128), bf) in seen and (f32, (128, 64), bf) in seen
     assert logits.dtype == f32 and all(p.grad is None or p.grad.dtype == f32 for p in model.parameters())
     with torch.autocast("cpu", dtype=torch.bfloat16):
         ref = oracle(g).float()
