@@ -230,13 +230,16 @@ __device__ __forceinline__ void stage_weights16(const float* w2, const float* b2
   }
 }
 
-// epilogue of P2: times g_e, masked by m1 (the record bits of the 16 edges in LDS)
-__device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl, int c, int g, f32x4 (&v)[4]) {
+// epilogue of P2: dL/dh1pre[e][k] = v[kb][i] * gm[kb][i] with gm = g_e where the relu mask m1 (the record bits of the 16
+// edges in LDS) is set, +0 elsewhere.  The factor is built here (one bit-field extract + one AND per element); the
+// product itself is left to the consumer — the run sums take it as a fused multiply-add (run_sums), so a half tile
+// without a run boundary costs 16 FMAs instead of 16 multiplies + 12 adds.
+__device__ __forceinline__ void dgrad_masks(const char* recl, const char* gl, int c, int g, f32x4 (&gm)[4]) {
   const int bitpos = 16 * (c & 1) + 7 - ((c & 7) >> 1);
   const char* rrow = recl + 64 * g + 4 * (c >> 3);      // edge 4 g + i at + 16 i; dwords (c >> 3) and 2 + (c >> 3)
 #if defined(PANGNN_D16_PROBE_GE_SCALAR) || defined(PANGNN_D16_PROBE_WAIT0)
   // diagnostic builds (tools/slp_probe.sh): the same arithmetic with (a) g_e read as four dwords instead of one
-  // ds_read_b128, (b) every LDS operand of the epilogue landed (lgkmcnt(0) + idle cycles) before the first product
+  // ds_read_b128, (b) every LDS operand of the epilogue landed (lgkmcnt(0) + idle cycles) before the first use
   f32x4 ge4;
 #ifdef PANGNN_D16_PROBE_GE_SCALAR
 #pragma unroll
@@ -259,8 +262,8 @@ __device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl,
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int keep = __builtin_amdgcn_sbfe((int)dd[i][kb & 1], bitpos - 4 * (kb >> 1), 1);
-      const float val = v[kb][i] * ge4[i];
-      v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
+      const float gei = ge4[i];          // a float OBJECT: __builtin_bit_cast of the vector element itself takes element 0
+      gm[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, gei) & keep);
     }
 #else
   const f32x4 ge4 = *reinterpret_cast<const f32x4*>(gl + 16 * g);
@@ -268,18 +271,31 @@ __device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl,
   for (int i = 0; i < 4; ++i) {
     const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i);          // kb even
     const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rrow + 16 * i + 8);      // kb odd
+    // a float OBJECT first: __builtin_bit_cast applied to the vector-element expression ge4[i] itself reinterprets the
+    // start of the vector (element 0 for every i — hipcc 7.2 emits one ds_read_b32 for all four)
+    const float gei = ge4[i];
+    const int gbits = __builtin_bit_cast(int, gei);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const uint32_t d = (kb & 1) ? d1 : d0;
       const int keep = __builtin_amdgcn_sbfe((int)d, bitpos - 4 * (kb >> 1), 1);     // 0 or -1
-      float val = v[kb][i] * ge4[i];
-#ifdef PANGNN_D16_PROBE_OPAQUE_EPI
-      asm volatile("" : "+v"(val));
-#endif
-      v[kb][i] = __builtin_bit_cast(float, __builtin_bit_cast(int, val) & keep);
+      gm[kb][i] = __builtin_bit_cast(float, gbits & keep);
     }
   }
 #endif
+}
+// the masked products themselves (rare paths of the run sums, the skip-feature gradient, diagnostic dumps)
+__device__ __forceinline__ void dgrad_apply(f32x4 (&v)[4], const f32x4 (&gm)[4]) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float val = v[kb][i] * gm[kb][i];
+#ifdef PANGNN_D16_PROBE_OPAQUE_EPI
+      asm volatile("" : "+v"(val));
+#endif
+      v[kb][i] = val;
+    }
 }
 
 // ---- P2 + its epilogue + run sums, shared by S and T.  Lane (c = lane & 15, g = lane >> 4).
@@ -287,10 +303,10 @@ __device__ __forceinline__ void dgrad_epilogue(const char* recl, const char* gl,
 //   recl    [16][4] dwords in LDS: the m1 bits of edge e, lane group g' (bit 16 (s&1) + 7 - (4 ks + (s >> 1)) for
 //           k = 32 ks + 8 g' + s)
 //   gl      [16] floats in LDS: g_e
-// returns v[kb][i] = dL/dh1pre[e = 4 g + i][k = 16 kb + c]
+// returns v[kb][i] and gm[kb][i] with dL/dh1pre[e = 4 g + i][k = 16 kb + c] = v * gm (dgrad_masks)
 template <bool PIPE>
 __device__ __forceinline__ void dgrad_tile(const char* lds, const char* recl, const char* gl, const bf16x8 (&a2)[2],
-                                           int c, int g, int w2p_off0, int w2p_off1, f32x4 (&v)[4]) {
+                                           int c, int g, int w2p_off0, int w2p_off1, f32x4 (&v)[4], f32x4 (&gm)[4]) {
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) v[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   // the three W2' terms of step (t, kb) are read one step ahead of their MFMAs (an LDS round trip is ~100 cycles,
@@ -320,7 +336,7 @@ __device__ __forceinline__ void dgrad_tile(const char* lds, const char* recl, co
     v[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[t], bq[st & 1][0], v[kb], 0, 0, 0);
   }
   D16_SETPRIO(0);
-  dgrad_epilogue(recl, gl, c, g, v);
+  dgrad_masks(recl, gl, c, g, gm);
 }
 
 // P2 of BOTH halves of a 32-edge tile per W2' fragment read (the T kernel): one ds_read_b128 triple feeds six MFMAs,
@@ -357,21 +373,22 @@ __device__ __forceinline__ void dgrad_tile2(const char* lds, const bf16x8 (&a2)[
 // 256-byte "part" rows; the tile is processed as two 16-edge halves and a run that crosses the middle is carried
 // in ONE register per lane.  m16: bit e set = edge e of this half is the last of its run.  Layout of every summed
 // row: lane (c, g) holds column colp = 16 kRow4[g] + c (what red4 leaves in row g).
-__device__ __forceinline__ void run_sums(const f32x4 (&v)[4], unsigned m16, float& carry, float* part, int64_t& pidx,
-                                         char* wv, int lane, int c, int g, int colp) {
+// The rows are given as factors: row value = v[kb][i] * gm[kb][i] (dgrad_masks) — multiplied inside the sums.
+__device__ __forceinline__ void run_sums(const f32x4 (&v)[4], const f32x4 (&gm)[4], unsigned m16, float& carry, float* part,
+                                         int64_t& pidx, char* wv, int lane, int c, int g, int colp) {
   const unsigned inner = m16 & 0x7fffu;
   if (inner == 0u) {
-    // no boundary before the last edge: one run (open or closing at edge 15)
+    // no boundary before the last edge: one run (open or closing at edge 15) — by far the most frequent case with
+    // chunked run sums: one multiply + three fused multiply-adds per column block
     float x[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
+      float t = v[kb][0] * gm[kb][0];
+      t = fmaf(v[kb][1], gm[kb][1], t);
+      t = fmaf(v[kb][2], gm[kb][2], t);
+      x[kb] = fmaf(v[kb][3], gm[kb][3], t);
 #ifdef PANGNN_D16_PROBE_OPAQUE_RUNSUM
-      float t0 = v[kb][0] + v[kb][1], t1 = v[kb][2] + v[kb][3];
-      asm volatile("" : "+v"(t0), "+v"(t1));
-      x[kb] = t0 + t1;
       asm volatile("" : "+v"(x[kb]));
-#else
-      x[kb] = (v[kb][0] + v[kb][1]) + (v[kb][2] + v[kb][3]);
 #endif
     }
     const float s = carry + red4(x[0], x[1], x[2], x[3]);
@@ -393,8 +410,8 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], unsigned m16, floa
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool first = 4 * g + i <= bnd;
-        a[kb] += first ? v[kb][i] : 0.f;
-        b[kb] += first ? 0.f : v[kb][i];
+        a[kb] = fmaf(v[kb][i], first ? gm[kb][i] : 0.f, a[kb]);
+        b[kb] = fmaf(v[kb][i], first ? 0.f : gm[kb][i], b[kb]);
 #ifdef PANGNN_D16_PROBE_OPAQUE_RUNSUM
         asm volatile("" : "+v"(a[kb]), "+v"(b[kb]));
 #endif
@@ -419,7 +436,7 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], unsigned m16, floa
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) tile[(4 * g + i) * 64 + 16 * kb + c] = v[kb][i];
+      for (int i = 0; i < 4; ++i) tile[(4 * g + i) * 64 + 16 * kb + c] = v[kb][i] * gm[kb][i];
     tile[16 * 64 + colp] = carry;
     wave_sync();
     float sum = tile[16 * 64 + lane];
@@ -795,24 +812,31 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 
       // ---- P2 + run sums by source
       if (RUNSUM || has_extra) {
-        f32x4 v[4];
-        dgrad_tile<false>(lds, wv + WV_REC, wv + WV_GL, a2, c, g, LDS_W2P + wfrag0, LDS_W2P + wfrag1, v);
+        f32x4 v[4], gm[4];
+        dgrad_tile<false>(lds, wv + WV_REC, wv + WV_GL, a2, c, g, LDS_W2P + wfrag0, LDS_W2P + wfrag1, v, gm);
 #ifdef PANGNN_D16_DEBUG
         if (d16_dbg_v != nullptr) {
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (tile * 32 + 16 * hx + 4 * g + i < a.E) d16_dbg_v[(tile * 32 + 16 * hx + 4 * g + i) * 64 + 16 * kb + c] = v[kb][i];
+              if (tile * 32 + 16 * hx + 4 * g + i < a.E)
+                d16_dbg_v[(tile * 32 + 16 * hx + 4 * g + i) * 64 + 16 * kb + c] = v[kb][i] * gm[kb][i];
         }
 #endif
         if (has_extra) {
+          // the skip feature's gradient needs the rows themselves: multiplied out on the side (config 5's instances only);
+          // the run sums below still take the factors, so that they are the same arithmetic in every instance
+          f32x4 pv[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) pv[kb] = v[kb];
+          dgrad_apply(pv, gm);
           const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + WV_WL + 16 * g);
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              gcv[kb] = fmaf(w4[i], v[kb][i], gcv[kb]);
+              gcv[kb] = fmaf(w4[i], pv[kb][i], gcv[kb]);
 #ifdef PANGNN_D16_PROBE_OPAQUE_GCV
               asm volatile("" : "+v"(gcv[kb]));
 #endif
@@ -822,7 +846,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
           const bool closes = in_cur.key != in_cur.key_nxt || (pos == 31 && last_tile);     // key change, or end of the chunk
           const unsigned long long bal = __ballot(closes);
           const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
-          run_sums(v, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
+          run_sums(v, gm, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
         }
       }
       wave_sync();          // the next half tile overwrites the images / recl / gl
@@ -1019,18 +1043,23 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
       dgrad_tile2(lds, a2, wfrag0, wfrag1, v);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        dgrad_epilogue(wv + TW_REC + 256 * h, wv + TW_GL + 64 * h, c, g, v[h]);
+        f32x4 gm[4];
+        dgrad_masks(wv + TW_REC + 256 * h, wv + TW_GL + 64 * h, c, g, gm);
         if (has_extra && gcv_slabs != nullptr) {
+          f32x4 pv[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) pv[kb] = v[h][kb];
+          dgrad_apply(pv, gm);
           const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + TW_WL + 64 * h + 16 * g);
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], v[h][kb][i], gcv[kb]);
+            for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], pv[kb][i], gcv[kb]);
         }
         const bool closes = cur[h].key != cur[h].key_nxt || (h == 1 && c == 15 && last_tile);   // key change, or end of the chunk
         const unsigned long long bal = __ballot(closes);
         const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
-        run_sums(v[h], m16, carry, rs.part, pidx, wv, lane, c, g, colp);
+        run_sums(v[h], gm, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
       }
     }
     wave_sync();          // the next tile overwrites recl / gl / wl
