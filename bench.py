@@ -414,8 +414,8 @@ def main():
         ct = PF.d16_chunk()
         pl_s = st_sim.runsum_plan(ct) if st_sim is not None else None
         pl_d = st_sim.csr_plan("dst", ct) if st_sim is not None else None
-        n_parts_s = pl_s.n_parts if pl_s is not None else 0
-        n_parts_d = pl_d.n_parts if pl_d is not None else 0
+        n_parts_s = pl_s.n_parts_exact() if pl_s is not None else 0        # (the buffers are sized by an upper bound)
+        n_parts_d = pl_d.n_parts_exact() if pl_d is not None else 0
         line = {
             "metric": "edges/sec in GNN forward+backward (link-pred train step)",
             "value": e_sim * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,

@@ -360,6 +360,18 @@ int    pangnn_band_propagate(const void* x, int32_t x_dtype, int64_t ldx, const 
  *   everything the layer's backward needs — dL/da, dL/dc, dL/db_in — from which dL/dW = dL/da w^T + dL/dc b^T,
  *   dL/dw = W^T dL/da, dL/db = W^T dL/dc.  g stored as f32 or bf16; reproducible two-stage sum.
  * ---------------------------------------------------------------------------------------- */
+/* The same layer with the parameter algebra inside the kernels (one launch forward, three backward — what the
+ * model uses): a = W w and c = W b are formed per workgroup in LDS; the backward runs pangnn_weighted_colsum3 and then
+ * forms dL/dW_in [H, D], dL/dw [D], dL/db [D], dL/db_in [H] (nullable) in one small kernel.
+ * workspace: pangnn_embed_conv_in_grads_workspace_bytes(H). */
+int    pangnn_embed_conv_in_rows(const float* r, const float* s, const float* w_emb, const float* b_emb, const float* w_in,
+                                 const float* b_in, int32_t D, void* out, int32_t out_dtype, int64_t ldo, int64_t n,
+                                 int32_t H, pangnn_stream_t stream);
+size_t pangnn_embed_conv_in_grads_workspace_bytes(int32_t H);
+int    pangnn_embed_conv_in_grads(const void* g, int32_t g_dtype, int64_t ldg, const float* r, const float* s, int64_t n,
+                                  const float* w_emb, const float* b_emb, const float* w_in, int32_t D, int32_t H,
+                                  float* g_w_emb, float* g_b_emb, float* g_w_in, float* g_b_in, void* workspace,
+                                  size_t workspace_bytes, pangnn_stream_t stream);
 int    pangnn_rank2_rows(const float* r, const float* s, const float* a, const float* c, const float* bias, void* out,
                          int32_t out_dtype, int64_t ldo, int64_t n, int32_t F, pangnn_stream_t stream);
 size_t pangnn_weighted_colsum3_workspace_bytes(int32_t F);

@@ -51,6 +51,10 @@ SIGNATURES = {
     "pangnn_weighted_colsum_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _p, _p, _sz, _p]),
     "pangnn_band_propagate_workspace_bytes": (_sz, [_i32]),
     "pangnn_band_propagate": (C.c_int, [_p, _i32, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),
+    "pangnn_embed_conv_in_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i64, _i64, _i32, _p]),
+    "pangnn_embed_conv_in_grads_workspace_bytes": (_sz, [_i32]),
+    "pangnn_embed_conv_in_grads": (C.c_int, [_p, _i32, _i64, _p, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _sz,
+                                             _p]),
     "pangnn_rank2_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _p]),
     "pangnn_weighted_colsum3_workspace_bytes": (_sz, [_i32]),
     "pangnn_weighted_colsum3": (C.c_int, [_p, _i32, _i64, _p, _p, _i64, _i32, _p, _p, _sz, _p]),

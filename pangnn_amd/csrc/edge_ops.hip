@@ -358,6 +358,66 @@ __global__ __launch_bounds__(kSumThreads) void colsum3_finish_kernel(const float
   if (threadIdx.x < kWave && i < 3 * F) out[i] = t;
 }
 
+// rank2_rows_kernel with a = W w and c = W b formed in the kernel (per workgroup, in LDS): no host-side parameter
+// algebra, one launch for the whole layer.  W [H, D] row-major, H <= 256.
+template <typename TY>
+__global__ __launch_bounds__(kBlock) void embed_conv_in_rows_kernel(const float* __restrict__ r, const float* __restrict__ sv,
+                                                                    const float* __restrict__ w_emb,
+                                                                    const float* __restrict__ b_emb,
+                                                                    const float* __restrict__ w_in,
+                                                                    const float* __restrict__ bias, int D,
+                                                                    TY* __restrict__ out, int64_t ldo, int64_t n, int F) {
+  __shared__ __attribute__((aligned(16))) float ac[2][kBlock];
+  if ((int)threadIdx.x < F) {
+    float a = 0.f, c = 0.f;
+    const float* wr = w_in + (int64_t)threadIdx.x * D;
+    for (int d = 0; d < D; ++d) { a = fmaf(wr[d], w_emb[d], a); c = fmaf(wr[d], b_emb[d], c); }
+    ac[0][threadIdx.x] = a;
+    ac[1][threadIdx.x] = c;
+  }
+  __syncthreads();
+  const int lpr = F / 4;
+  const int col = 4 * (threadIdx.x % lpr), rg = threadIdx.x / lpr, groups = kBlock / lpr;
+  const float4 av = *reinterpret_cast<const float4*>(&ac[0][col]), cv = *reinterpret_cast<const float4*>(&ac[1][col]);
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t row = (int64_t)blockIdx.x * groups + rg; row < n; row += (int64_t)gridDim.x * groups) {
+    const float rv = r[row], sw = sv[row];
+    const float v0 = fmaf(rv, av.x, fmaf(sw, cv.x, bv.x)), v1 = fmaf(rv, av.y, fmaf(sw, cv.y, bv.y));
+    const float v2 = fmaf(rv, av.z, fmaf(sw, cv.z, bv.z)), v3 = fmaf(rv, av.w, fmaf(sw, cv.w, bv.w));
+    if constexpr (sizeof(TY) == 4) {
+      *reinterpret_cast<float4*>(out + row * ldo + col) = make_float4(v0, v1, v2, v3);
+    } else {
+      __bf16 o[4] = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+      *reinterpret_cast<uint2*>(out + row * ldo + col) = *reinterpret_cast<const uint2*>(o);
+    }
+  }
+}
+
+// the layer's parameter gradients from sums = [r s 1]^T g  ([3, H], finished):  dL/da = sums[0], dL/dc = sums[1]
+//   g_w_in[h][d] = sums[0][h] w[d] + sums[1][h] b[d]     g_w_emb[d] = sum_h W[h][d] sums[0][h]
+//   g_b_in[h]    = sums[2][h]                            g_b_emb[d] = sum_h W[h][d] sums[1][h]      (fixed order)
+__global__ __launch_bounds__(kBlock) void embed_conv_in_param_grads_kernel(const float* __restrict__ sums,
+                                                                           const float* __restrict__ w_emb,
+                                                                           const float* __restrict__ b_emb,
+                                                                           const float* __restrict__ w_in, int D, int H,
+                                                                           float* __restrict__ g_w_emb,
+                                                                           float* __restrict__ g_b_emb,
+                                                                           float* __restrict__ g_w_in,
+                                                                           float* __restrict__ g_b_in) {
+  for (int i = threadIdx.x; i < H * D; i += kBlock) {
+    const int h = i / D, d = i % D;
+    g_w_in[i] = fmaf(sums[h], w_emb[d], sums[H + h] * b_emb[d]);
+  }
+  for (int d = threadIdx.x; d < D; d += kBlock) {
+    float u = 0.f, v = 0.f;
+    for (int h = 0; h < H; ++h) { u = fmaf(w_in[(int64_t)h * D + d], sums[h], u); v = fmaf(w_in[(int64_t)h * D + d], sums[H + h], v); }
+    g_w_emb[d] = u;
+    g_b_emb[d] = v;
+  }
+  if (g_b_in)
+    for (int h = threadIdx.x; h < H; h += kBlock) g_b_in[h] = sums[2 * H + h];
+}
+
 static inline unsigned grid_for(int64_t total) {
   int64_t b = (total + kBlock - 1) / kBlock;
   const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
@@ -628,6 +688,32 @@ extern "C" int pangnn_rank2_rows(const float* r, const float* s, const float* a,
   return 0;
 }
 
+extern "C" int pangnn_embed_conv_in_rows(const float* r, const float* s, const float* w_emb, const float* b_emb,
+                                         const float* w_in, const float* b_in, int32_t D, void* out, int32_t out_dtype,
+                                         int64_t ldo, int64_t n, int32_t H, pangnn_stream_t stream) {
+  const char* who = "pangnn_embed_conv_in_rows";
+  PG_CHECK_ARG(n >= 0 && D > 0 && H > 0 && H % 4 == 0 && H <= kBlock && (4 * kBlock) % H == 0 && ldo >= H && ldo % 4 == 0,
+               PANGNN_E_BADARG, "%s: H must be a multiple of 4 dividing 1024, at most 256; ldo >= H (H=%d)", who, (int)H);
+  PG_CHECK_ARG(out_dtype == PANGNN_DTYPE_F32 || out_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
+               "%s: out_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  if (n == 0) return 0;
+  PG_CHECK_ARG(r && s && w_emb && b_emb && w_in && out, PANGNN_E_BADARG, "%s: null pointer", who);
+  PG_CHECK_ARG((!b_in || aligned16(b_in)) &&
+                   (out_dtype == PANGNN_DTYPE_F32 ? aligned16(out) : (reinterpret_cast<uintptr_t>(out) & 7u) == 0),
+               PANGNN_E_ALIGN, "%s: b_in / out rows must be 16-byte (bf16 out: 8-byte) aligned", who);
+  const int groups = kBlock / (H / 4);
+  int64_t blocks = (n + groups - 1) / groups;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (out_dtype == PANGNN_DTYPE_F32)
+    hipLaunchKernelGGL(embed_conv_in_rows_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r, s, w_emb,
+                       b_emb, w_in, b_in, (int)D, static_cast<float*>(out), ldo, n, (int)H);
+  else
+    hipLaunchKernelGGL(embed_conv_in_rows_kernel<unsigned short>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r,
+                       s, w_emb, b_emb, w_in, b_in, (int)D, static_cast<unsigned short*>(out), ldo, n, (int)H);
+  PG_CHECK_LAUNCH(who);
+  return 0;
+}
+
 extern "C" size_t pangnn_weighted_colsum3_workspace_bytes(int32_t F) {
   return (size_t)kColsumBlocks * 3 * (size_t)(F > 0 ? F : 1) * sizeof(float);
 }
@@ -659,6 +745,31 @@ extern "C" int pangnn_weighted_colsum3(const void* g, int32_t g_dtype, int64_t l
   hipLaunchKernelGGL(colsum3_finish_kernel, dim3((3 * F + kWave - 1) / kWave), dim3(kSumThreads), 0, st,
                      static_cast<const float*>(workspace), blocks, (int)F, out);
   PG_CHECK_LAUNCH("pangnn_weighted_colsum3(finish)");
+  return 0;
+}
+
+extern "C" size_t pangnn_embed_conv_in_grads_workspace_bytes(int32_t H) {
+  return pangnn_weighted_colsum3_workspace_bytes(H) + 3 * (size_t)(H > 0 ? H : 1) * sizeof(float);
+}
+
+extern "C" int pangnn_embed_conv_in_grads(const void* g, int32_t g_dtype, int64_t ldg, const float* r, const float* s,
+                                          int64_t n, const float* w_emb, const float* b_emb, const float* w_in, int32_t D,
+                                          int32_t H, float* g_w_emb, float* g_b_emb, float* g_w_in, float* g_b_in,
+                                          void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
+  const char* who = "pangnn_embed_conv_in_grads";
+  PG_CHECK_ARG(D > 0 && H > 0 && w_emb && b_emb && w_in && g_w_emb && g_b_emb && g_w_in, PANGNN_E_BADARG,
+               "%s: null pointer / size", who);
+  PG_CHECK_ARG(workspace && workspace_bytes >= pangnn_embed_conv_in_grads_workspace_bytes(H), PANGNN_E_WORKSPACE,
+               "%s: workspace too small", who);
+  // sums [3, H] at the head of the workspace, the column-sum partials behind it
+  float* sums = static_cast<float*>(workspace);
+  char* rest = static_cast<char*>(workspace) + 3 * (size_t)H * sizeof(float);
+  const int rc = pangnn_weighted_colsum3(g, g_dtype, ldg, r, s, n, H, sums, rest, workspace_bytes - 3 * (size_t)H * sizeof(float),
+                                         stream);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(embed_conv_in_param_grads_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, sums, w_emb, b_emb, w_in,
+                     (int)D, (int)H, g_w_emb, g_b_emb, g_w_in, g_b_in);
+  PG_CHECK_LAUNCH(who);
   return 0;
 }
 

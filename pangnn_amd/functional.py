@@ -858,9 +858,10 @@ class _EmbedConvIn(torch.autograd.Function):
         A_hat (x w^T + 1 b^T) W^T + b_in  =  r a^T + s c^T + b_in,     r = A_hat x, s = A_hat 1, a = W w, c = W b.
 
     r and s are node vectors computed once per graph by the propagate kernel (`_node_actions`, cached like gcn_norm);
-    per step the layer is ONE pass that writes the [N, H] rows (pangnn_rank2_rows) — no propagate, no dense product —
-    and its backward ONE pass over dL/dout (pangnn_weighted_colsum3: [r s 1]^T g), from which
-    dL/dW = (r^T g) w^T + (s^T g) b^T, dL/dw = W^T (r^T g), dL/db = W^T (s^T g), dL/db_in = 1^T g.
+    per step the layer is ONE launch that writes the [N, H] rows (pangnn_embed_conv_in_rows: a, c formed in the kernel) —
+    no propagate, no dense product — and its backward ONE pass over dL/dout ([r s 1]^T g) plus a one-workgroup kernel
+    forming dL/dW = (r^T g) w^T + (s^T g) b^T, dL/dw = W^T (r^T g), dL/db = W^T (s^T g), dL/db_in = 1^T g
+    (pangnn_embed_conv_in_grads).
     The propagate and the dense layer commute, so this is also GCNConv's linear-then-propagate order (in >= out).
     Exact algebra (no approximation): the result differs from the layer-by-layer evaluation by fp32 re-association
     only.  `x_tab` as in _EmbedPropagate (own + halo rows on a shard)."""
@@ -870,17 +871,15 @@ class _EmbedConvIn(torch.autograd.Function):
         lib = _lib.load()
         _lib.require_device(x_tab, w, b, w_in, b_in)
         r, s = _node_actions(x_tab, st, norm)
-        wv, bv, win = w.detach().reshape(-1).float(), b.detach().reshape(-1).float(), w_in.detach().float()
-        with torch.autocast("cuda", enabled=False):      # H x D x 2 parameter algebra stays fp32 (the kernel reads floats)
-            ac = (win @ torch.stack([wv, bv], dim=1)).t().contiguous()         # [2, H]: a = W w, c = W b
-        assert ac.dtype == torch.float32
-        n, h = st.num_nodes, win.shape[0]
+        wv, bv, win = _f32c(w.detach().reshape(-1)), _f32c(b.detach().reshape(-1)), _f32c(w_in.detach())
+        n, h, d = st.num_nodes, win.shape[0], win.shape[1]
         bias = None if b_in is None else _f32c(b_in.detach())
         out = torch.empty(n, h, dtype=out_dtype or torch.float32, device=r.device)
         with torch.cuda.device(r.device):
-            _lib.check(lib.pangnn_rank2_rows(r.data_ptr(), s.data_ptr(), ac[0].data_ptr(), ac[1].data_ptr(), _lib.ptr(bias),
-                                             out.data_ptr(), _dt(out), out.stride(0), n, h, _lib.stream_ptr()),
-                       "pangnn_rank2_rows")
+            # a = W w and c = W b are formed inside the kernel: the whole layer is this one launch
+            _lib.check(lib.pangnn_embed_conv_in_rows(r.data_ptr(), s.data_ptr(), wv.data_ptr(), bv.data_ptr(), win.data_ptr(),
+                                                     _lib.ptr(bias), d, out.data_ptr(), _dt(out), out.stride(0), n, h,
+                                                     _lib.stream_ptr()), "pangnn_embed_conv_in_rows")
         ctx.save_for_backward(r, s, wv, bv, win)
         ctx.has_bias = b_in is not None
         return out
@@ -891,18 +890,19 @@ class _EmbedConvIn(torch.autograd.Function):
         r, s, wv, bv, win = ctx.saved_tensors
         g = _rows_any(g)
         n, h = g.shape
-        sums = torch.empty(3, h, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
-            ws_bytes = lib.pangnn_weighted_colsum3_workspace_bytes(h)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
-            _lib.check(lib.pangnn_weighted_colsum3(g.data_ptr(), _dt(g), g.stride(0), r.data_ptr(), s.data_ptr(), n, h,
-                                                   sums.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
-                       "pangnn_weighted_colsum3")
-        ga_gc = sums[:2]                                                       # dL/da, dL/dc  [2, H]
-        with torch.autocast("cuda", enabled=False):      # backward may run inside the caller's autocast region
-            g_emb = ga_gc @ win                                                # [2, D]: dL/dw, dL/db
-            g_win = ga_gc.t() @ torch.stack([wv, bv], dim=0)                   # [H, D] = dL/da w^T + dL/dc b^T
-        return (None, g_emb[0].reshape(-1, 1), g_emb[1], g_win, sums[2] if ctx.has_bias else None, None, None, None)
+        d = win.shape[1]
+        dev = g.device
+        g_w, g_b = torch.empty(d, 1, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)
+        g_win = torch.empty(h, d, dtype=torch.float32, device=dev)
+        g_bin = torch.empty(h, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        with torch.cuda.device(dev):
+            ws_bytes = lib.pangnn_embed_conv_in_grads_workspace_bytes(h)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.pangnn_embed_conv_in_grads(g.data_ptr(), _dt(g), g.stride(0), r.data_ptr(), s.data_ptr(), n,
+                                                      wv.data_ptr(), bv.data_ptr(), win.data_ptr(), d, h, g_w.data_ptr(),
+                                                      g_b.data_ptr(), g_win.data_ptr(), _lib.ptr(g_bin), ws.data_ptr(), ws_bytes,
+                                                      _lib.stream_ptr()), "pangnn_embed_conv_in_grads")
+        return None, g_w, g_b, g_win, g_bin, None, None, None
 
 
 def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):

@@ -61,10 +61,15 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, group_by: int, validate:
 class EdgeStructure:
     """Both groupings of one edge_index plus memoised GCN normalisations."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, num_src: Optional[int] = None):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, num_src: Optional[int] = None, hints: Optional[dict] = None):
         """`num_nodes` = number of TARGET rows (= all nodes for a whole graph).  `num_src` (default
         the same) = number of SOURCE rows: a destination-partitioned shard keeps local target ids
-        and global source ids (pangnn_amd/dist.py)."""
+        and global source ids (pangnn_amd/dist.py).
+        `hints` (optional; set by producers that KNOW them, e.g. SubGraphDataset.batch): {"valid_ids": True} — every id
+        is inside [0, num_nodes), skip the range check and its host read-back; {"sorted_by_src": bool} — whether the
+        list is source-sorted, skip that test's host read-back.  With both a structure is built without any
+        device -> host synchronisation (a fresh mini-batch per step, pangnn.py:152-216)."""
+        self.hints = dict(hints or {})
         self._key_tensor = edge_index        # the caches are keyed on THIS tensor's address: keep it alive
         self.edge_index = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
         self.num_nodes = int(num_nodes)
@@ -80,7 +85,8 @@ class EdgeStructure:
     def by_dst(self) -> CSR:
         if self._by_dst is None:
             nmax = max(self.num_nodes, self.num_src)
-            self._by_dst = build_csr(self.edge_index, nmax, 1, num_rows=self.num_nodes)
+            self._by_dst = build_csr(self.edge_index, nmax, 1, validate=not self.hints.get("valid_ids", False),
+                                     num_rows=self.num_nodes)
             if self.num_nodes < nmax and self.num_edges and int(self.edge_index[1].max()) >= self.num_nodes:
                 raise ValueError("target id outside the local row range")
         return self._by_dst
@@ -126,11 +132,17 @@ class EdgeStructure:
         flags = (torch.arange(e, device=keys.device) % span) == 0
         flags[1:] |= keys[1:] != keys[:-1]
         part_id = torch.cumsum(flags, 0) - 1
-        n_parts = int(part_id[-1]) + 1
-        part_rowptr = torch.searchsorted(keys[flags].contiguous(), torch.arange(n_rows + 1, device=keys.device))
-        return SimpleNamespace(n_parts=n_parts, part_off=part_id[::span].to(torch.int32).contiguous(),
-                               part_rowptr=part_rowptr.contiguous(), keys=keys.to(torch.int32).contiguous(),
-                               chunk_tiles=int(chunk_tiles))
+        # Everything stays on the device (no host read-back): the part buffer is sized by an upper bound — one part per
+        # chunk start plus one per key change — and a row's first part is the part of its first entry (a key change
+        # always starts a part).  `n_parts_exact()` reads the true count when somebody needs it (bench accounting).
+        n_bound = (e + span - 1) // span + min(int(n_rows), e)
+        first = torch.searchsorted(keys, torch.arange(n_rows + 1, device=keys.device, dtype=keys.dtype))
+        pid_ext = torch.cat([part_id, part_id[-1:] + 1])
+        plan = SimpleNamespace(n_parts=n_bound, part_off=part_id[::span].to(torch.int32).contiguous(),
+                               part_rowptr=pid_ext[first].contiguous(), keys=keys.to(torch.int32).contiguous(),
+                               chunk_tiles=int(chunk_tiles), _last=part_id[-1:])
+        plan.n_parts_exact = lambda: int(plan._last) + 1
+        return plan
 
     def csr_plan(self, by: str, chunk_tiles: int = 1):
         """run-sum plan of the CSR order `by` in {"dst", "src"} (pangnn_decoder_dgrad_f32: perm = that CSR's perm)"""
@@ -151,7 +163,12 @@ class EdgeStructure:
           part_rowptr[s] parts of source s are [part_rowptr[s], part_rowptr[s+1])   (consecutive: sorted)"""
         if self._runsum is None:
             src, e = self.edge_index[0], self.num_edges
-            self._runsum = {} if (e > 0 and bool((src[1:] >= src[:-1]).all())) else False
+            if e == 0:
+                self._runsum = False
+            elif "sorted_by_src" in self.hints:
+                self._runsum = {} if self.hints["sorted_by_src"] else False
+            else:
+                self._runsum = {} if bool((src[1:] >= src[:-1]).all()) else False
         if self._runsum is False:
             return None
         ct = int(chunk_tiles)
@@ -252,7 +269,8 @@ def structure_of(edge_index: torch.Tensor, num_nodes: int, holder=None, name: st
             hit = d.get(name)
             if hit is not None and hit[0] == key:
                 return hit[1]
-            st = EdgeStructure(edge_index, num_nodes)
+            hints = getattr(holder, "_pangnn_hints", None)
+            st = EdgeStructure(edge_index, num_nodes, hints=None if hints is None else hints.get(name))
             d[name] = (key, st)
             return st
     hit = _CACHE.get(key)

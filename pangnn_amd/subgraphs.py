@@ -185,20 +185,37 @@ class SubGraphDataset:
     def __len__(self):
         return self.num_graphs
 
+    def _host(self):
+        """host copies of the three offset tables and the order property of the flat edge list, read back ONCE: collating a
+        batch then needs no device -> host synchronisation"""
+        h = self.__dict__.get("_host_cache")
+        if h is None:
+            src = self.edge_index[0]
+            h = self._host_cache = SimpleNamespace(
+                node=self.node_off.tolist(), edge=self.edge_off.tolist(), nb=self.nb_off.tolist(),
+                sorted_by_src=bool((src[1:] >= src[:-1]).all()) if src.numel() > 1 else True)
+        return h
+
     def batch(self, i0: int, i1: int):
         i1 = min(i1, self.num_graphs)
-        n0, n1 = int(self.node_off[i0]), int(self.node_off[i1])
-        e0, e1 = int(self.edge_off[i0]), int(self.edge_off[i1])
-        b0, b1 = int(self.nb_off[i0]), int(self.nb_off[i1])
+        h = self._host()
+        n0, n1 = h.node[i0], h.node[i1]
+        e0, e1 = h.edge[i0], h.edge[i1]
+        b0, b1 = h.nb[i0], h.nb[i1]
         dev = self.edge_index.device
         ptr = self.node_off[i0:i1 + 1] - n0
+        # what this producer knows about the batch (graph.EdgeStructure hints): ids are local and in range by
+        # construction; a slice of a source-sorted flat list shifted by a constant is source-sorted
+        hints = {"sim": {"valid_ids": True, "sorted_by_src": h.sorted_by_src}, "nb": {"valid_ids": True}}
         return SimpleNamespace(
+            _pangnn_hints=hints,
             x=torch.ones(n1 - n0, 1, dtype=torch.float32, device=dev),
             edge_index=(self.edge_index[:, e0:e1] - n0).contiguous(),
             edge_attr=self.edge_attr[e0:e1].contiguous(), y=self.y[e0:e1].contiguous(),
             neighbour_edge_index=(self.neighbour_edge_index[:, b0:b1] - n0).contiguous(),
             ptr=ptr, num_graphs=i1 - i0,
-            batch=torch.repeat_interleave(torch.arange(i1 - i0, device=dev), ptr[1:] - ptr[:-1]))
+            # graph id of every node: position of the node among the graphs' end offsets (no data-dependent output size)
+            batch=torch.searchsorted(ptr[1:].contiguous(), torch.arange(n1 - n0, device=dev), right=True))
 
     def graph(self, i: int):
         return self.batch(i, i + 1)
