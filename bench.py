@@ -50,8 +50,9 @@ WORKLOADS = {
 CFG5 = {"cfg5", "cfg5slice"}
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # what limits the S kernel (profiles/*_pmc_sq_decoder16.txt; updated with the kernel)
-S_BINDS = ("vector-instruction issue (611 vector incl. 84 MFMA + 88 LDS + 46 scalar instructions per 16 edges at two waves "
-           "per SIMD; profiles/r02zz_pmc_sq_decoder16.txt), not the matrix pipe (36 % busy) nor HBM")
+S_BINDS = ("vector-instruction issue (580 vector incl. 84 MFMA + 89 LDS + 55 scalar instructions per 16 edges at two waves "
+           "per SIMD; profiles/r03a_pmc_sq_decoder16.txt, profiles/r03_S_instruction_budget.txt), not the matrix pipe (36 % "
+           "busy) nor HBM")
 
 
 def spmm_alg_bytes(e, n, f, s=4):
