@@ -121,17 +121,24 @@ class _Propagate(torch.autograd.Function):
         return gx, gb, None, None, None
 
 
-# PANGNN_DISPATCHER_OPS=1: the propagate goes through the registered dispatcher op torch.ops.pangnn.propagate
-# (csrc/torch_ops.cpp + torch_ops.py: autograd, fake kernel, autocast policy) instead of the ctypes autograd.Function —
-# same kernels, bit-identical results; what torch.compile / accelerate's autocast need to see the operator.
-USE_DISPATCHER_OPS = os.environ.get("PANGNN_DISPATCHER_OPS", "0") == "1"
+# The per-step operators (dense layer, GCN propagate, first layer by linearity, training / inference decoder) go through
+# registered dispatcher ops `torch.ops.pangnn.*` (torch_ops.py: fake kernels, autograd formulas built from registered
+# ops) — what FakeTensor tracing / torch.compile need to see them.  Same kernels and the same host code as the ctypes
+# autograd.Functions in this file, bit-identical results.  PANGNN_DISPATCHER_OPS=0 selects the autograd.Functions (the
+# route a partitioned shard always takes: its rectangular structures have no tensor-only description).
+USE_DISPATCHER_OPS = os.environ.get("PANGNN_DISPATCHER_OPS", "1") == "1"
+
+
+def _via_ops(st: Optional[EdgeStructure] = None, tag=None) -> bool:
+    """route this call through torch.ops.pangnn.*: whole (square) graphs, default decoder precision, no kernel timer"""
+    return USE_DISPATCHER_OPS and (st is None or st.num_src == st.num_nodes) and (KERNEL_TIMER is None or tag is None)
 
 
 def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
-    if USE_DISPATCHER_OPS and st.num_src == st.num_nodes and (KERNEL_TIMER is None or tag is None):
+    if _via_ops(st, tag) and getattr(norm, "weight_ref", norm) is not norm:
         from . import torch_ops
         _lib.require_device(x, bias)
-        return torch_ops.propagate(x, bias, st, norm)
+        return torch_ops.gcn_propagate(x, bias, st, norm)
     return _Propagate.apply(x, bias, st, norm, tag)
 
 
@@ -180,11 +187,19 @@ def band_propagate(x, bias, st: EdgeStructure, norm: GcnNorm):
     return _BandPropagate.apply(x, bias, norm.deg_inv_sqrt, st.band_width())
 
 
+def _band_ok(x, st: EdgeStructure, unit_weights: bool) -> bool:
+    return bool(unit_weights) and x.dim() == 2 and x.shape[1] in (64, 128) and st.num_src == st.num_nodes \
+        and st.band_width() > 0
+
+
 def propagate_any(x, bias, st: EdgeStructure, norm: GcnNorm, unit_weights: bool, tag=None):
     """GCNConv's message passing: the band kernel when the structure is the positional-neighbour band with unit weights
     (whole-graph mode of the reference), the general CSR kernels otherwise"""
-    if unit_weights and x.dim() == 2 and x.shape[1] in (64, 128) and st.num_src == st.num_nodes and st.band_width() > 0 \
-            and (KERNEL_TIMER is None or tag is None or (tag + ".fwd") not in KERNEL_TIMER):
+    if _via_ops(st, tag) and getattr(norm, "weight_ref", norm) is not norm:
+        from . import torch_ops
+        _lib.require_device(x, bias)
+        return torch_ops.gcn_propagate(x, bias, st, norm, unit_weights)         # the op makes the same band / CSR choice
+    if _band_ok(x, st, unit_weights) and (KERNEL_TIMER is None or tag is None or (tag + ".fwd") not in KERNEL_TIMER):
         return band_propagate(x, bias, st, norm)
     return propagate(x, bias, st, norm, tag)
 
@@ -570,6 +585,10 @@ def decoder_mlp(p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
 
 def decoder_mlp_pq(pq, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
     """p = pq[:, :D], q = pq[:, D:] (one [N, 2D] node-level product)"""
+    _lib.require_device(pq, extra, cvec, w2, b2, w3, b3)
+    if _via_ops(st) and DECODER_PRECISION == 1:
+        from . import torch_ops
+        return torch_ops.decoder_mlp_pq(pq, st, extra, cvec, w2, b2, w3, b3)
     return _DecoderMLP.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, True)
 
 
@@ -589,6 +608,8 @@ def unit_grad(device) -> torch.Tensor:
 
 
 def is_unit_grad(g: torch.Tensor) -> bool:
+    if type(g) is not torch.Tensor:          # a FakeTensor / FunctionalTensor while a compiler traces the backward formula
+        return False
     t = _UNIT_GRAD.get(g.device)
     return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0
 
@@ -688,6 +709,10 @@ def decoder_loss(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
 
 
 def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+    _lib.require_device(pq, extra, cvec, w2, b2, w3, b3, y, pos_weight)
+    if _via_ops(st) and DECODER_PRECISION == 1:
+        from . import torch_ops
+        return torch_ops.decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
     return _DecoderLoss.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, True)
 
 
@@ -744,16 +769,24 @@ class _Linear(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+@torch.compiler.assume_constant_result
+def _linear_supported(k: int, m: int) -> bool:
+    """pangnn_linear_supported(k, m, wgrad=1); a constant of the shapes, baked in when torch.compile traces"""
+    return bool(_lib.load().pangnn_linear_supported(k, m, 1))
+
+
 def linear(x, w, bias=None, in_act: int = 0, out_dtype=None):
     """torch.nn.functional.linear for node-level layers; shapes the HIP kernels do not cover
     (K or M outside {64,128}, or the 128x128 weight gradient) go to hipBLASLt via torch.
     in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels (see _Linear).
     `x` may be stored as bfloat16 and `out_dtype=torch.bfloat16` stores the result as bfloat16 (config 5's autocast
     Linear outputs): fp32 products and sums either way, one rounding on store; gradients of bf16 tensors are bf16."""
-    lib = _lib.load()
     _lib.require_device(x, w, bias)                  # no CPU path: the torch branch below is hipBLASLt on the GPU
     k, m = w.shape[1], w.shape[0]
-    if x.dim() == 2 and lib.pangnn_linear_supported(k, m, 1):
+    if x.dim() == 2 and _linear_supported(int(k), int(m)):
+        if _via_ops() and out_dtype in (None, torch.float32, torch.bfloat16):
+            from . import torch_ops
+            return torch_ops.ops.linear(x, w, bias, int(in_act), out_dtype == torch.bfloat16)
         return _Linear.apply(x, w, bias, in_act, out_dtype)
     if in_act:
         x = torch.nn.functional.elu(x)
@@ -790,6 +823,10 @@ class _BCEWithLogits(torch.autograd.Function):
 
 
 def bce_with_logits(logits, y, pos_weight=None, denom=None):
+    _lib.require_device(logits, y, pos_weight)
+    if _via_ops():
+        from . import torch_ops
+        return torch_ops.ops.bce_with_logits(logits, y, pos_weight, int(logits.shape[0] if denom is None else denom))[0]
     return _BCEWithLogits.apply(logits, y, pos_weight, logits.shape[0] if denom is None else denom)
 
 
@@ -849,6 +886,10 @@ class _EmbedPropagate(torch.autograd.Function):
 
 
 def embed_propagate(x_tab, w, b, st, norm, tag=None):
+    _lib.require_device(x_tab, w, b)
+    if _via_ops(st, tag) and getattr(norm, "weight_ref", norm) is not norm:
+        from . import torch_ops
+        return torch_ops.embed_propagate(x_tab, w, b, st, norm)
     return _EmbedPropagate.apply(x_tab, w, b, st, norm, tag)
 
 
@@ -906,4 +947,8 @@ class _EmbedConvIn(torch.autograd.Function):
 
 
 def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):
+    _lib.require_device(x_tab, w, b, w_in, b_in)
+    if _via_ops(st) and getattr(norm, "weight_ref", norm) is not norm and out_dtype in (None, torch.float32, torch.bfloat16):
+        from . import torch_ops
+        return torch_ops.embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype)
     return _EmbedConvIn.apply(x_tab, w, b, w_in, b_in, st, norm, out_dtype)

@@ -187,6 +187,7 @@ class EdgeStructure:
             # the entry keeps `edge_weight` alive: a freed tensor's address can be handed to a new same-shape
             # tensor (fresh tensors all have _version 0), which would then match this key
             hit = (GcnNorm(self, edge_weight, gather_dis), edge_weight)
+            hit[0].weight_ref = edge_weight              # the caller's tensor (cache key): the dispatcher ops pass it on
             if len(self._norm) >= 4:
                 self._norm.pop(next(iter(self._norm)))
             self._norm[key] = hit
@@ -255,6 +256,8 @@ _CACHE_MAX = 16
 def structure_of(edge_index: torch.Tensor, num_nodes: int, holder=None, name: str = "") -> EdgeStructure:
     """EdgeStructure for `edge_index`.  If `holder` (a Data/Batch object) is given the structure is
     kept on it (`holder._pangnn_structs[name]`), otherwise in a small identity-keyed cache."""
+    if torch.compiler.is_compiling():
+        return TracedStructure(edge_index, num_nodes)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
            edge_index.device.index)
     if holder is not None:
@@ -272,6 +275,7 @@ def structure_of(edge_index: torch.Tensor, num_nodes: int, holder=None, name: st
             hints = getattr(holder, "_pangnn_hints", None)
             st = EdgeStructure(edge_index, num_nodes, hints=None if hints is None else hints.get(name))
             d[name] = (key, st)
+            register(st, key)
             return st
     hit = _CACHE.get(key)
     if hit is not None:
@@ -281,6 +285,40 @@ def structure_of(edge_index: torch.Tensor, num_nodes: int, holder=None, name: st
         _CACHE.pop(next(iter(_CACHE)))
     _CACHE[key] = st
     return st
+
+
+class TracedStructure:
+    """What torch.compile sees of a graph while it traces the model: the tensors and the sizes, nothing built.  The
+    dispatcher ops (torch_ops.py) take `edge_index` / `edge_weight` as tensors and look the real EdgeStructure / GcnNorm up
+    by identity when the compiled graph RUNS (structure_of without a holder: the small global cache)."""
+    traced = True
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        self._key_tensor = self.edge_index = edge_index
+        self.num_nodes = self.num_src = int(num_nodes)
+        self.num_edges = edge_index.shape[1]
+
+    def gcn_norm(self, edge_weight, gather_dis=None):
+        return TracedNorm(edge_weight)
+
+
+class TracedNorm:
+    def __init__(self, edge_weight):
+        self.weight_ref = edge_weight
+
+
+def register(st, key=None):
+    """make `st` the answer of structure_of(st.edge_index, st.num_nodes) without a holder (the dispatcher ops receive the
+    raw tensors and look the structure up by identity)"""
+    if getattr(st, "traced", False):
+        return
+    if key is None:
+        ei = st._key_tensor
+        key = (ei.data_ptr(), ei._version, tuple(ei.shape), int(st.num_nodes), ei.device.index)
+    if _CACHE.get(key) is not st:
+        if len(_CACHE) >= _CACHE_MAX:
+            _CACHE.pop(next(iter(_CACHE)))
+        _CACHE[key] = st
 
 
 def clear_cache():

@@ -8,7 +8,11 @@ from conftest import random_graph
 from oracle import gcn_oracle as go
 
 OPS = ["csr_from_coo", "gcn_norm", "spmm", "propagate", "edge_gather_concat", "segment_sum_rows", "segment_max_rows",
-       "segment_max_bwd"]
+       "segment_max_bwd",
+       # the per-step operators of the train step (torch_ops.py, round 3)
+       "linear", "linear_backward", "gcn_propagate", "gcn_propagate_backward", "embed_conv_in", "embed_conv_in_backward",
+       "embed_propagate", "embed_propagate_backward", "decoder_loss", "decoder_mlp", "decoder_mlp_backward",
+       "bce_with_logits"]
 
 
 def test_ops_are_registered_with_schemas():
@@ -38,11 +42,65 @@ def test_fake_kernels_trace_without_a_gpu():
         assert mx.shape == (20, 8) and arg.dtype == torch.int32
 
 
+def test_step_operators_trace_with_fake_tensors():
+    """forward and backward ops of the train step: shapes / dtypes from the fake kernels alone (what torch.compile and
+    FakeTensor tracing see); no GPU, no launch"""
+    import pangnn_amd  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    ops = torch.ops.pangnn
+    with FakeTensorMode():
+        dev, n, e = "cuda", 20, 50
+        f = lambda *s: torch.empty(*s, device=dev)                     # noqa: E731
+        ei = torch.empty(2, e, dtype=torch.int64, device=dev)
+        x, w, b = f(n, 64), f(128, 64), f(128)
+        y = ops.linear(x, w, b, 1, True)
+        assert y.shape == (n, 128) and y.dtype == torch.bfloat16
+        gx, gw, gb = ops.linear_backward(y, x, w, 1, True, True)
+        assert gx.shape == x.shape and gw.shape == w.shape and gb.shape == b.shape
+        assert ops.linear_backward(y, x, w, 0, False, False)[0].numel() == 0
+        z = ops.gcn_propagate(x.to(torch.bfloat16), b[:64], ei, f(e), True)
+        assert z.shape == (n, 64) and z.dtype == torch.float32
+        gz, gbias = ops.gcn_propagate_backward(z, ei, None, True, True, True)
+        assert gz.dtype == torch.bfloat16 and gbias.shape == (64,)
+        xt, ew, eb = f(n, 1), f(64, 1), f(64)
+        h = ops.embed_conv_in(xt, ew, eb, w, b, ei, None, False)
+        assert h.shape == (n, 128) and h.dtype == torch.float32
+        assert [tuple(t.shape) for t in ops.embed_conv_in_backward(h, xt, ew, eb, w, ei, None, True)] == \
+            [(64, 1), (64,), (128, 64), (128,)]
+        a = ops.embed_propagate(xt, ew, eb, ei, None)
+        assert a.shape == (n, 64)
+        assert [tuple(t.shape) for t in ops.embed_propagate_backward(a, xt, ei, None)] == [(64, 1), (64,)]
+        pq, w2, b2, w3, b3, cv = f(n, 128), f(64, 64), f(64), f(64), f(1), f(64)
+        out = ops.decoder_loss(pq, ei, f(e), cv, w2, b2, w3, b3, f(e), f(1), e)
+        assert [tuple(t.shape) for t in out] == [(), (e,), (n, 128), (64,), (64, 64), (64,), (64,), (1,)]
+        assert ops.decoder_loss(pq, ei, None, None, w2, b2, w3, b3, f(e), None, e)[3].numel() == 0
+        lg = ops.decoder_mlp(pq.to(torch.bfloat16), ei, None, None, w2, b2, w3, b3)
+        assert lg.shape == (e,) and lg.dtype == torch.float32
+        assert [tuple(t.shape) for t in ops.decoder_mlp_backward(lg, pq, ei, f(e), cv, w2, b2, w3, b3)] == \
+            [(n, 128), (64,), (64, 64), (64,), (64,), (1,)]
+        loss, g = ops.bce_with_logits(lg, f(e), None, e)
+        assert loss.shape == () and g.shape == (e,)
+
+
+def test_dispatcher_is_the_default_route():
+    from pangnn_amd import functional as PF
+    import os
+    assert PF.USE_DISPATCHER_OPS == (os.environ.get("PANGNN_DISPATCHER_OPS", "1") == "1")
+    assert PF._via_ops() == PF.USE_DISPATCHER_OPS
+
+
 def test_ops_refuse_cpu_tensors():
     import pangnn_amd  # noqa: F401
     ei = torch.tensor([[0, 1], [1, 0]])
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops.pangnn.csr_from_coo(ei, 2, 1)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.pangnn.linear(torch.randn(4, 64), torch.randn(64, 64), None, 0, False)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.pangnn.gcn_propagate(torch.randn(3, 64), None, torch.tensor([[0, 1], [1, 2]]), None, True)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.pangnn.decoder_mlp(torch.randn(3, 128), torch.tensor([[0, 1], [1, 2]]), None, None, torch.randn(64, 64),
+                                     torch.randn(64), torch.randn(64), torch.randn(1))
 
 
 @pytest.mark.gpu
@@ -147,27 +205,161 @@ def test_autocast_policy_and_compile():
     assert torch.allclose(out, fn(x)) and torch.allclose(xc.grad, xe.grad)
 
 
-@pytest.mark.gpu
-def test_model_through_dispatcher_ops_is_bit_identical():
+MODEL_CASES = {
+    "default": dict(),
+    "skip": dict(skip_connections=True),
+    "union": dict(union_edge_weights=True, neighbours=3),
+    "base": dict(base_model=True),
+    "layerwise": dict(_fuse=False),
+    "round2_first_layer": dict(_fuse="propagate"),
+    "wide": dict(_dims=[64, 128], skip_connections=True),
+    "bf16": dict(_dims=[64, 128], _autocast=True),
+    "infer_decoder": dict(_fused_decoder_only=True),
+}
+
+
+def _model_and_graph(case, dev):
     import pangnn_amd
-    from pangnn_amd import functional as PF
     from conftest import copy_graph, whole_graph_from_golden
-    dev = torch.device("cuda:0")
+    kw = dict(MODEL_CASES[case])
+    fuse, dims = kw.pop("_fuse", True), kw.pop("_dims", [64, 64])
+    autocast, via_forward = kw.pop("_autocast", False), kw.pop("_fused_decoder_only", False)
     g = copy_graph(whole_graph_from_golden("cfg2_sim_1000x5"), dev)
+    if kw.get("union_edge_weights"):
+        g.edge_attr = g.union_edge_attr       # dataset.py:380: Data(x, ei, union_edge_weights, y)
     torch.manual_seed(0)
-    model = pangnn_amd.AlternateGCN(dev, None, False, dims=[64, 64], fuse_embedding=False)
+    model = pangnn_amd.AlternateGCN(dev, None, False, dims=dims, fuse_embedding=fuse, **kw)
     pw = (g.y == 0).sum() / g.y.sum()
+    return model, g, pw, autocast, via_forward
+
+
+def _one_step(model, g, pw, autocast, via_forward, fn=None):
+    from pangnn_amd.train import criterion
+    model.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        if via_forward:                                   # forward() + criterion: decoder_mlp / bce ops and their backward
+            logits = model(g)
+            loss = criterion(logits, g.y, pw)
+        else:
+            loss, logits = (fn or model.loss_and_logits)(g, g.y, pw)
+    loss.backward()
+    return (loss.detach().clone(), logits.detach().clone(),
+            {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+
+
+def _assert_same_step(a, b):
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[2].keys() == b[2].keys() and len(a[2]) >= 8
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(MODEL_CASES))
+def test_model_through_dispatcher_ops_is_bit_identical(case):
+    """the default route (torch.ops.pangnn.* for every per-step operator) against the ctypes autograd.Functions: the
+    same kernels behind both, so loss, logits and every parameter gradient agree bit for bit"""
+    from pangnn_amd import functional as PF
+    dev = torch.device("cuda:0")
+    model, g, pw, autocast, via_forward = _model_and_graph(case, dev)
     outs = []
     for flag in (False, True):
         old, PF.USE_DISPATCHER_OPS = PF.USE_DISPATCHER_OPS, flag
         try:
-            model.zero_grad()
-            loss, logits = model.loss_and_logits(g, g.y, pw)
-            loss.backward()
-            outs.append((loss.detach().clone(), logits.clone(), [p.grad.clone() for p in model.parameters()
-                                                                 if p.grad is not None]))
+            outs.append(_one_step(model, g, pw, autocast, via_forward))
         finally:
             PF.USE_DISPATCHER_OPS = old
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    for a, b in zip(outs[0][2], outs[1][2]):
-        assert torch.equal(a, b)
+    _assert_same_step(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_the_dispatcher_route_is_what_runs_by_default():
+    """every per-step operator of a default train step is a torch.ops.pangnn.* call (seen by a TorchDispatchMode)"""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    dev = torch.device("cuda:0")
+    model, g, pw, *_ = _model_and_graph("default", dev)
+    seen = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            if func.namespace == "pangnn":
+                seen.append(func._schema.name.split("::")[1])
+            return func(*args, **(kwargs or {}))
+
+    with Spy():
+        loss, _ = model.loss_and_logits(g, g.y, pw)
+        loss.backward()
+    for name in ("embed_conv_in", "gcn_propagate", "linear", "decoder_loss", "embed_conv_in_backward",
+                 "gcn_propagate_backward", "linear_backward"):
+        assert name in seen, (name, seen)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["default", "skip", "union", "bf16", "infer_decoder"])
+def test_compiled_step_is_one_graph_and_bit_identical(case):
+    """torch.compile(backend="aot_eager", fullgraph=True) of the model's loss_and_logits (forward()+criterion for the
+    inference decoder): dynamo traces the whole forward into ONE graph of torch.ops.pangnn.* calls, AOTAutograd derives the
+    backward graph from the registered formulas (backward ops are registered ops too), and the compiled step returns what
+    the eager step returns, bit for bit."""
+    from pangnn_amd.train import criterion
+    dev = torch.device("cuda:0")
+    model, g, pw, autocast, via_forward = _model_and_graph(case, dev)
+    eager = _one_step(model, g, pw, autocast, via_forward)
+    graphs = []
+
+    def backend(gm, example_inputs):
+        from torch._dynamo.backends.debugging import aot_eager
+        graphs.append([n.target for n in gm.graph.nodes if n.op == "call_function"])
+        return aot_eager(gm, example_inputs)
+
+    torch._dynamo.reset()
+    if via_forward:
+        def step(graph, y, w):
+            return criterion(model(graph), y, w), None
+        compiled = torch.compile(step, backend=backend, fullgraph=True)
+        model.zero_grad()
+        loss, _ = compiled(g, g.y, pw)
+        loss.backward()
+        assert torch.equal(loss.detach(), eager[0])
+        grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        assert grads.keys() == eager[2].keys()
+        for k in grads:
+            assert torch.equal(grads[k], eager[2][k]), k
+    else:
+        compiled = torch.compile(model.loss_and_logits, backend=backend, fullgraph=True)
+        _assert_same_step(eager, _one_step(model, g, pw, autocast, False, fn=compiled))
+    assert len(graphs) == 1, f"{len(graphs)} graphs"
+    names = {str(t) for t in graphs[0]}
+    assert any("pangnn" in t for t in names), names
+    torch._dynamo.reset()
+
+
+@pytest.mark.gpu
+def test_opcheck_of_the_step_operators():
+    """torch.library.opcheck: schema (no undeclared mutation / aliasing), fake kernel against the real one, autograd
+    registration, and AOT dispatch of each forward op on real operands"""
+    from pangnn_amd.graph import structure_of
+    dev = torch.device("cuda:0")
+    n, e = 300, 2400
+    ei, w = random_graph(n, e, seed=2)
+    ei, w = ei.to(dev), w.to(dev)
+    structure_of(ei, n)
+    torch.manual_seed(1)
+    r = lambda *s: torch.randn(*s, device=dev)                         # noqa: E731
+    p = lambda *s: (torch.randn(*s, device=dev) * 0.2).requires_grad_(True)   # noqa: E731
+    ops = torch.ops.pangnn
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_static")
+    y = (torch.rand(e, device=dev) < 0.3).float()
+    cases = [
+        (ops.linear, (p(n, 64), p(128, 64), p(128), 1, False)),
+        (ops.linear, (r(n, 128).to(torch.bfloat16), p(64, 128), None, 0, True)),
+        (ops.gcn_propagate, (p(n, 64), p(64), ei, w, True)),
+        (ops.gcn_propagate, (p(n, 128), None, ei, None, False)),
+        (ops.embed_conv_in, (r(n, 1), p(64, 1), p(64), p(128, 64), p(128), ei, w, False)),
+        (ops.embed_propagate, (r(n, 1), p(64, 1), p(64), ei, w)),
+        (ops.decoder_mlp, (p(n, 128), ei, w, p(64), p(64, 64), p(64), p(64), p(1))),
+        (ops.decoder_loss, (p(n, 128), ei, None, None, p(64, 64), p(64), p(64), p(1), y, None, e)),
+        (ops.bce_with_logits, (p(e), y, r(1).abs(), e)),
+    ]
+    for op, args in cases:
+        torch.library.opcheck(op, args, test_utils=tests)
