@@ -61,6 +61,32 @@ int    pangnn_csr_build(const int64_t* edge_index, int64_t ld, int64_t num_edges
  * (non-zero = some node id was outside [0, N) and was clamped).  Read it after synchronising. */
 const void* pangnn_csr_build_flag_ptr(void* workspace, int64_t num_edges);
 
+/* Small graphs — one mini-batch of sub-graphs (reference regime: DataLoader batches of 32 sub-graphs, pangnn.py:152-216,
+ * collated by PyG's Batch): BOTH CSR orders of pangnn_csr_build (same stable order: identical rowptr / other / perm) and,
+ * for each order, the int32 sorted keys and the run-sum plan over chunks of `chunk_edges` consecutive sorted positions
+ * (the `part_off` / part row pointers the decoder's S / T kernels take, chunk_edges = 32 * pangnn_decoder_chunk_tiles()),
+ * in ONE launch.  part_off_*[ceil(E / chunk_edges)], part_rowptr_*[N+1], last_part_*[1] = number of parts - 1.
+ * bad_flag[0] (device) = 1 if a node id was outside [0, N) (clamped).  Limits: pangnn_structure_small_supported(E, N). */
+int pangnn_structure_small_supported(int64_t num_edges, int64_t num_nodes);
+int pangnn_structure_small(const int64_t* edge_index, int64_t ld, int64_t num_edges, int64_t num_nodes,
+                           int32_t chunk_edges, int64_t* rowptr_dst, int32_t* other_dst, int32_t* perm_dst,
+                           int32_t* keys_dst, int32_t* part_off_dst, int64_t* part_rowptr_dst, int64_t* last_part_dst,
+                           int64_t* rowptr_src, int32_t* other_src, int32_t* perm_src, int32_t* keys_src,
+                           int32_t* part_off_src, int64_t* part_rowptr_src, int64_t* last_part_src, int32_t* bad_flag,
+                           pangnn_stream_t stream);
+
+/* Collation of one mini-batch out of a flat sub-graph storage (the reference's DataLoader(batch_size=32) + PyG
+ * Batch.from_data_list, pangnn.py:152-216; pangnn_amd/subgraphs.py): the batch is sub-graphs [i0, i0 + num_graphs), i.e.
+ * nodes [n0, n0 + num_nodes), similarity edges [e0, e0 + num_edges) of edge_index[2][ld_e] and neighbour edges
+ * [b0, b0 + num_nb) of nb_index[2][ld_b]; node_off points at entry i0 of the node offset table.  One launch writes the
+ * batch-local lists out_edge_index[2][num_edges], out_nb_index[2][num_nb] (ids - n0), out_ptr[num_graphs + 1],
+ * out_batch[num_nodes] (graph id of every node) and out_x[num_nodes] = 1 (the reference's node feature, dataset.py:369). */
+int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e, int64_t e0, int64_t num_edges,
+                             const int64_t* nb_index, int64_t ld_b, int64_t b0, int64_t num_nb,
+                             const int64_t* node_off, int32_t num_graphs, int64_t n0, int64_t num_nodes,
+                             int64_t* out_edge_index, int64_t* out_nb_index, int64_t* out_ptr, int64_t* out_batch,
+                             float* out_x, pangnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * gcn_norm (k1-k3; PyG gcn_norm as called by GCNConv.forward, src/gnn.py:158):
  *   deg[i]  = sum over in-edges of w        (w = 1 when edge_weight == NULL, src/gnn.py:165)

@@ -23,6 +23,10 @@ SIGNATURES = {
     "pangnn_csr_build_workspace_bytes": (_sz, [_i64, _i64]),
     "pangnn_csr_build": (C.c_int, [_p, _i64, _i64, _i64, C.c_int, _p, _p, _p, _p, _sz, _p]),
     "pangnn_csr_build_flag_ptr": (_p, [_p, _i64]),
+    "pangnn_structure_small_supported": (C.c_int, [_i64, _i64]),
+    "pangnn_structure_small": (C.c_int, [_p, _i64, _i64, _i64, _i32] + [_p] * 15 + [_p]),
+    "pangnn_collate_subgraphs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i32, _i64, _i64,
+                                           _p, _p, _p, _p, _p, _p]),
     "pangnn_gcn_norm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "pangnn_gcn_degree_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p]),
     "pangnn_gcn_edge_norm_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p]),
@@ -124,9 +128,34 @@ def check(rc: int, what: str = ""):
         raise PangnnHipError(f"{what or 'pangnn_hip'} failed (rc={rc}): {msg}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr() -> int:
-    """hipStream_t of torch's current stream on the current device."""
+    """hipStream_t of torch's current stream on the current device (the raw handle: `torch.cuda.current_stream()` builds a
+    Stream object per call, ~10 us — a tenth of a launch-bound mini-batch step's host time)."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(dev):
+    """`with torch.cuda.device(dev)` that costs nothing when `dev` already is the current device (the usual case)"""
+    if _cur_device is not None and dev.index is not None and dev.index == _cur_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def ptr(t):

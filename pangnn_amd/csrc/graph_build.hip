@@ -144,3 +144,248 @@ extern "C" const void* pangnn_csr_build_flag_ptr(void* workspace, int64_t num_ed
   if (!workspace || num_edges <= 0) return nullptr;
   return static_cast<char*>(workspace) + 3 * align_up((size_t)num_edges * 4, 256);
 }
+
+// ==============================================================================================================
+// Small graphs (a mini-batch of sub-graphs, reference regime pangnn.py:152-216): BOTH CSR orders of one edge list and
+// the run-sum plans of both orders in ONE launch — workgroup 0 groups by target, workgroup 1 by source.  A fresh batch per
+// step otherwise costs ~10 launches per CSR order (radix sort passes) and ~18 small index launches per plan, all
+// launch-bound at these sizes.
+//
+// Per workgroup: (key << ib | edge id) composites of the E edges in LDS, padded to a power of two with 0xFFFFFFFF, bitonic
+// sort (unique composites, so the result IS the stable sort by key: inside a row the edges keep ascending original id —
+// the same perm / other / rowptr as pangnn_csr_build's stable radix sort), then one thread-contiguous walk over the
+// sorted list that writes perm, other, the int32 keys, rowptr, and the chunk plan of that order
+// (EdgeStructure._plan_of_sorted_keys: a part starts at every chunk start and at every key change):
+//   part_off[c]     part id of the first edge of chunk c (chunk = chunk_edges consecutive sorted positions)
+//   part_rowptr[r]  first part of row r  (= part id at rowptr[r]; total parts for rows behind the last edge)
+//   last_part[0]    part id of the last edge (parts - 1)
+// Limits: 1 <= E <= kSmallMaxEdges, N <= kSmallMaxNodes (composites stay below the pad value).
+// ==============================================================================================================
+namespace pangnn {
+
+constexpr int kSmallMaxEdges = 16384;
+constexpr int kSmallMaxNodes = 65536;
+constexpr int kSmallThreads = 1024;
+
+struct SmallOrder {
+  int64_t* rowptr;       // [N+1]
+  int32_t* other;        // [E]
+  int32_t* perm;         // [E]
+  int32_t* keys;         // [E]
+  int32_t* part_off;     // [ceil(E / chunk_edges)]
+  int64_t* part_rowptr;  // [N+1]
+  int64_t* last_part;    // [1]
+};
+
+__global__ __launch_bounds__(kSmallThreads) void small_structure_kernel(const int64_t* __restrict__ edge_index, int64_t ld,
+                                                                        int e, int n, int epad, int ib, int chunk_edges,
+                                                                        SmallOrder by_dst, SmallOrder by_src,
+                                                                        int* __restrict__ bad) {
+  __shared__ uint32_t comp[kSmallMaxEdges];
+  __shared__ int wave_tot[kSmallThreads / 64];
+  const int tid = threadIdx.x;
+  const bool dst_order = blockIdx.x == 0;
+  const SmallOrder o = dst_order ? by_dst : by_src;
+  const int64_t* key_row = edge_index + (dst_order ? ld : 0);
+  const int64_t* other_row = edge_index + (dst_order ? 0 : ld);
+
+  for (int i = tid; i < epad; i += kSmallThreads) {
+    uint32_t c = 0xFFFFFFFFu;
+    if (i < e) {
+      int64_t k = key_row[i];
+      if (k < 0 || k >= n) { *bad = 1; k = k < 0 ? 0 : n - 1; }     // clamp: never a wild row
+      c = ((uint32_t)k << ib) | (uint32_t)i;
+    }
+    comp[i] = c;
+  }
+  __syncthreads();
+  // already in order (a source-sorted list grouped by source, the usual case of a collated batch)?  then no sort
+  int unsorted = 0;
+  for (int i = tid + 1; i < epad; i += kSmallThreads) unsorted |= comp[i - 1] > comp[i];
+  if (__syncthreads_or(unsorted)) {
+    for (int k = 2; k <= epad; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        // pair index t -> elements (lo, lo | j).  A wave's 64 consecutive pair indices touch one aligned block of 128
+        // elements, and for j < 128 both elements of every pair stay inside that block: those stages need no workgroup
+        // barrier, only the in-order LDS pipe of the wave itself.
+        for (int t = tid; t < (epad >> 1); t += kSmallThreads) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const uint32_t a = comp[lo], b = comp[hi];
+          const bool up = (lo & k) == 0;
+          if ((a > b) == up) { comp[lo] = b; comp[hi] = a; }
+        }
+        if (j >= 128 || j == 1) {
+          __syncthreads();           // (j == 1: the next k starts with a wide stride)
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+
+  // Walk over the sorted list: wave w owns the contiguous range [w * seg, (w + 1) * seg), 64 consecutive positions per
+  // round (LDS reads without bank conflicts, coalesced stores).  A part starts at every chunk start and every key change;
+  // part id = (number of part starts up to and including the position) - 1.
+  const int lane = tid & 63, wv = tid >> 6;
+  constexpr int kWaves = kSmallThreads / 64;
+  const int seg = ((epad + kWaves - 1) / kWaves + 63) & ~63;
+  const int w0 = wv * seg < e ? wv * seg : e;
+  const int w1 = (wv + 1) * seg < e ? (wv + 1) * seg : e;
+  const uint32_t idmask = (1u << ib) - 1u;
+  int cnt = 0;
+  for (int r0 = w0; r0 < w1; r0 += 64) {
+    const int i = r0 + lane;
+    bool start = false;
+    if (i < w1) {
+      const int key = (int)(comp[i] >> ib);
+      const int prev = i == 0 ? -1 : (int)(comp[i - 1] >> ib);
+      start = (i % chunk_edges == 0) || key != prev;
+    }
+    cnt += __popcll(__ballot(start));
+  }
+  if (lane == 0) wave_tot[wv] = cnt;
+  __syncthreads();
+  int running = 0, total = 0;
+  for (int w = 0; w < kWaves; ++w) {
+    const int v = wave_tot[w];
+    if (w < wv) running += v;
+    total += v;
+  }
+  for (int r0 = w0; r0 < w1; r0 += 64) {
+    const int i = r0 + lane;
+    bool start = false;
+    int key = 0, prev = 0, idx = 0;
+    if (i < w1) {
+      const uint32_t c = comp[i];
+      key = (int)(c >> ib);
+      idx = (int)(c & idmask);
+      prev = i == 0 ? -1 : (int)(comp[i - 1] >> ib);
+      start = (i % chunk_edges == 0) || key != prev;
+    }
+    const unsigned long long m = __ballot(start);
+    if (i < w1) {
+      const int id = running + __popcll(m & (~0ull >> (63 - lane))) - 1;
+      if (i % chunk_edges == 0) o.part_off[i / chunk_edges] = id;
+      for (int r = prev + 1; r <= key; ++r) {       // rows whose first edge is here (empty rows in between included)
+        o.rowptr[r] = i;
+        o.part_rowptr[r] = id;
+      }
+      o.perm[i] = idx;
+      o.keys[i] = key;
+      int64_t v = other_row[idx];
+      if (v < 0 || v >= n) { *bad = 1; v = v < 0 ? 0 : n - 1; }
+      o.other[i] = (int32_t)v;
+    }
+    running += __popcll(m);
+  }
+  // rows behind the last edge (all threads)
+  const int last_key = (int)(comp[e - 1] >> ib);
+  for (int r = last_key + 1 + tid; r <= n; r += kSmallThreads) {
+    o.rowptr[r] = e;
+    o.part_rowptr[r] = total;
+  }
+  if (tid == 0) o.last_part[0] = total - 1;
+}
+
+}  // namespace pangnn
+
+extern "C" int pangnn_structure_small_supported(int64_t num_edges, int64_t num_nodes) {
+  return num_edges >= 1 && num_edges <= kSmallMaxEdges && num_nodes >= 1 && num_nodes <= kSmallMaxNodes;
+}
+
+extern "C" int pangnn_structure_small(const int64_t* edge_index, int64_t ld, int64_t num_edges, int64_t num_nodes,
+                                      int32_t chunk_edges, int64_t* rowptr_dst, int32_t* other_dst, int32_t* perm_dst,
+                                      int32_t* keys_dst, int32_t* part_off_dst, int64_t* part_rowptr_dst,
+                                      int64_t* last_part_dst, int64_t* rowptr_src, int32_t* other_src, int32_t* perm_src,
+                                      int32_t* keys_src, int32_t* part_off_src, int64_t* part_rowptr_src,
+                                      int64_t* last_part_src, int32_t* bad_flag, pangnn_stream_t stream) {
+  PG_CHECK_ARG(pangnn_structure_small_supported(num_edges, num_nodes) && ld >= num_edges, PANGNN_E_BADARG,
+               "pangnn_structure_small: needs 1 <= E <= %d, 1 <= N <= %d (got E=%lld N=%lld ld=%lld)", kSmallMaxEdges,
+               kSmallMaxNodes, (long long)num_edges, (long long)num_nodes, (long long)ld);
+  PG_CHECK_ARG(chunk_edges >= 32 && chunk_edges % 32 == 0, PANGNN_E_BADARG,
+               "pangnn_structure_small: chunk_edges must be a positive multiple of 32 (got %d)", (int)chunk_edges);
+  PG_CHECK_ARG(edge_index && rowptr_dst && other_dst && perm_dst && keys_dst && part_off_dst && part_rowptr_dst &&
+                   last_part_dst && rowptr_src && other_src && perm_src && keys_src && part_off_src && part_rowptr_src &&
+                   last_part_src && bad_flag,
+               PANGNN_E_BADARG, "pangnn_structure_small: null pointer");
+  int epad = 2, ib = 1;
+  while (epad < num_edges) { epad <<= 1; ++ib; }
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipMemsetAsync(bad_flag, 0, sizeof(int32_t), s);
+  PG_CHECK_ARG(err == hipSuccess, (int)err, "pangnn_structure_small: memset failed: %s", hipGetErrorString(err));
+  SmallOrder d{rowptr_dst, other_dst, perm_dst, keys_dst, part_off_dst, part_rowptr_dst, last_part_dst};
+  SmallOrder r{rowptr_src, other_src, perm_src, keys_src, part_off_src, part_rowptr_src, last_part_src};
+  hipLaunchKernelGGL(small_structure_kernel, dim3(2), dim3(kSmallThreads), 0, s, edge_index, ld, (int)num_edges,
+                     (int)num_nodes, epad, ib, (int)chunk_edges, d, r, reinterpret_cast<int*>(bad_flag));
+  PG_CHECK_LAUNCH("pangnn_structure_small");
+  return 0;
+}
+
+// ==============================================================================================================
+// Collation of a mini-batch out of the flat sub-graph storage (pangnn_amd/subgraphs.py; the reference's DataLoader +
+// PyG Batch.from_data_list, pangnn.py:152-216): sub-graphs [i0, i0 + g) occupy the node range [n0, n0 + n), the
+// similarity-edge range [e0, e0 + e) and the neighbour-edge range [b0, b0 + b) of the flat lists.  One launch writes the
+// batch-local edge lists (ids shifted by -n0), the graph pointer, every node's graph id and the unit node feature.
+// ==============================================================================================================
+namespace pangnn {
+
+__global__ __launch_bounds__(kBlock) void collate_kernel(const int64_t* __restrict__ ei, int64_t ld_e, int64_t e0, int64_t e,
+                                                         const int64_t* __restrict__ nb, int64_t ld_b, int64_t b0, int64_t b,
+                                                         const int64_t* __restrict__ node_off, int g, int64_t n0, int64_t n,
+                                                         int64_t* __restrict__ out_ei, int64_t* __restrict__ out_nb,
+                                                         int64_t* __restrict__ ptr, int64_t* __restrict__ batch,
+                                                         float* __restrict__ x) {
+  const int64_t total = 2 * e + 2 * b + (g + 1) + n;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int64_t k = i;
+    if (k < 2 * e) {
+      const int64_t row = k >= e, col = k - row * e;
+      out_ei[k] = ei[row * ld_e + e0 + col] - n0;
+      continue;
+    }
+    k -= 2 * e;
+    if (k < 2 * b) {
+      const int64_t row = k >= b, col = k - row * b;
+      out_nb[k] = nb[row * ld_b + b0 + col] - n0;
+      continue;
+    }
+    k -= 2 * b;
+    if (k <= g) {
+      ptr[k] = node_off[k] - n0;
+      continue;
+    }
+    k -= g + 1;
+    // graph of node k: number of graph ends <= k  (torch.searchsorted(ptr[1:], k, right=True))
+    int lo = 0, hi = g;
+    const int64_t key = k + n0;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (node_off[mid + 1] <= key) lo = mid + 1; else hi = mid;
+    }
+    batch[k] = lo;
+    x[k] = 1.0f;
+  }
+}
+
+}  // namespace pangnn
+
+extern "C" int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e, int64_t e0, int64_t num_edges,
+                                        const int64_t* nb_index, int64_t ld_b, int64_t b0, int64_t num_nb,
+                                        const int64_t* node_off, int32_t num_graphs, int64_t n0, int64_t num_nodes,
+                                        int64_t* out_edge_index, int64_t* out_nb_index, int64_t* out_ptr,
+                                        int64_t* out_batch, float* out_x, pangnn_stream_t stream) {
+  PG_CHECK_ARG(num_edges >= 0 && num_nb >= 0 && num_nodes >= 0 && num_graphs >= 0 && e0 >= 0 && b0 >= 0 &&
+                   ld_e >= e0 + num_edges && ld_b >= b0 + num_nb,
+               PANGNN_E_BADARG, "pangnn_collate_subgraphs: bad range");
+  PG_CHECK_ARG(node_off && out_ptr && (num_edges == 0 || (edge_index && out_edge_index)) &&
+                   (num_nb == 0 || (nb_index && out_nb_index)) && (num_nodes == 0 || (out_batch && out_x)),
+               PANGNN_E_BADARG, "pangnn_collate_subgraphs: null pointer");
+  const int64_t total = 2 * num_edges + 2 * num_nb + (num_graphs + 1) + num_nodes;
+  hipLaunchKernelGGL(collate_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, edge_index, ld_e, e0,
+                     num_edges, nb_index, ld_b, b0, num_nb, node_off, (int)num_graphs, n0, num_nodes, out_edge_index,
+                     out_nb_index, out_ptr, out_batch, out_x);
+  PG_CHECK_LAUNCH("pangnn_collate_subgraphs");
+  return 0;
+}

@@ -10,12 +10,18 @@ GPU (stable radix sort => deterministic per-row order) and memoises the GCN norm
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 import torch
 
 from . import _lib
+
+
+# mini-batch sized square structures are built by one launch (EdgeStructure._small_build); False: always the general
+# radix-sort build + index-op plans (what the parity tests compare the small build with)
+SMALL_STRUCTURE = os.environ.get("PANGNN_SMALL_STRUCTURE", "1") != "0"
 
 
 @dataclass
@@ -40,7 +46,7 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, group_by: int, validate:
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=dev)
     other = torch.empty(e, dtype=torch.int32, device=dev)
     perm = torch.empty(e, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         ws_bytes = lib.pangnn_csr_build_workspace_bytes(e, num_nodes)
         if ws_bytes == 0:
             raise _lib.PangnnHipError("pangnn_csr_build_workspace_bytes failed")
@@ -80,9 +86,53 @@ class EdgeStructure:
         self._norm: Dict[Tuple, Tuple["GcnNorm", Optional[torch.Tensor]]] = {}
         self._runsum = None
         self._band: Optional[int] = None
+        self._small_built = False
+
+    def _small_build(self) -> bool:
+        """A small square structure (a mini-batch of sub-graphs): both CSR orders and the S / T kernels' chunk plans of both
+        orders from ONE launch (pangnn_structure_small) instead of ~10 launches per CSR order and ~18 per plan — the same
+        tables, entry for entry, as build_csr / _plan_of_sorted_keys (tests/test_hip_parity.py).  False: not applicable."""
+        if not SMALL_STRUCTURE or self._by_dst is not None or self._by_src is not None or self.num_src != self.num_nodes:
+            return False
+        lib = _lib.load()
+        e, n = self.num_edges, self.num_nodes
+        if not lib.pangnn_structure_small_supported(e, n):
+            return False
+        ct = int(lib.pangnn_decoder_chunk_tiles())
+        span = 32 * ct
+        nc = (e + span - 1) // span
+        dev = self.edge_index.device
+        ea, na, ca = -(-e // 4) * 4, -(-(n + 1) // 2) * 2, -(-nc // 4) * 4             # 16-byte aligned segments
+        i32 = torch.empty(2 * (3 * ea + ca) + 4, dtype=torch.int32, device=dev)
+        i64 = torch.empty(2 * (2 * na + 2), dtype=torch.int64, device=dev)
+        seg32 = [i32[k * ea:k * ea + e] for k in range(6)] + [i32[6 * ea + k * ca:6 * ea + k * ca + nc] for k in range(2)]
+        other_d, perm_d, keys_d, other_s, perm_s, keys_s, poff_d, poff_s = seg32
+        bad = i32[6 * ea + 2 * ca:6 * ea + 2 * ca + 1]
+        rp_d, prp_d, rp_s, prp_s = (i64[k * na:k * na + n + 1] for k in range(4))
+        last_d, last_s = i64[4 * na:4 * na + 1], i64[4 * na + 2:4 * na + 3]
+        with _lib.device_guard(dev):
+            _lib.check(lib.pangnn_structure_small(
+                self.edge_index.data_ptr(), e, e, n, span, rp_d.data_ptr(), other_d.data_ptr(), perm_d.data_ptr(),
+                keys_d.data_ptr(), poff_d.data_ptr(), prp_d.data_ptr(), last_d.data_ptr(), rp_s.data_ptr(),
+                other_s.data_ptr(), perm_s.data_ptr(), keys_s.data_ptr(), poff_s.data_ptr(), prp_s.data_ptr(),
+                last_s.data_ptr(), bad.data_ptr(), _lib.stream_ptr()), "pangnn_structure_small")
+            if not self.hints.get("valid_ids", False) and int(bad.item()) != 0:
+                raise ValueError(f"edge_index contains node ids outside [0, {n})")
+        self._by_dst, self._by_src = CSR(rp_d, other_d, perm_d), CSR(rp_s, other_s, perm_s)
+        self._small_built = True
+        from types import SimpleNamespace
+        n_bound = nc + min(n, e)
+        plans = self.__dict__.setdefault("_csr_plans", {})
+        for by, poff, prp, keys, last in (("dst", poff_d, prp_d, keys_d, last_d), ("src", poff_s, prp_s, keys_s, last_s)):
+            plan = SimpleNamespace(n_parts=n_bound, part_off=poff, part_rowptr=prp, keys=keys, chunk_tiles=ct, _last=last)
+            plan.n_parts_exact = (lambda pl: (lambda: int(pl._last) + 1))(plan)
+            plans[(by, ct)] = plan
+        return True
 
     @property
     def by_dst(self) -> CSR:
+        if self._by_dst is None and self._small_build():
+            return self._by_dst
         if self._by_dst is None:
             nmax = max(self.num_nodes, self.num_src)
             self._by_dst = build_csr(self.edge_index, nmax, 1, validate=not self.hints.get("valid_ids", False),
@@ -93,6 +143,8 @@ class EdgeStructure:
 
     @property
     def by_src(self) -> CSR:
+        if self._by_src is None and self._small_build():
+            return self._by_src
         if self._by_src is None:
             nmax = max(self.num_nodes, self.num_src)
             self._by_src = build_csr(self.edge_index, nmax, 0, validate=False, num_rows=self.num_src)
@@ -173,7 +225,12 @@ class EdgeStructure:
             return None
         ct = int(chunk_tiles)
         if ct not in self._runsum:
-            self._runsum[ct] = self._plan_of_sorted_keys(self.edge_index[0], self.num_src, ct)
+            # a source-sorted list IS its by-source order (stable sort of a sorted list): the small build's plan of that
+            # order is this plan
+            self._small_build()              # no-op unless applicable and nothing is built yet
+            small = self.__dict__.get("_csr_plans", {}).get(("src", ct)) if self._small_built else None
+            self._runsum[ct] = small if small is not None else \
+                self._plan_of_sorted_keys(self.edge_index[0], self.num_src, ct)
         return self._runsum[ct]
 
     def gcn_norm(self, edge_weight: Optional[torch.Tensor], gather_dis=None) -> "GcnNorm":
@@ -207,10 +264,14 @@ class GcnNorm:
                 raise ValueError(f"edge_weight must be [E>={e}], got {tuple(edge_weight.shape)}")
             edge_weight = edge_weight.detach().to(torch.float32).contiguous()
         d = st.by_dst
-        self.deg_inv_sqrt = torch.empty(n, dtype=torch.float32, device=dev)
-        self.by_dst = torch.empty(e, dtype=torch.float32, device=dev)    # CSR(dst) order
-        self.orig = torch.empty(e, dtype=torch.float32, device=dev)      # caller's edge order
-        with torch.cuda.device(dev):
+        ea, na = -(-e // 4) * 4, -(-n // 4) * 4                          # one allocation, 16-byte aligned segments
+        small = e <= (1 << 20)                  # small graphs: the by-source table too (a launch-bound step counts allocations)
+        buf = torch.empty(na + (3 if small else 2) * ea, dtype=torch.float32, device=dev)
+        self.deg_inv_sqrt = buf[:n]
+        self.by_dst = buf[na:na + e]                                     # CSR(dst) order
+        self.orig = buf[na + ea:na + ea + e]                             # caller's edge order
+        self._by_src_buf = buf[na + 2 * ea:na + 2 * ea + e] if small else None      # CSR(src) order, filled on first use
+        with _lib.device_guard(dev):
             if gather_dis is None:
                 if st.num_src != st.num_nodes:
                     raise ValueError("a rectangular structure needs gather_dis= for gcn_norm")
@@ -238,8 +299,8 @@ class GcnNorm:
         if self._by_src is None:
             st, lib = self._st, _lib.load()
             s = st.by_src
-            out = torch.empty_like(self.orig)
-            with torch.cuda.device(out.device):
+            out = self._by_src_buf if self._by_src_buf is not None else torch.empty_like(self.orig)
+            with _lib.device_guard(out.device):
                 _lib.check(lib.pangnn_permute_f32(_lib.ptr(self.orig), _lib.ptr(s.perm), _lib.ptr(out),
                                                   st.num_edges, _lib.stream_ptr()), "pangnn_permute_f32")
             self._by_src = out

@@ -176,6 +176,11 @@ def build_subgraphs(num_nodes: int, src, dst, weight, group_id: torch.Tensor, gr
         group_of_graph=torch.nonzero(keep_g).view(-1))
 
 
+# batches of a GPU-resident data set are collated by one HIP launch (pangnn_collate_subgraphs); False: the index ops
+# a CPU-resident data set always uses (what tests/test_construct.py compares the kernel with)
+COLLATE_KERNEL = True
+
+
 class SubGraphDataset:
     """Flat storage of all sub-graphs; `batch(i0, i1)` is the disjoint union of sub-graphs [i0, i1)."""
 
@@ -207,6 +212,25 @@ class SubGraphDataset:
         # what this producer knows about the batch (graph.EdgeStructure hints): ids are local and in range by
         # construction; a slice of a source-sorted flat list shifted by a constant is source-sorted
         hints = {"sim": {"valid_ids": True, "sorted_by_src": h.sorted_by_src}, "nb": {"valid_ids": True}}
+        if dev.type == "cuda" and COLLATE_KERNEL:
+            # one launch (pangnn_collate_subgraphs) instead of seven index ops: the step around it is launch-bound
+            from . import _lib
+            lib = _lib.load()
+            n, e, b, g = n1 - n0, e1 - e0, b1 - b0, i1 - i0
+            buf = torch.empty(2 * e + 2 * b + (g + 1) + n, dtype=torch.int64, device=dev)
+            x = torch.empty(n, 1, dtype=torch.float32, device=dev)
+            ei, nb = buf[:2 * e].view(2, e), buf[2 * e:2 * e + 2 * b].view(2, b)
+            ptr, bid = buf[2 * e + 2 * b:2 * e + 2 * b + g + 1], buf[2 * e + 2 * b + g + 1:]
+            src_ei, src_nb = self.edge_index, self.neighbour_edge_index
+            if not (src_ei.is_contiguous() and src_nb.is_contiguous() and self.node_off.is_contiguous()):
+                raise ValueError("SubGraphDataset tensors must be contiguous")
+            with _lib.device_guard(dev):
+                _lib.check(lib.pangnn_collate_subgraphs(
+                    src_ei.data_ptr(), src_ei.shape[1], e0, e, src_nb.data_ptr(), src_nb.shape[1], b0, b,
+                    self.node_off.data_ptr() + 8 * i0, g, n0, n, _lib.ptr(ei), _lib.ptr(nb), ptr.data_ptr(),
+                    _lib.ptr(bid), _lib.ptr(x), _lib.stream_ptr()), "pangnn_collate_subgraphs")
+            return SimpleNamespace(_pangnn_hints=hints, x=x, edge_index=ei, edge_attr=self.edge_attr[e0:e1],
+                                   y=self.y[e0:e1], neighbour_edge_index=nb, ptr=ptr, num_graphs=g, batch=bid)
         return SimpleNamespace(
             _pangnn_hints=hints,
             x=torch.ones(n1 - n0, 1, dtype=torch.float32, device=dev),

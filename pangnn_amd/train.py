@@ -14,13 +14,20 @@ def criterion(logits, labels, pos_weight):
     return PF.bce_with_logits(logits, labels, pos_weight)
 
 
-def make_optimizer(model, lr: float = 1e-3, capturable: bool = False):
-    return torch.optim.Adam(model.parameters(), lr=lr, capturable=capturable)      # pangnn.py:88
+def make_optimizer(model, lr: float = 1e-3, capturable: bool = False, fused: bool = True):
+    """torch.optim.Adam(lr) of pangnn.py:88.  `fused=True`: PyTorch's single-launch Adam over all parameter tensors
+    (the same update rule; ~8 launches fewer per step than the default foreach form, which is what a launch-bound
+    mini-batch step notices)."""
+    params = list(model.parameters())
+    fused = bool(fused) and all(p.is_cuda and p.dtype == torch.float32 for p in params)
+    return torch.optim.Adam(params, lr=lr, capturable=capturable, fused=fused)
 
 
 def train_step(model, optimizer, graph, labels, pos_weight):
     """One step; returns (loss, logits) as device tensors without synchronising."""
-    optimizer.zero_grad(set_to_none=True)
+    for group in optimizer.param_groups:              # optimizer.zero_grad(set_to_none=True) without its dynamo-disable
+        for p in group["params"]:                     # wrapper (~20 us of a launch-bound mini-batch step)
+            p.grad = None
     if hasattr(model, "loss_and_logits"):
         loss, out = model.loss_and_logits(graph, labels, pos_weight)                # fused forward + criterion
     else:

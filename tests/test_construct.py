@@ -158,6 +158,25 @@ def test_subgraph_batches_are_disjoint_unions(device):
     assert torch.equal(b.edge_index[:, e0:e0 + one.edge_index.shape[1]], one.edge_index + off)
 
 
+@pytest.mark.gpu
+def test_collation_kernel_equals_the_index_op_collation():
+    """pangnn_collate_subgraphs (one launch) against the torch index ops the CPU path uses: every field of the batch,
+    first / middle / last / single-graph / short final batches"""
+    ds = simulate.simulate_subgraph_dataset(300, 4, 0.3, 10, 2, seed=3, device="cuda")
+    n = len(ds)
+    for i0, i1 in [(0, 32), (5, 37), (n - 7, n + 20), (11, 12), (0, n)]:
+        a = ds.batch(i0, i1)
+        old, subgraphs.COLLATE_KERNEL = subgraphs.COLLATE_KERNEL, False
+        try:
+            b = ds.batch(i0, i1)
+        finally:
+            subgraphs.COLLATE_KERNEL = old
+        assert a.num_graphs == b.num_graphs and a._pangnn_hints == b._pangnn_hints
+        for f in ("x", "edge_index", "edge_attr", "y", "neighbour_edge_index", "ptr", "batch"):
+            x, y = getattr(a, f), getattr(b, f)
+            assert x.dtype == y.dtype and x.shape == y.shape and x.is_contiguous() and torch.equal(x, y), f
+
+
 # ---------------------------------------------------------------- simulator: distributional parity
 @pytest.mark.parametrize("device", DEVICES)
 def test_simulator_matches_reference_statistics(device):

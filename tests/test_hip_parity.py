@@ -49,6 +49,76 @@ def test_csr_build_rejects_out_of_range_ids():
         build_csr(ei, 5, 1)
 
 
+SMALL_CASES = [(1, 1, 0, False), (7, 1, 1, False), (2, 2, 2, True), (100, 31, 3, True), (100, 32, 4, False),
+               (100, 33, 5, True), (300, 511, 6, True), (300, 512, 7, False), (300, 513, 8, True), (2000, 4096, 9, True),
+               (5000, 4097, 10, False), (33, 5000, 11, True), (65536, 16384, 12, False), (65536, 16384, 13, True),
+               (40, 16384, 14, True), (60000, 9000, 15, True)]
+
+
+@pytest.mark.parametrize("n,e,seed,sort_src", SMALL_CASES)
+def test_small_structure_build_equals_the_general_build(n, e, seed, sort_src):
+    """pangnn_structure_small (one launch: both CSR orders + both chunk plans of a mini-batch sized list) against
+    pangnn_csr_build's radix sort and the index-op plan construction: every table, entry for entry — and against numpy's
+    stable argsort.  Edge counts around the 32-edge tile, the 512-edge chunk and the power-of-two padding; hubs; isolated
+    nodes at the end of the id range; source-sorted and unsorted lists."""
+    from pangnn_amd import graph as G
+    from pangnn_amd import functional as PF
+    ei, _ = random_graph(n, e, seed=seed, hub=min(e, 1500))
+    if sort_src:
+        ei = ei[:, torch.argsort(ei[0], stable=True)]
+    ei = ei.to(dev())
+    ct = PF.d16_chunk()
+    small = G.EdgeStructure(ei, n, hints={"sorted_by_src": sort_src})
+    assert small._small_build() and small._small_built
+    old, G.SMALL_STRUCTURE = G.SMALL_STRUCTURE, False
+    try:
+        gen = G.EdgeStructure(ei, n, hints={"sorted_by_src": sort_src})
+        assert not gen._small_build()
+        pairs = [(small.by_dst, gen.by_dst), (small.by_src, gen.by_src)]
+        plans = [(small.csr_plan("dst", ct), gen.csr_plan("dst", ct)), (small.csr_plan("src", ct), gen.csr_plan("src", ct))]
+        if sort_src:
+            plans.append((small.runsum_plan(ct), gen.runsum_plan(ct)))
+            assert small.runsum_plan(ct) is small.csr_plan("src", ct)
+        else:
+            assert small.runsum_plan(ct) is None and gen.runsum_plan(ct) is None
+        # a chunk size the small build does not emit goes through the general plan code on the small build's tables
+        plans.append((small.csr_plan("dst", 1), gen.csr_plan("dst", 1)))
+    finally:
+        G.SMALL_STRUCTURE = old
+    for a, b in pairs:
+        assert a.rowptr.dtype == b.rowptr.dtype and a.other.dtype == b.other.dtype and a.perm.dtype == b.perm.dtype
+        assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.other, b.other) and torch.equal(a.perm, b.perm)
+    for a, b in plans:
+        assert a.n_parts == b.n_parts and a.chunk_tiles == b.chunk_tiles
+        for f in ("part_off", "part_rowptr", "keys"):
+            x, y = getattr(a, f), getattr(b, f)
+            assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y), f
+        assert a.n_parts_exact() == b.n_parts_exact() <= a.n_parts
+    for group_by, csr in ((1, small.by_dst), (0, small.by_src)):
+        key = ei[group_by].cpu().numpy()
+        perm = np.argsort(key, kind="stable")
+        assert np.array_equal(csr.perm.cpu().numpy().astype(np.int64), perm)
+        assert np.array_equal(csr.rowptr.cpu().numpy(), np.searchsorted(key[perm], np.arange(n + 1), side="left"))
+
+
+def test_small_structure_build_limits_and_bad_ids():
+    from pangnn_amd import graph as G
+    from pangnn_amd import _lib
+    lib = _lib.load()
+    assert lib.pangnn_structure_small_supported(16384, 65536) and not lib.pangnn_structure_small_supported(16385, 10)
+    assert not lib.pangnn_structure_small_supported(10, 65537) and not lib.pangnn_structure_small_supported(0, 10)
+    ei, _ = random_graph(50, 20000, seed=1)
+    big = G.EdgeStructure(ei.to(dev()), 50)
+    assert not big._small_build() and big.by_dst.perm.shape[0] == 20000          # too many edges: the general build
+    bad = torch.tensor([[0, 1, 9], [1, 2, 0]], device=dev())
+    with pytest.raises(ValueError):
+        G.EdgeStructure(bad, 5).by_dst
+    with pytest.raises(ValueError):
+        G.EdgeStructure(torch.tensor([[0, 1, 2], [1, -2, 0]], device=dev()), 5).by_src
+    ok = G.EdgeStructure(torch.tensor([[0, 1, 4], [1, 2, 0]], device=dev()), 5)
+    assert ok.by_dst.rowptr.tolist() == [0, 1, 2, 3, 3, 3]
+
+
 # ---------------------------------------------------------------- gcn_norm
 @pytest.mark.parametrize("weighted", [True, False])
 def test_gcn_norm_matches_oracle(weighted):
