@@ -398,6 +398,25 @@ int    pangnn_embed_conv_in_grads(const void* g, int32_t g_dtype, int64_t ldg, c
                                   const float* w_emb, const float* b_emb, const float* w_in, int32_t D, int32_t H,
                                   float* g_w_emb, float* g_b_emb, float* g_w_in, float* g_b_in, void* workspace,
                                   size_t workspace_bytes, pangnn_stream_t stream);
+
+/* The same layer FUSED into the dense layer that follows it (GCNConv.lin of conv_out, gnn.py:164-166 / linear_out,
+ * gnn.py:147): y = ELU(h) W_out^T (+ bias_out) with the [n, H] rows h = r a^T + s c^T + b_in generated inside the kernels
+ * (8 bytes per row read instead of 4 H; the values are pangnn_embed_conv_in_rows', bit for bit).  Backward: dL/dW_out [M, H],
+ * dL/dbias_out [M] (nullable) and sums [3, H] = [r s 1]^T dL/dh — dL/dh itself is never written — which
+ * pangnn_embed_conv_in_grads_from_sums turns into the first layer's parameter gradients (as pangnn_embed_conv_in_grads
+ * does after its own column sums).  (H, M) as pangnn_linear_supported(H, M, 1); fp32 storage. */
+int    pangnn_embed_linear_supported(int32_t H, int32_t M);
+int    pangnn_embed_linear_fwd(const float* r, const float* s, int64_t n, const float* w_emb, const float* b_emb,
+                               const float* w_in, const float* b_in, int32_t D, int32_t H, const float* w_out,
+                               const float* bias_out, int32_t M, float* y, int64_t ldy, pangnn_stream_t stream);
+size_t pangnn_embed_linear_bwd_workspace_bytes(int32_t H, int32_t M);
+int    pangnn_embed_linear_bwd(const float* g, int64_t ldg, const float* r, const float* s, int64_t n, const float* w_emb,
+                               const float* b_emb, const float* w_in, const float* b_in, int32_t D, int32_t H,
+                               const float* w_out, int32_t M, float* g_w_out, float* g_b_out, float* sums, void* workspace,
+                               size_t workspace_bytes, pangnn_stream_t stream);
+int    pangnn_embed_conv_in_grads_from_sums(const float* sums, const float* w_emb, const float* b_emb, const float* w_in,
+                                            int32_t D, int32_t H, float* g_w_emb, float* g_b_emb, float* g_w_in,
+                                            float* g_b_in, pangnn_stream_t stream);
 int    pangnn_rank2_rows(const float* r, const float* s, const float* a, const float* c, const float* bias, void* out,
                          int32_t out_dtype, int64_t ldo, int64_t n, int32_t F, pangnn_stream_t stream);
 size_t pangnn_weighted_colsum3_workspace_bytes(int32_t F);

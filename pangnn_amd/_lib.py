@@ -27,6 +27,11 @@ SIGNATURES = {
     "pangnn_structure_small": (C.c_int, [_p, _i64, _i64, _i64, _i32] + [_p] * 15 + [_p]),
     "pangnn_collate_subgraphs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i32, _i64, _i64,
                                            _p, _p, _p, _p, _p, _p]),
+    "pangnn_embed_linear_supported": (C.c_int, [_i32, _i32]),
+    "pangnn_embed_linear_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _i32, _i32, _p, _p, _i32, _p, _i64, _p]),
+    "pangnn_embed_linear_bwd_workspace_bytes": (_sz, [_i32, _i32]),
+    "pangnn_embed_linear_bwd": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i32, _i32, _p, _i32, _p, _p, _p, _p, _sz, _p]),
+    "pangnn_embed_conv_in_grads_from_sums": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "pangnn_gcn_norm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "pangnn_gcn_degree_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p]),
     "pangnn_gcn_edge_norm_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p]),

@@ -120,9 +120,11 @@ class GCNConv(MessagePassing):
             nn.init.zeros_(self.bias)
 
     def forward(self, x, edge_index, edge_weight: Optional[torch.Tensor] = None, graph=None, name: str = "",
-                in_elu: bool = False):
+                in_elu: bool = False, dense_done: bool = False):
         """`in_elu=True`: `x` is the pre-activation of an ELU (alpha 1) the caller deferred — the layer computes
-        conv(ELU(x)); when its dense part comes first the activation is folded into that kernel."""
+        conv(ELU(x)); when its dense part comes first the activation is folded into that kernel.
+        `dense_done=True`: `x` already is `self.lin(...)` of the layer's input (the caller fused this layer's dense part into
+        the producer of its input, functional._EmbedConvInLinear) — propagate and bias are what is left."""
         _lib.require_device(x, edge_index, edge_weight)
         st = edge_index if isinstance(edge_index, EdgeStructure) else \
             structure_of(edge_index, x.shape[0], holder=graph, name=name)
@@ -131,6 +133,10 @@ class GCNConv(MessagePassing):
             # raise on the length mismatch, so do we
             raise ValueError(f"edge_weight has {edge_weight.shape[0]} entries for {st.num_edges} edges")
         norm = st.gcn_norm(edge_weight)
+        if dense_done:
+            if self.in_channels < self.out_channels or x.shape[1] != self.out_channels:
+                raise ValueError("dense_done=True needs a dense-first layer (in >= out) and x = lin(input)")
+            return PF.propagate_any(x, self.bias, st, norm, edge_weight is None, tag=name or None)
         if not (x.dtype == torch.bfloat16 and self.in_channels >= self.out_channels):
             x = x.float()          # (a bf16-stored input of a dense-first layer is read as stored by the linear kernel)
         # Under bf16 autocast (`accelerate` mixed precision) PyG's propagate gathers bf16 rows — the

@@ -748,6 +748,20 @@ extern "C" int pangnn_weighted_colsum3(const void* g, int32_t g_dtype, int64_t l
   return 0;
 }
 
+// the first layer's parameter gradients from the finished sums [3, H] = [r s 1]^T dL/dh (device), however they were formed
+// (pangnn_weighted_colsum3, or pangnn_embed_linear_bwd which never writes dL/dh)
+extern "C" int pangnn_embed_conv_in_grads_from_sums(const float* sums, const float* w_emb, const float* b_emb,
+                                                    const float* w_in, int32_t D, int32_t H, float* g_w_emb, float* g_b_emb,
+                                                    float* g_w_in, float* g_b_in, pangnn_stream_t stream) {
+  const char* who = "pangnn_embed_conv_in_grads_from_sums";
+  PG_CHECK_ARG(D > 0 && H > 0 && sums && w_emb && b_emb && w_in && g_w_emb && g_b_emb && g_w_in, PANGNN_E_BADARG,
+               "%s: null pointer / size", who);
+  hipLaunchKernelGGL(embed_conv_in_param_grads_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, sums, w_emb, b_emb, w_in,
+                     (int)D, (int)H, g_w_emb, g_b_emb, g_w_in, g_b_in);
+  PG_CHECK_LAUNCH(who);
+  return 0;
+}
+
 extern "C" size_t pangnn_embed_conv_in_grads_workspace_bytes(int32_t H) {
   return pangnn_weighted_colsum3_workspace_bytes(H) + 3 * (size_t)(H > 0 ? H : 1) * sizeof(float);
 }

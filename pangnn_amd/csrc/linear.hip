@@ -473,6 +473,329 @@ static int launch_wgrad(const void* g, int g_bf16, int64_t ldg, const void* x, i
 #undef PG_WG
 }
 
+
+// ==============================================================================================================
+// First layer by linearity, fused into the dense layer that follows it (gnn.py:97,125-166 for the scalar-feature model):
+//     h[i][k] = r_i a_k + s_i c_k + b_k          (functional._EmbedConvIn: r = A_hat x, s = A_hat 1, a = W_in w, c = W_in b_emb)
+//     y = ELU(h) W_out^T (+ bias)                 (conv_out's / linear_out's dense part)
+// The [N, H] rows of h are GENERATED inside the kernels that would read them — 8 bytes per row (r_i, s_i) instead of 4 H:
+//   gen_linear_fwd_kernel         y = ELU(h) W_out^T (+ bias)          (h is never written)
+//   gen_linear_wgrad_kernel       dL/dW_out = g^T ELU(h), dL/dbias     (h regenerated)
+//   gen_linear_dgrad_sums_kernel  [r s 1]^T ((g W_out) * ELU'(h))      (dL/dh is never written: its three weighted column
+//                                                                       sums are all the first layer's parameters need)
+// The generated values are exactly embed_conv_in_rows_kernel's (same fused multiply-adds), so the forward result equals the
+// layer-by-layer evaluation bit for bit; the backward sums differ from it by fp32 re-association only.
+// ==============================================================================================================
+// acb[0..K) = a, [K..2K) = c, [2K..3K) = b_in (0 when absent): same dot-product order as embed_conv_in_rows_kernel
+template <int K>
+__device__ __forceinline__ void gen_params(const float* __restrict__ w_emb, const float* __restrict__ b_emb,
+                                           const float* __restrict__ w_in, const float* __restrict__ b_in, int D, float* acb,
+                                           int n_threads) {
+  for (int k = threadIdx.x; k < K; k += n_threads) {
+    float a = 0.f, c = 0.f;
+    const float* wr = w_in + (int64_t)k * D;
+    for (int d = 0; d < D; ++d) { a = fmaf(wr[d], w_emb[d], a); c = fmaf(wr[d], b_emb[d], c); }
+    acb[k] = a;
+    acb[K + k] = c;
+    acb[2 * K + k] = b_in ? b_in[k] : 0.f;
+  }
+}
+
+// r of rows [base, base + 32) in lanes 0..31, s of the same rows in lanes 32..63; rows >= n read as 0
+__device__ __forceinline__ float gen_load(const float* __restrict__ rv, const float* __restrict__ sv, int64_t n, int64_t base,
+                                          int lane) {
+  const int64_t row = base + (lane & 31);
+  const float* p = lane < 32 ? rv : sv;
+  return row < n ? p[row] : 0.f;
+}
+
+__device__ __forceinline__ float gen_h(float rv, float sv, float a, float c, float b) { return fmaf(rv, a, fmaf(sv, c, b)); }
+
+// the [32][C+4] LDS tile of ELU(h) for the 32 rows whose (r, s) sit in `rsv` (gen_load)
+template <int C>
+__device__ __forceinline__ void gen_store_rows(float rsv, int lane, float* tile, float4 a4, float4 c4, float4 b4) {
+  constexpr int LPR = C / 4;
+  constexpr int RPI = 64 / LPR;
+  constexpr int RS = C + 4;
+  const int q = lane % LPR, r0 = lane / LPR;
+#pragma unroll
+  for (int i = 0; i < 32 / RPI; ++i) {
+    const int row = i * RPI + r0;
+    const float rv = __shfl(rsv, row), sv = __shfl(rsv, 32 + row);
+    float4 v;
+    v.x = elu1(gen_h(rv, sv, a4.x, c4.x, b4.x));
+    v.y = elu1(gen_h(rv, sv, a4.y, c4.y, b4.y));
+    v.z = elu1(gen_h(rv, sv, a4.z, c4.z, b4.z));
+    v.w = elu1(gen_h(rv, sv, a4.w, c4.w, b4.w));
+    *reinterpret_cast<float4*>(tile + row * RS + 4 * q) = v;
+  }
+}
+
+template <int K, int M>
+__global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void gen_linear_fwd_kernel(
+    const float* __restrict__ rvec, const float* __restrict__ svec, const float* __restrict__ w_emb,
+    const float* __restrict__ b_emb, const float* __restrict__ w_in, const float* __restrict__ b_in, int D,
+    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int64_t ldy, int64_t n,
+    int64_t n_tiles) {
+  constexpr int KS = K + 4;
+  constexpr int WAVES = FwdGeo<K, M>::WAVES;
+  __shared__ __attribute__((aligned(16))) float lds[M * KS + WAVES * 32 * KS];
+  __shared__ __attribute__((aligned(16))) float acb[3 * K];
+  float* Wl = lds;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* Xt = lds + M * KS + wave * (32 * KS);
+  for (int i = threadIdx.x; i < M * (K / 4); i += WAVES * 64) {
+    const int m = i / (K / 4), k4 = i % (K / 4);
+    *reinterpret_cast<float4*>(Wl + m * KS + 4 * k4) = reinterpret_cast<const float4*>(w)[i];
+  }
+  gen_params<K>(w_emb, b_emb, w_in, b_in, D, acb, WAVES * 64);
+  __syncthreads();
+  const int q = lane % (K / 4);
+  const float4 a4 = *reinterpret_cast<const float4*>(acb + 4 * q), c4 = *reinterpret_cast<const float4*>(acb + K + 4 * q);
+  const float4 b4 = *reinterpret_cast<const float4*>(acb + 2 * K + 4 * q);
+  const int r = lane & 31, hh = lane >> 5;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  float bv[M / 32];
+#pragma unroll
+  for (int b = 0; b < M / 32; ++b) bv[b] = bias ? bias[r + 32 * b] : 0.f;
+  f32x16 acc[M / 32];
+  float rsv = gen_load(rvec, svec, n, tile * 32, lane);
+  for (; tile < n_tiles; tile += stride) {
+    gen_store_rows<K>(rsv, lane, Xt, a4, c4, b4);
+    rsv = gen_load(rvec, svec, n, (tile + stride) * 32, lane);
+    wave_sync_lds();
+    tile_product<K, M>(Xt, Wl, r, hh, acc);
+    if (tile * 32 + 32 <= n) {                     // wave-uniform: full tile, 128-byte row segments
+      uint32_t loff = (4u * hh * (uint32_t)ldy + r) * (uint32_t)sizeof(float);
+      int64_t sbase = tile * 32;
+      pin(sbase, loff);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* yr = y + (sbase + (i & 3) + 8 * (i >> 2)) * ldy;
+#pragma unroll
+        for (int b = 0; b < M / 32; ++b) st_f32(yr + 32 * b, loff, acc[b][i] + bv[b]);
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = tile * 32 + jrow(i, hh);
+          if (row < n) y[row * ldy + r + 32 * b] = acc[b][i] + bv[b];
+        }
+    }
+    wave_sync_lds();
+  }
+}
+
+// dL/dW_out [M][K] (+ dL/dbias [M]) with x = ELU(h) regenerated: linear_wgrad_kernel's accumulation and slab reduction
+template <int K, int M>
+__global__ __launch_bounds__(256) void gen_linear_wgrad_kernel(const float* __restrict__ g, int64_t ldg,
+                                                               const float* __restrict__ rvec, const float* __restrict__ svec,
+                                                               const float* __restrict__ w_emb, const float* __restrict__ b_emb,
+                                                               const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                               int D, int64_t n, int64_t n_tiles, float* __restrict__ slabs) {
+  constexpr int KS = K + 4, MS = M + 4;
+  constexpr int PER_WAVE = 32 * KS + 32 * MS;
+  constexpr int SLAB = WgradGeo<K, M>::SLAB;
+  constexpr int LDS_F = (4 * PER_WAVE > SLAB) ? 4 * PER_WAVE : SLAB;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_F];
+  __shared__ __attribute__((aligned(16))) float acb[3 * K];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* Xt = lds + wave * PER_WAVE;
+  float* Gt = Xt + 32 * KS;
+  gen_params<K>(w_emb, b_emb, w_in, b_in, D, acb, 256);
+  __syncthreads();
+  const int q = lane % (K / 4);
+  const float4 a4 = *reinterpret_cast<const float4*>(acb + 4 * q), c4 = *reinterpret_cast<const float4*>(acb + K + 4 * q);
+  const float4 b4 = *reinterpret_cast<const float4*>(acb + 2 * K + 4 * q);
+  const int r = lane & 31, hh = lane >> 5;
+  f32x16 acc[M / 32][K / 32];
+  float gbp[M / 32];
+#pragma unroll
+  for (int a = 0; a < M / 32; ++a) {
+    gbp[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < K / 32; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  RowRegs<M, float> rgm;
+  float rsv = gen_load(rvec, svec, n, tile * 32, lane);
+  load_rows<M, float>(g, ldg, n, tile * 32, lane, rgm);
+  for (; tile < n_tiles; tile += stride) {
+    gen_store_rows<K>(rsv, lane, Xt, a4, c4, b4);
+    store_rows<M, 0, float>(rgm, lane, Gt);                 // rows >= n are zero: their generated x contributes nothing
+    rsv = gen_load(rvec, svec, n, (tile + stride) * 32, lane);
+    load_rows<M, float>(g, ldg, n, (tile + stride) * 32, lane, rgm);
+    wave_sync_lds();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = 2 * s + hh;
+      float av[M / 32], bv[K / 32];
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a) { av[a] = Gt[row * MS + r + 32 * a]; gbp[a] += av[a]; }
+#pragma unroll
+      for (int b = 0; b < K / 32; ++b) bv[b] = Xt[row * KS + r + 32 * b];
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a)
+#pragma unroll
+        for (int b = 0; b < K / 32; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    wave_sync_lds();
+  }
+#pragma unroll
+  for (int a = 0; a < M / 32; ++a) gbp[a] += __shfl_xor(gbp[a], 32);
+  __syncthreads();
+  float* red = lds;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+      const bool first = (wv == 0);
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a) {
+#pragma unroll
+        for (int b = 0; b < K / 32; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int idx = (32 * a + jrow(i, hh)) * K + r + 32 * b;
+            red[idx] = (first ? 0.f : red[idx]) + acc[a][b][i];
+          }
+        if (hh == 0) red[M * K + r + 32 * a] = (first ? 0.f : red[M * K + r + 32 * a]) + gbp[a];
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * SLAB;
+  for (int i = threadIdx.x; i < SLAB; i += 256) slab[i] = red[i];
+}
+
+// sums[3][H] = [r s 1]^T ((g W_out) * ELU'(h)): KG = width of g (the dense layer's output width), H = width of h.
+// The product is linear_fwd_kernel's (x = g, w = W_out^T staged transposed out of W_out [KG][H]); the epilogue multiplies
+// by ELU'(h) of the regenerated h and accumulates the three weighted column sums per lane over all of the wave's tiles;
+// lanes -> waves -> workgroup slab in a fixed order, slabs summed by slab_reduce_kernel (bitwise reproducible).
+template <int KG, int H>
+__global__ __launch_bounds__((FwdGeo<KG, H>::WAVES * 64)) void gen_linear_dgrad_sums_kernel(
+    const float* __restrict__ g, int64_t ldg, const float* __restrict__ w_out, const float* __restrict__ rvec,
+    const float* __restrict__ svec, const float* __restrict__ w_emb, const float* __restrict__ b_emb,
+    const float* __restrict__ w_in, const float* __restrict__ b_in, int D, int64_t n, int64_t n_tiles,
+    float* __restrict__ slabs) {
+  constexpr int KS = KG + 4;
+  constexpr int WAVES = FwdGeo<KG, H>::WAVES;
+  __shared__ __attribute__((aligned(16))) float lds[H * KS + WAVES * 32 * KS];
+  __shared__ __attribute__((aligned(16))) float acb[3 * H];
+  __shared__ float part[WAVES][3 * H];
+  float* Wl = lds;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* Xt = lds + H * KS + wave * (32 * KS);
+  for (int i = threadIdx.x; i < H * KG; i += WAVES * 64) {       // Wl[h][m] = W_out[m][h]
+    const int m = i / H, h = i % H;
+    Wl[h * KS + m] = w_out[i];
+  }
+  gen_params<H>(w_emb, b_emb, w_in, b_in, D, acb, WAVES * 64);
+  __syncthreads();
+  const int r = lane & 31, hh = lane >> 5;
+  float ca[H / 32], cc[H / 32], cb[H / 32];
+#pragma unroll
+  for (int b = 0; b < H / 32; ++b) { ca[b] = acb[r + 32 * b]; cc[b] = acb[H + r + 32 * b]; cb[b] = acb[2 * H + r + 32 * b]; }
+  float s0[H / 32], s1[H / 32], s2[H / 32];
+#pragma unroll
+  for (int b = 0; b < H / 32; ++b) s0[b] = s1[b] = s2[b] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  f32x16 acc[H / 32];
+  RowRegs<KG, float> rg;
+  load_rows<KG, float>(g, ldg, n, tile * 32, lane, rg);
+  float rsv = gen_load(rvec, svec, n, tile * 32, lane);
+  for (; tile < n_tiles; tile += stride) {
+    store_rows<KG, 0, float>(rg, lane, Xt);
+    const float rs_cur = rsv;
+    load_rows<KG, float>(g, ldg, n, (tile + stride) * 32, lane, rg);
+    rsv = gen_load(rvec, svec, n, (tile + stride) * 32, lane);
+    wave_sync_lds();
+    tile_product<KG, H>(Xt, Wl, r, hh, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = jrow(i, hh);
+      const float rv = __shfl(rs_cur, row), sv = __shfl(rs_cur, 32 + row);
+#pragma unroll
+      for (int b = 0; b < H / 32; ++b) {
+        const float v = acc[b][i] * elu1_grad(gen_h(rv, sv, ca[b], cc[b], cb[b]));     // rows >= n: g = 0 -> acc = 0
+        s0[b] = fmaf(rv, v, s0[b]);
+        s1[b] = fmaf(sv, v, s1[b]);
+        s2[b] += v;
+      }
+    }
+    wave_sync_lds();
+  }
+#pragma unroll
+  for (int b = 0; b < H / 32; ++b) {
+    s0[b] += __shfl_xor(s0[b], 32);
+    s1[b] += __shfl_xor(s1[b], 32);
+    s2[b] += __shfl_xor(s2[b], 32);
+    if (hh == 0) { part[wave][r + 32 * b] = s0[b]; part[wave][H + r + 32 * b] = s1[b]; part[wave][2 * H + r + 32 * b] = s2[b]; }
+  }
+  __syncthreads();
+  float* slab = slabs + (int64_t)blockIdx.x * (3 * H);
+  for (int i = threadIdx.x; i < 3 * H; i += WAVES * 64) {
+    float t = part[0][i];
+#pragma unroll
+    for (int wv = 1; wv < WAVES; ++wv) t += part[wv][i];
+    slab[i] = t;
+  }
+}
+
+template <int K, int M>
+static int launch_gen_fwd(const float* r, const float* sv, const float* w_emb, const float* b_emb, const float* w_in,
+                          const float* b_in, int D, const float* w, const float* bias, float* y, int64_t ldy, int64_t n,
+                          hipStream_t s) {
+  constexpr int WAVES = FwdGeo<K, M>::WAVES;
+  const int64_t n_tiles = (n + 31) / 32;
+  int64_t grid = (n_tiles + WAVES - 1) / WAVES;
+  const int64_t cap = (int64_t)num_cus();
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((gen_linear_fwd_kernel<K, M>), dim3((unsigned)grid), dim3(WAVES * 64), 0, s, r, sv, w_emb, b_emb, w_in, b_in,
+                     D, w, bias, y, ldy, n, n_tiles);
+  PG_CHECK_LAUNCH("pangnn_embed_linear_fwd");
+  return 0;
+}
+
+static int64_t gen_grid(int64_t n, int waves) {
+  const int64_t n_tiles = (n + 31) / 32;
+  int64_t grid = (n_tiles + waves - 1) / waves;
+  const int64_t cap = (int64_t)num_cus();
+  if (grid > cap) grid = cap;
+  return grid < 1 ? 1 : grid;
+}
+
+template <int K, int M>
+static int launch_gen_bwd(const float* g, int64_t ldg, const float* r, const float* sv, const float* w_emb, const float* b_emb,
+                          const float* w_in, const float* b_in, int D, const float* w_out, int64_t n, float* g_w_out,
+                          float* g_b_out, float* sums, float* ws, hipStream_t s) {
+  constexpr int SLAB = WgradGeo<K, M>::SLAB;
+  const int64_t n_tiles = (n + 31) / 32;
+  const int64_t grid_w = gen_grid(n, 4);
+  hipLaunchKernelGGL((gen_linear_wgrad_kernel<K, M>), dim3((unsigned)grid_w), dim3(256), 0, s, g, ldg, r, sv, w_emb, b_emb, w_in,
+                     b_in, D, n, n_tiles, ws);
+  PG_CHECK_LAUNCH("pangnn_embed_linear_bwd(wgrad)");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB + kWave - 1) / kWave), dim3(kSumThreads), 0, s, ws, (int)grid_w, SLAB,
+                     M * K, g_w_out, g_b_out);
+  PG_CHECK_LAUNCH("pangnn_embed_linear_bwd(wgrad reduce)");
+  float* ws2 = ws + (size_t)num_cus() * SLAB;
+  constexpr int WAVES = FwdGeo<M, K>::WAVES;
+  const int64_t grid_d = gen_grid(n, WAVES);
+  hipLaunchKernelGGL((gen_linear_dgrad_sums_kernel<M, K>), dim3((unsigned)grid_d), dim3(WAVES * 64), 0, s, g, ldg, w_out, r, sv,
+                     w_emb, b_emb, w_in, b_in, D, n, n_tiles, ws2);
+  PG_CHECK_LAUNCH("pangnn_embed_linear_bwd(dgrad sums)");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((3 * K + kWave - 1) / kWave), dim3(kSumThreads), 0, s, ws2, (int)grid_d, 3 * K,
+                     3 * K, sums, static_cast<float*>(nullptr));
+  PG_CHECK_LAUNCH("pangnn_embed_linear_bwd(sums reduce)");
+  return 0;
+}
+
 }  // namespace pangnn
 
 using namespace pangnn;
@@ -561,4 +884,49 @@ extern "C" int pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float*
                                        int32_t K, int32_t M, float* gw, float* gb, void* workspace,
                                        size_t workspace_bytes, pangnn_stream_t stream) {
   return pangnn_linear_act_wgrad_f32(g, ldg, x, ldx, n, K, M, 0, gw, gb, workspace, workspace_bytes, stream);
+}
+
+// ---- first layer by linearity fused into the following dense layer (see gen_linear_*_kernel above) ----
+extern "C" int pangnn_embed_linear_supported(int32_t H, int32_t M) { return pangnn_linear_supported(H, M, 1); }
+
+extern "C" int pangnn_embed_linear_fwd(const float* r, const float* s, int64_t n, const float* w_emb, const float* b_emb,
+                                       const float* w_in, const float* b_in, int32_t D, int32_t H, const float* w_out,
+                                       const float* bias_out, int32_t M, float* y, int64_t ldy, pangnn_stream_t stream) {
+  const char* who = "pangnn_embed_linear_fwd";
+  PG_CHECK_ARG(n >= 0 && D > 0, PANGNN_E_BADARG, "%s: negative size", who);
+  PG_CHECK_ARG(pangnn_embed_linear_supported(H, M), PANGNN_E_BADARG, "%s: unsupported (H, M) = (%d, %d)", who, (int)H, (int)M);
+  if (n == 0) return 0;
+  PG_CHECK_ARG(r && s && w_emb && b_emb && w_in && w_out && y && ldy >= M, PANGNN_E_BADARG, "%s: bad pointer / ld", who);
+  PG_CHECK_ARG(aligned16(w_out), PANGNN_E_ALIGN, "%s: w_out must be 16-byte aligned", who);
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 64 && M == 64) return launch_gen_fwd<64, 64>(r, s, w_emb, b_emb, w_in, b_in, D, w_out, bias_out, y, ldy, n, st);
+  if (H == 64 && M == 128) return launch_gen_fwd<64, 128>(r, s, w_emb, b_emb, w_in, b_in, D, w_out, bias_out, y, ldy, n, st);
+  return launch_gen_fwd<128, 64>(r, s, w_emb, b_emb, w_in, b_in, D, w_out, bias_out, y, ldy, n, st);
+}
+
+extern "C" size_t pangnn_embed_linear_bwd_workspace_bytes(int32_t H, int32_t M) {
+  return (size_t)num_cus() * ((size_t)M * H + M + 3 * (size_t)H) * sizeof(float);
+}
+
+// g [n, M] = dL/dy.  Outputs: g_w_out [M, H], g_b_out [M] (nullable), sums [3, H] = [r s 1]^T dL/dh (feed
+// pangnn_embed_conv_in_grads_from_sums).
+extern "C" int pangnn_embed_linear_bwd(const float* g, int64_t ldg, const float* r, const float* s, int64_t n,
+                                       const float* w_emb, const float* b_emb, const float* w_in, const float* b_in, int32_t D,
+                                       int32_t H, const float* w_out, int32_t M, float* g_w_out, float* g_b_out, float* sums,
+                                       void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
+  const char* who = "pangnn_embed_linear_bwd";
+  PG_CHECK_ARG(n >= 0 && D > 0, PANGNN_E_BADARG, "%s: negative size", who);
+  PG_CHECK_ARG(pangnn_embed_linear_supported(H, M), PANGNN_E_BADARG, "%s: unsupported (H, M) = (%d, %d)", who, (int)H, (int)M);
+  PG_CHECK_ARG(w_emb && b_emb && w_in && w_out && g_w_out && sums && (n == 0 || (g && r && s)) && ldg >= M && ldg % 4 == 0,
+               PANGNN_E_BADARG, "%s: bad pointer / ld", who);
+  PG_CHECK_ARG(workspace && workspace_bytes >= pangnn_embed_linear_bwd_workspace_bytes(H, M), PANGNN_E_WORKSPACE,
+               "%s: workspace too small", who);
+  PG_CHECK_ARG(n == 0 || aligned16(g), PANGNN_E_ALIGN, "%s: g rows must start on 16 bytes", who);
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = static_cast<float*>(workspace);
+#define PG_GB(HH, MM) return launch_gen_bwd<HH, MM>(g, ldg, r, s, w_emb, b_emb, w_in, b_in, D, w_out, n, g_w_out, g_b_out, sums, ws, st)
+  if (H == 64 && M == 64) PG_GB(64, 64);
+  if (H == 64 && M == 128) PG_GB(64, 128);
+  PG_GB(128, 64);
+#undef PG_GB
 }

@@ -974,3 +974,79 @@ def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):
         from . import torch_ops
         return torch_ops.embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype)
     return _EmbedConvIn.apply(x_tab, w, b, w_in, b_in, st, norm, out_dtype)
+
+
+class _EmbedConvInLinear(torch.autograd.Function):
+    """linear(ELU(conv_in(embedding(x))), w_out, bias_out) for the scalar-feature model — the first layer by linearity
+    (_EmbedConvIn) FUSED into the dense layer that consumes it (conv_out's GCNConv.lin, gnn.py:164-166; linear_out,
+    gnn.py:147): the [N, H] rows are generated inside the kernels (pangnn_embed_linear_fwd / _bwd), never written or read.
+    Backward: one pass over g = dL/dy gives dL/dW_out (+ dL/dbias_out), a second one the three weighted column sums of
+    dL/dh = (g W_out) * ELU'(h) — all the first layer's parameters need — without writing dL/dh.
+    Forward equals linear(embed_conv_in(...), in_act=1) bit for bit (same generated values, same product); the parameter
+    gradients differ from that form by fp32 re-association."""
+
+    @staticmethod
+    def forward(ctx, x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):
+        lib = _lib.load()
+        _lib.require_device(x_tab, w, b, w_in, b_in, w_out, bias_out)
+        r, s = _node_actions(x_tab, st, norm)
+        wv, bv, win = _f32c(w.detach().reshape(-1)), _f32c(b.detach().reshape(-1)), _f32c(w_in.detach())
+        bin_ = None if b_in is None else _f32c(b_in.detach())
+        wout = _f32c(w_out.detach())
+        bout = None if bias_out is None else _f32c(bias_out.detach())
+        n, h, d, m = st.num_nodes, win.shape[0], win.shape[1], wout.shape[0]
+        if wout.shape[1] != h or not lib.pangnn_embed_linear_supported(h, m):
+            raise ValueError(f"embed_conv_in_linear: unsupported widths H={h}, M={m}")
+        y = torch.empty(n, m, dtype=torch.float32, device=r.device)
+        with _lib.device_guard(r.device):
+            _lib.check(lib.pangnn_embed_linear_fwd(r.data_ptr(), s.data_ptr(), n, wv.data_ptr(), bv.data_ptr(), win.data_ptr(),
+                                                   _lib.ptr(bin_), d, h, wout.data_ptr(), _lib.ptr(bout), m, y.data_ptr(),
+                                                   y.stride(0), _lib.stream_ptr()), "pangnn_embed_linear_fwd")
+        ctx.save_for_backward(r, s, wv, bv, win, wout, bin_ if bin_ is not None else wv.new_empty(0))
+        ctx.has_bin, ctx.has_bout = b_in is not None, bias_out is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        r, s, wv, bv, win, wout, bin_ = ctx.saved_tensors
+        bin_ = bin_ if ctx.has_bin else None
+        g = _rows_f32(g)
+        n, m = g.shape
+        h, d = win.shape
+        dev = g.device
+        out = torch.empty(m * h + m + 3 * h + d + d + h * d + h, dtype=torch.float32, device=dev)     # one allocation
+        o = 0
+        g_wout, o = out[o:o + m * h].view(m, h), o + m * h
+        g_bout, o = out[o:o + m], o + m
+        sums, o = out[o:o + 3 * h], o + 3 * h
+        g_w, o = out[o:o + d].view(d, 1), o + d
+        g_b, o = out[o:o + d], o + d
+        g_win, o = out[o:o + h * d].view(h, d), o + h * d
+        g_bin = out[o:o + h]
+        with _lib.device_guard(dev):
+            ws_bytes = lib.pangnn_embed_linear_bwd_workspace_bytes(h, m)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.pangnn_embed_linear_bwd(g.data_ptr(), g.stride(0), r.data_ptr(), s.data_ptr(), n, wv.data_ptr(),
+                                                   bv.data_ptr(), win.data_ptr(), _lib.ptr(bin_), d, h, wout.data_ptr(), m,
+                                                   g_wout.data_ptr(), g_bout.data_ptr() if ctx.has_bout else None,
+                                                   sums.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
+                       "pangnn_embed_linear_bwd")
+            _lib.check(lib.pangnn_embed_conv_in_grads_from_sums(sums.data_ptr(), wv.data_ptr(), bv.data_ptr(), win.data_ptr(),
+                                                                d, h, g_w.data_ptr(), g_b.data_ptr(), g_win.data_ptr(),
+                                                                g_bin.data_ptr() if ctx.has_bin else None,
+                                                                _lib.stream_ptr()), "pangnn_embed_conv_in_grads_from_sums")
+        return (None, g_w, g_b, g_win, g_bin if ctx.has_bin else None, g_wout, g_bout if ctx.has_bout else None, None, None)
+
+
+def embed_linear_supported(h: int, m: int) -> bool:
+    return _linear_supported(int(h), int(m))           # the same (K, M) set as the weight-gradient kernel
+
+
+def embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):
+    _lib.require_device(x_tab, w, b, w_in, b_in, w_out, bias_out)
+    if _via_ops(st) and getattr(norm, "weight_ref", norm) is not norm:
+        from . import torch_ops
+        return torch_ops.embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm)
+    return _EmbedConvInLinear.apply(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm)
+

@@ -30,6 +30,7 @@ op.  `encode()` always returns activated embeddings.
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Optional
 
@@ -49,7 +50,7 @@ _FLAG_DEFAULTS = dict(union_edge_weights=False, base_model=False, skip_connectio
 class AlternateGCN(nn.Module):
     def __init__(self, device=None, dataset=None, categorical_nodes: bool = False, dims=(64, 128),
                  args=None, num_nodes: Optional[int] = None, fused_decoder: bool = True,
-                 fuse_embedding: bool = True, fold_activation: bool = True, **flags):
+                 fuse_embedding: bool = True, fold_activation: bool = True, fuse_first_dense: Optional[bool] = None, **flags):
         super().__init__()
         self.device = device
         cfg = dict(_FLAG_DEFAULTS)
@@ -65,6 +66,9 @@ class AlternateGCN(nn.Module):
         self.fused_decoder = fused_decoder
         self.fuse_embedding = fuse_embedding
         self.fold_activation = fold_activation
+        # None: on unless PANGNN_FUSE_FIRST_DENSE=0 (same-box A/B of bench.py)
+        self.fuse_first_dense = (os.environ.get("PANGNN_FUSE_FIRST_DENSE", "1") != "0") if fuse_first_dense is None \
+            else bool(fuse_first_dense)
         node_embedding_dim, hidden_dim = dims
 
         if categorical_nodes:
@@ -120,6 +124,27 @@ class AlternateGCN(nn.Module):
         h = x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
         return conv(h, ei, graph.edge_attr, graph=graph, name=name)
 
+    def _embed_conv_in_then_dense(self, graph, ei, name, w_out, bias_out):
+        """linear(ELU(conv_in(embedding(x))), w_out, bias_out) with the [N, H] rows of the first layer generated inside the
+        dense layer's kernels (functional._EmbedConvInLinear) — or None where that operator does not apply: categorical
+        nodes, fuse_embedding / fuse_first_dense / fold_activation off, widths its kernels do not cover, bf16 autocast
+        (the reference's autocast stores those rows as bfloat16; the generated rows are fp32)."""
+        x, conv = graph.x, self.conv_in
+        if self.categorical_nodes or not self.fuse_first_dense or not self._fold_elu() or not self.fuse_embedding \
+                or self.fuse_embedding == "propagate":
+            return None
+        if w_out.shape[1] != conv.out_channels or not PF.embed_linear_supported(conv.out_channels, w_out.shape[0]):
+            return None
+        _lib.require_device(x)
+        if PF.autocast_bf16(x):
+            return None
+        st = structure_of(ei, x.shape[0], holder=graph, name=name)
+        w = graph.edge_attr
+        if w is not None and w.shape[0] != st.num_edges:
+            raise ValueError(f"edge_weight has {w.shape[0]} entries for {st.num_edges} edges")
+        return PF.embed_conv_in_linear(x, self.embedding.weight, self.embedding.bias, conv.lin.weight, conv.bias, w_out,
+                                       bias_out, st, st.gcn_norm(w))
+
     def _fold_elu(self) -> bool:
         """the encoder's activation (gnn.py:108: ELU) can be folded into the dense layer that follows it"""
         a = self.activation_fct
@@ -134,20 +159,34 @@ class AlternateGCN(nn.Module):
         act, fold = self.activation_fct, self._fold_elu()
         if fl.union_edge_weights:                                              # gnn.py:128-139
             ei = graph.union_edge_index
-            h = self._embed_conv_in(graph, ei, "union")
-            for _ in range(max(fl.neighbours - 2, 1)):
-                h = self.conv_hidden(h, ei, graph.edge_attr, graph=graph, name="union", in_elu=True) if fold \
-                    else self.conv_hidden(act(h), ei, graph.edge_attr, graph=graph, name="union")
+            hid = self.conv_hidden
+            y = self._embed_conv_in_then_dense(graph, ei, "union", hid.lin.weight, None) \
+                if hid.in_channels >= hid.out_channels else None
+            h = self._embed_conv_in(graph, ei, "union") if y is None else None
+            for k in range(max(fl.neighbours - 2, 1)):
+                if k == 0 and y is not None:           # the first hidden layer's dense part came fused with conv_in
+                    h = hid(y, ei, graph.edge_attr, graph=graph, name="union", dense_done=True)
+                    continue
+                h = hid(h, ei, graph.edge_attr, graph=graph, name="union", in_elu=True) if fold \
+                    else hid(act(h), ei, graph.edge_attr, graph=graph, name="union")
             h = self.conv_out(h, ei, graph=graph, name="union", in_elu=True) if fold \
                 else self.conv_out(act(h), ei, graph=graph, name="union")
         elif fl.base_model:                                                    # gnn.py:143-150
-            h = self._embed_conv_in(graph, graph.edge_index, "sim")
-            h = PF.linear(h, self.linear_out.weight, self.linear_out.bias, 1) if fold \
-                else PF.linear(act(h), self.linear_out.weight, self.linear_out.bias)
+            h = self._embed_conv_in_then_dense(graph, graph.edge_index, "sim", self.linear_out.weight, self.linear_out.bias)
+            if h is None:
+                h = self._embed_conv_in(graph, graph.edge_index, "sim")
+                h = PF.linear(h, self.linear_out.weight, self.linear_out.bias, 1) if fold \
+                    else PF.linear(act(h), self.linear_out.weight, self.linear_out.bias)
         else:                                                                  # gnn.py:153-166
-            h = self._embed_conv_in(graph, graph.edge_index, "sim")
-            h = self.conv_out(h, graph.neighbour_edge_index, graph=graph, name="nb", in_elu=True) if fold \
-                else self.conv_out(act(h), graph.neighbour_edge_index, graph=graph, name="nb")
+            out = self.conv_out
+            y = self._embed_conv_in_then_dense(graph, graph.edge_index, "sim", out.lin.weight, None) \
+                if out.in_channels >= out.out_channels else None
+            if y is not None:                          # conv_out's dense part came fused with conv_in: propagate + bias left
+                h = out(y, graph.neighbour_edge_index, graph=graph, name="nb", dense_done=True)
+            else:
+                h = self._embed_conv_in(graph, graph.edge_index, "sim")
+                h = out(h, graph.neighbour_edge_index, graph=graph, name="nb", in_elu=True) if fold \
+                    else out(act(h), graph.neighbour_edge_index, graph=graph, name="nb")
         return h, True
 
     def encode(self, graph) -> torch.Tensor:

@@ -187,6 +187,12 @@ _lib2.define("embed_propagate(Tensor x, Tensor w, Tensor b, Tensor edge_index, T
 _lib2.define("embed_propagate_backward(Tensor g, Tensor x, Tensor edge_index, Tensor? edge_weight) -> (Tensor, Tensor)")
 
 
+_lib2.define("embed_conv_in_linear(Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor? b_in, Tensor w_out, Tensor? bias_out, "
+             "Tensor edge_index, Tensor? edge_weight) -> Tensor")
+_lib2.define("embed_conv_in_linear_backward(Tensor g, Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor? b_in, Tensor w_out, "
+             "Tensor edge_index, Tensor? edge_weight, bool has_bias_out) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
+
+
 class _Ctx:
     """what an autograd.Function's static forward / backward needs from its context, outside autograd"""
 
@@ -353,6 +359,57 @@ def _eci_bwd(ctx, g):
 
 
 torch.library.register_autograd("pangnn::embed_conv_in", _eci_bwd, setup_context=_eci_setup)
+
+
+# ---------------------------------------------------------------------------------------------- first layer + next dense layer
+def _ecil_impl(x, w, b, w_in, b_in, w_out, bias_out, edge_index, edge_weight):
+    st = _struct(edge_index, x.shape[0])
+    return _PF._EmbedConvInLinear.forward(_Ctx(), x, w, b, w_in, b_in, w_out, bias_out, st, st.gcn_norm(edge_weight))
+
+
+def _ecil_backward_impl(g, x, w, b, w_in, b_in, w_out, edge_index, edge_weight, has_bias_out):
+    st = _struct(edge_index, x.shape[0])
+    r, s = _PF._node_actions(x, st, st.gcn_norm(edge_weight))
+    f = _PF._f32c
+    ctx = _Ctx()
+    ctx.save_for_backward(r, s, f(w.reshape(-1)), f(b.reshape(-1)), f(w_in), f(w_out), f(b_in) if b_in is not None else r.new_empty(0))
+    ctx.has_bin, ctx.has_bout = b_in is not None, bool(has_bias_out)
+    out = _PF._EmbedConvInLinear.backward(ctx, g)
+    return (out[1], out[2], out[3], out[4] if out[4] is not None else _e(g, 0), out[5],
+            out[6] if out[6] is not None else _e(g, 0))
+
+
+_lib2.impl("embed_conv_in_linear", _ecil_impl, "CUDA")
+_lib2.impl("embed_conv_in_linear_backward", _ecil_backward_impl, "CUDA")
+
+
+@torch.library.register_fake("pangnn::embed_conv_in_linear")
+def _(x, w, b, w_in, b_in, w_out, bias_out, edge_index, edge_weight):
+    return w_out.new_empty(x.shape[0], w_out.shape[0], dtype=torch.float32)
+
+
+@torch.library.register_fake("pangnn::embed_conv_in_linear_backward")
+def _(g, x, w, b, w_in, b_in, w_out, edge_index, edge_weight, has_bias_out):
+    f = lambda *s: w_in.new_empty(s, dtype=torch.float32)        # noqa: E731
+    h, d = w_in.shape
+    return (f(d, 1), f(d), f(h, d), f(h if b_in is not None else 0), f(*w_out.shape), f(w_out.shape[0] if has_bias_out else 0))
+
+
+def _ecil_setup(ctx, inputs, output):
+    x, w, b, w_in, b_in, w_out, bias_out, edge_index, edge_weight = inputs
+    ctx.save_for_backward(x, w, b, w_in, b_in, w_out, edge_index, edge_weight)
+    ctx.has_bout = bias_out is not None
+
+
+def _ecil_bwd(ctx, g):
+    x, w, b, w_in, b_in, w_out, edge_index, edge_weight = ctx.saved_tensors
+    g_w, g_b, g_win, g_bin, g_wout, g_bout = ops.embed_conv_in_linear_backward(g, x, w, b, w_in, b_in, w_out, edge_index,
+                                                                               edge_weight, ctx.has_bout)
+    return (None, g_w.reshape(w.shape), g_b, g_win, g_bin if b_in is not None else None, g_wout,
+            g_bout if ctx.has_bout else None, None, None)
+
+
+torch.library.register_autograd("pangnn::embed_conv_in_linear", _ecil_bwd, setup_context=_ecil_setup)
 
 
 # ---------------------------------------------------------------------------------------------- round 2's first layer
@@ -525,6 +582,11 @@ def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):
     _G.register(st)
     return ops.embed_conv_in(x_tab, w, b, w_in, b_in, st._key_tensor, getattr(norm, "weight_ref", None),
                              out_dtype == torch.bfloat16)
+
+
+def embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):
+    _G.register(st)
+    return ops.embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st._key_tensor, getattr(norm, "weight_ref", None))
 
 
 def embed_propagate(x_tab, w, b, st, norm):

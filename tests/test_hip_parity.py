@@ -1175,6 +1175,103 @@ def test_fused_embedding_layer_equals_layerwise_form_and_oracle(flags, dims):
         assert close(model(copy_graph(g, dev())), ref_logits)
 
 
+# ---------------------------------------------------------------- first layer generated inside the next dense layer
+@pytest.mark.parametrize("h,m", [(64, 64), (64, 128), (128, 64)])
+@pytest.mark.parametrize("n,bias", [(1, True), (31, False), (32, True), (33, False), (1000, True), (40007, False), (70016, True)])
+def test_first_layer_generated_inside_the_next_dense_layer(h, m, n, bias):
+    """functional.embed_conv_in_linear (pangnn_embed_linear_fwd / _bwd: the [N, H] rows of conv_in(embedding(x)) generated
+    inside the dense layer's kernels) against the two-operator form linear(embed_conv_in(...), in_act=1): the forward and
+    dL/dW_out / dL/dbias_out bit for bit (same generated values, same products, same slab order), the first layer's four
+    parameter gradients within fp32 re-association of the column sums — and everything against an fp64 evaluation.
+    Row counts around the 32-row tile, one wave's share, and more tiles than one pass of the grid."""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    d = 64
+    gen = torch.Generator().manual_seed(7 * n + h + m)
+    e = max(4 * n, 8)
+    ei, w = random_graph(n, e, seed=n + h, hub=min(e, 700))
+    st = EdgeStructure(ei.to(dev()), n)
+    norm = st.gcn_norm(w.to(dev()))
+    x = torch.randn(n, 1, generator=gen).to(dev())
+    P = lambda *s_: (torch.randn(*s_, generator=gen) * 0.3).to(dev()).requires_grad_(True)       # noqa: E731
+    params = [P(d, 1), P(d), P(h, d), P(h), P(m, h), P(m) if bias else None]
+    go_ = torch.randn(n, m, generator=gen).to(dev())
+
+    def run(fused):
+        for p_ in params:
+            if p_ is not None:
+                p_.grad = None
+        we, be, win, bin_, wout, bout = params
+        if fused:
+            y = PF.embed_conv_in_linear(x, we, be, win, bin_, wout, bout, st, norm)
+        else:
+            y = PF.linear(PF.embed_conv_in(x, we, be, win, bin_, st, norm), wout, bout, 1)
+        y.backward(go_)
+        return y.detach(), [None if p_ is None else p_.grad.clone() for p_ in params]
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert torch.equal(y1, y0)
+    assert torch.equal(g1[4], g0[4]) and (not bias or torch.equal(g1[5], g0[5]))
+    # fp64 evaluation
+    r, s_ = PF._node_actions(x, st, norm)
+    pd = [None if p_ is None else p_.detach().double().requires_grad_(True) for p_ in params]
+    hh = r.double()[:, None] * (pd[2] @ pd[0]).T + s_.double()[:, None] * (pd[2] @ pd[1])[None, :] + pd[3]
+    yd = torch.nn.functional.elu(hh) @ pd[4].T + (pd[5] if bias else 0.0)
+    yd.backward(go_.double())
+    assert close(y1, yd, atol=2e-5, rtol=1e-5)
+    for k_ in range(6):
+        if params[k_] is None:
+            continue
+        ref = pd[k_].grad
+        scale = float(ref.abs().max()) + 1e-30
+        assert close(g1[k_], ref, atol=2e-5 * scale, rtol=1e-4), k_
+        assert close(g1[k_], g0[k_], atol=2e-5 * scale, rtol=1e-4), k_
+
+
+@pytest.mark.parametrize("flags,dims", [(dict(), (64, 128)), (dict(base_model=True), (64, 128)), (dict(), (64, 64)),
+                                        (dict(union_edge_weights=True), (64, 64)), (dict(skip_connections=True), (64, 128)),
+                                        (dict(union_edge_weights=True, neighbours=4), (64, 64))],
+                         ids=["default", "base", "default-64x64", "union-64x64", "skip", "union-3-hidden"])
+def test_model_with_first_dense_layer_fused_equals_unfused_model(flags, dims):
+    """AlternateGCN(fuse_first_dense=True) (default) against fuse_first_dense=False: loss, logits and every gradient behind
+    the fused operator bit for bit; the first layer's own parameter gradients within re-association"""
+    import pangnn_amd
+    g, gd, oracle, model = _pair("cfg2_sim_1000x5", dims, flags, seed=2)
+    gen = torch.Generator().manual_seed(4)
+    gd.x = torch.randn(g.x.shape[0], 1, generator=gen).to(dev())
+    assert model.fuse_first_dense is True
+    plain = pangnn_amd.AlternateGCN(dev(), None, False, dims=list(dims), fuse_first_dense=False, **flags)
+    plain.load_state_dict(model.state_dict())
+    pw = (gd.y == 0).sum() / gd.y.sum()
+    seen = []
+    orig = PF_mod()._EmbedConvInLinear.forward
+    PF_mod()._EmbedConvInLinear.forward = staticmethod(lambda *a: (seen.append(1), orig(*a))[1])
+    try:
+        out = []
+        for m_ in (model, plain):
+            loss, logits = m_.loss_and_logits(copy_graph(gd, dev()), gd.y, pw)
+            loss.backward()
+            out.append((loss.detach(), logits, {k: p.grad for k, p in m_.named_parameters() if p.grad is not None}))
+    finally:
+        PF_mod()._EmbedConvInLinear.forward = orig
+    assert len(seen) == 1                                   # the fused operator ran in `model`, not in `plain`
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    first = ("embedding.weight", "embedding.bias", "conv_in.lin.weight", "conv_in.bias")
+    assert out[0][2].keys() == out[1][2].keys()
+    for k, v in out[0][2].items():
+        if k in first:
+            scale = float(out[1][2][k].abs().max()) + 1e-30
+            assert close(v, out[1][2][k], atol=2e-5 * scale, rtol=1e-4), k
+        else:
+            assert torch.equal(v, out[1][2][k]), k
+
+
+def PF_mod():
+    from pangnn_amd import functional
+    return functional
+
+
 # ---------------------------------------------------------------- dense layer with the preceding ELU folded in
 @pytest.mark.parametrize("k,m", [(64, 64), (64, 128), (128, 64)])
 @pytest.mark.parametrize("n", [1, 33, 1000, 40007])

@@ -11,6 +11,7 @@ OPS = ["csr_from_coo", "gcn_norm", "spmm", "propagate", "edge_gather_concat", "s
        "segment_max_bwd",
        # the per-step operators of the train step (torch_ops.py, round 3)
        "linear", "linear_backward", "gcn_propagate", "gcn_propagate_backward", "embed_conv_in", "embed_conv_in_backward",
+       "embed_conv_in_linear", "embed_conv_in_linear_backward",
        "embed_propagate", "embed_propagate_backward", "decoder_loss", "decoder_mlp", "decoder_mlp_backward",
        "bce_with_logits"]
 
@@ -67,6 +68,10 @@ def test_step_operators_trace_with_fake_tensors():
         assert h.shape == (n, 128) and h.dtype == torch.float32
         assert [tuple(t.shape) for t in ops.embed_conv_in_backward(h, xt, ew, eb, w, ei, None, True)] == \
             [(64, 1), (64,), (128, 64), (128,)]
+        yl = ops.embed_conv_in_linear(xt, ew, eb, w, b, f(64, 128), None, ei, None)
+        assert yl.shape == (n, 64) and yl.dtype == torch.float32
+        assert [tuple(t.shape) for t in ops.embed_conv_in_linear_backward(yl, xt, ew, eb, w, b, f(64, 128), ei, None, False)] == \
+            [(64, 1), (64,), (128, 64), (128,), (64, 128), (0,)]
         a = ops.embed_propagate(xt, ew, eb, ei, None)
         assert a.shape == (n, 64)
         assert [tuple(t.shape) for t in ops.embed_propagate_backward(a, xt, ei, None)] == [(64, 1), (64,)]
@@ -231,6 +236,7 @@ MODEL_CASES = {
     "union": dict(union_edge_weights=True, neighbours=3),
     "base": dict(base_model=True),
     "layerwise": dict(_fuse=False),
+    "two_operators": dict(_first_dense=False),
     "round2_first_layer": dict(_fuse="propagate"),
     "wide": dict(_dims=[64, 128], skip_connections=True),
     "bf16": dict(_dims=[64, 128], _autocast=True),
@@ -242,13 +248,13 @@ def _model_and_graph(case, dev):
     import pangnn_amd
     from conftest import copy_graph, whole_graph_from_golden
     kw = dict(MODEL_CASES[case])
-    fuse, dims = kw.pop("_fuse", True), kw.pop("_dims", [64, 64])
+    fuse, dims, first_dense = kw.pop("_fuse", True), kw.pop("_dims", [64, 64]), kw.pop("_first_dense", True)
     autocast, via_forward = kw.pop("_autocast", False), kw.pop("_fused_decoder_only", False)
     g = copy_graph(whole_graph_from_golden("cfg2_sim_1000x5"), dev)
     if kw.get("union_edge_weights"):
         g.edge_attr = g.union_edge_attr       # dataset.py:380: Data(x, ei, union_edge_weights, y)
     torch.manual_seed(0)
-    model = pangnn_amd.AlternateGCN(dev, None, False, dims=dims, fuse_embedding=fuse, **kw)
+    model = pangnn_amd.AlternateGCN(dev, None, False, dims=dims, fuse_embedding=fuse, fuse_first_dense=first_dense, **kw)
     pw = (g.y == 0).sum() / g.y.sum()
     return model, g, pw, autocast, via_forward
 
@@ -309,7 +315,7 @@ def test_an_observer_sees_every_step_operator_as_a_registered_op():
     with Spy():
         loss, _ = model.loss_and_logits(g, g.y, pw)
         loss.backward()
-    for name in ("embed_conv_in", "gcn_propagate", "linear", "decoder_loss", "embed_conv_in_backward",
+    for name in ("embed_conv_in_linear", "gcn_propagate", "linear", "decoder_loss", "embed_conv_in_linear_backward",
                  "gcn_propagate_backward", "linear_backward"):
         assert name in seen, (name, seen)
 
@@ -376,6 +382,8 @@ def test_opcheck_of_the_step_operators():
         (ops.gcn_propagate, (p(n, 64), p(64), ei, w, True)),
         (ops.gcn_propagate, (p(n, 128), None, ei, None, False)),
         (ops.embed_conv_in, (r(n, 1), p(64, 1), p(64), p(128, 64), p(128), ei, w, False)),
+        (ops.embed_conv_in_linear, (r(n, 1), p(64, 1), p(64), p(128, 64), p(128), p(64, 128), None, ei, w)),
+        (ops.embed_conv_in_linear, (r(n, 1), p(64, 1), p(64), p(64, 64), None, p(64, 64), p(64), ei, None)),
         (ops.embed_propagate, (r(n, 1), p(64, 1), p(64), ei, w)),
         (ops.decoder_mlp, (p(n, 128), ei, w, p(64), p(64, 64), p(64), p(64), p(1))),
         (ops.decoder_loss, (p(n, 128), ei, None, None, p(64, 64), p(64), p(64), p(1), y, None, e)),
