@@ -149,8 +149,10 @@ struct FwdGeo {
   static constexpr int KS = K + 4;
 #ifdef PANGNN_LIN_WAVES      // diagnostic builds only
   static constexpr int WAVES = PANGNN_LIN_WAVES;
-#else
+#elif defined(PANGNN_LIN_F32_MFMA)
   static constexpr int WAVES = 4;
+#else
+  static constexpr int WAVES = 4;        // (8 waves for K = 64 measured: no gain — these kernels are at their HBM time)
 #endif
 };
 
@@ -194,6 +196,138 @@ __device__ __forceinline__ void tile_product(const float* Xt, const float* Wl, i
   }
 }
 
+// ---- the same product on the bf16 matrix pipe with fp32-exact operand handling (default; -DPANGNN_LIN_F32_MFMA: the
+// f32-MFMA product above).  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate and holds its SIMD for 16 passes: at
+// N = 1e6 a 128 x 64 layer is 1.6e10 flop = 0.10 ms of matrix time at peak, 0.20 ms measured — above the layers' HBM
+// time once their row streams are short (the generated first layer reads 8 bytes per row).  Here both operands are split
+// into three bf16 terms by truncation (x = hi + mid + lo EXACTLY: 8 + 8 + 8 significand bits) and the six partial
+// products of order <= 2^-16 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest first; the three dropped
+// terms (mid.lo, lo.mid, lo.lo) are <= 2^-23 |x||w| — below fp32's own rounding of the product.  Weights are split
+// once per workgroup into three LDS images [M][K+8] bf16; a tile's x values are split as they are read (5.5 VALU per
+// value, under the matrix instructions).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+struct Split3 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ Split3 split8(const float4& f0, const float4& f1) {
+  const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+  u32x4v hi, mid, lo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, f[2 * q]), b = __builtin_bit_cast(uint32_t, f[2 * q + 1]);
+    hi[q] = __builtin_amdgcn_perm(b, a, 0x07060302u);                       // the two high halves
+    const float ra = f[2 * q] - __builtin_bit_cast(float, a & 0xffff0000u);
+    const float rb = f[2 * q + 1] - __builtin_bit_cast(float, b & 0xffff0000u);
+    const uint32_t ua = __builtin_bit_cast(uint32_t, ra), ub = __builtin_bit_cast(uint32_t, rb);
+    mid[q] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float sa = ra - __builtin_bit_cast(float, ua & 0xffff0000u);
+    const float sb = rb - __builtin_bit_cast(float, ub & 0xffff0000u);
+    lo[q] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x07060302u);
+  }
+  Split3 r;
+  r.hi = __builtin_bit_cast(bf16x8, hi);
+  r.mid = __builtin_bit_cast(bf16x8, mid);
+  r.lo = __builtin_bit_cast(bf16x8, lo);
+  return r;
+}
+
+#ifdef PANGNN_LIN_F32_MFMA
+constexpr bool kLinX3 = false;
+#else
+constexpr bool kLinX3 = true;
+#endif
+
+// floats of LDS the weight image of a [M][K] layer takes
+template <int K, int M>
+struct WImg {
+  static constexpr int WS = K + 8;                                     // bf16 row stride of a split image
+  // 128 x 128 (three 34 KB images + four 17 KB row tiles) does not fit the 160 KB of LDS: that shape keeps the f32 product
+  static constexpr bool X3 = kLinX3 && (3 * M * WS * 2 + 4 * 32 * (K + 4) * 4 <= 150 * 1024);
+  static constexpr int FLOATS = X3 ? (3 * M * WS + 1) / 2 : M * (K + 4);
+};
+
+// stage w into LDS: element (m, k) of the [M][K] operand is w[m * sm + k * sk] (sk = 1: row-major [M][K]; sm = 1: the
+// transpose of a row-major [K][M])
+template <int K, int M>
+__device__ __forceinline__ void stage_w(const float* __restrict__ w, int sm, int sk, float* Wl, int n_threads) {
+  if constexpr (WImg<K, M>::X3) {
+    constexpr int WS = WImg<K, M>::WS, IMG = M * WS;
+    unsigned short* W3 = reinterpret_cast<unsigned short*>(Wl);
+    for (int i = threadIdx.x; i < M * K; i += n_threads) {
+      const int m = sk == 1 ? i / K : i % M, k = sk == 1 ? i % K : i / M;       // consecutive threads: consecutive addresses
+      const float v = w[m * sm + k * sk];
+      const uint32_t a = __builtin_bit_cast(uint32_t, v);
+      const float r1 = v - __builtin_bit_cast(float, a & 0xffff0000u);
+      const uint32_t b = __builtin_bit_cast(uint32_t, r1);
+      const float r2 = r1 - __builtin_bit_cast(float, b & 0xffff0000u);
+      W3[m * WS + k] = (unsigned short)(a >> 16);
+      W3[IMG + m * WS + k] = (unsigned short)(b >> 16);
+      W3[2 * IMG + m * WS + k] = (unsigned short)(__builtin_bit_cast(uint32_t, r2) >> 16);
+    }
+  } else {
+    constexpr int KS = K + 4;
+    for (int i = threadIdx.x; i < M * K; i += n_threads) {
+      const int m = sk == 1 ? i / K : i % M, k = sk == 1 ? i % K : i / M;
+      Wl[m * KS + k] = w[m * sm + k * sk];
+    }
+  }
+}
+
+template <int K, int M>
+__device__ __forceinline__ void tile_product_x3(const float* Xt, const float* Wl, int r, int hh, f32x16 (&acc)[M / 32]) {
+  constexpr int KS = K + 4, WS = WImg<K, M>::WS, IMG = M * WS;
+#pragma unroll
+  for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+  const float* xa = Xt + r * KS + 8 * hh;
+  const unsigned short* wb = reinterpret_cast<const unsigned short*>(Wl) + r * WS + 8 * hh;
+  float4 x0 = *reinterpret_cast<const float4*>(xa), x1 = *reinterpret_cast<const float4*>(xa + 4);
+  // weight fragments of a k-step (hi, mid, lo per output block): double-buffered one step ahead where the registers
+  // allow it (M = 64: 2 x 24), read at the top of their own step, ahead of the x split, for M = 128 (48)
+  constexpr bool DB = (M / 32) <= 2;
+  bf16x8 wf[DB ? 2 : 1][M / 32][3];
+  if constexpr (DB) {
+#pragma unroll
+    for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wf[0][b][t] = *reinterpret_cast<const bf16x8*>(wb + 32 * b * WS + t * IMG);
+  }
+#pragma unroll
+  for (int i = 0; i < K / 16; ++i) {
+    if constexpr (!DB) {
+#pragma unroll
+      for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) wf[0][b][t] = *reinterpret_cast<const bf16x8*>(wb + 32 * b * WS + 16 * i + t * IMG);
+    }
+    const Split3 a = split8(x0, x1);
+    if (i + 1 < K / 16) {                  // operands of step i + 1 are read from LDS before step i's matrix instructions
+      x0 = *reinterpret_cast<const float4*>(xa + 16 * (i + 1));
+      x1 = *reinterpret_cast<const float4*>(xa + 16 * (i + 1) + 4);
+      if constexpr (DB) {
+#pragma unroll
+        for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            wf[(i + 1) & 1][b][t] = *reinterpret_cast<const bf16x8*>(wb + 32 * b * WS + 16 * (i + 1) + t * IMG);
+      }
+    }
+    // the six partial products, smallest first; the output blocks interleaved so that consecutive matrix instructions
+    // never wait for each other's accumulator
+#define PG_X3(AT, WT)                                                                                     \
+    _Pragma("unroll") for (int b = 0; b < M / 32; ++b)                                                    \
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.AT, wf[DB ? (i & 1) : 0][b][WT], acc[b], 0, 0, 0);
+    PG_X3(lo, 0) PG_X3(hi, 2) PG_X3(mid, 1) PG_X3(mid, 0) PG_X3(hi, 1) PG_X3(hi, 0)
+#undef PG_X3
+  }
+}
+
+template <int K, int M>
+__device__ __forceinline__ void tile_mult(const float* Xt, const float* Wl, int r, int hh, f32x16 (&acc)[M / 32]) {
+  if constexpr (WImg<K, M>::X3) tile_product_x3<K, M>(Xt, Wl, r, hh, acc);
+  else tile_product<K, M>(Xt, Wl, r, hh, acc);
+}
+
 // Pipeline per wave over the FULL tiles (rows [32t, 32t+32) all inside the matrix):
 //   registers hold the x rows of tile t+1 (global loads issued one tile ahead) while tile t is multiplied out
 //   of LDS; they are committed to LDS at the END of iteration t, in the same basic block as tile t's 64 output
@@ -214,14 +348,12 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
                                                          int64_t ldgate) {
   constexpr int KS = K + 4;
   constexpr int WAVES = FwdGeo<K, M>::WAVES;
-  __shared__ __attribute__((aligned(16))) float lds[M * KS + WAVES * 32 * KS];
+  constexpr int WF = (WImg<K, M>::FLOATS + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float lds[WF + WAVES * 32 * KS];
   float* Wl = lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR
-  float* Xt = lds + M * KS + wave * (32 * KS);
-  for (int i = threadIdx.x; i < M * (K / 4); i += WAVES * 64) {
-    const int m = i / (K / 4), k4 = i % (K / 4);
-    *reinterpret_cast<float4*>(Wl + m * KS + 4 * k4) = reinterpret_cast<const float4*>(w)[i];
-  }
+  float* Xt = lds + WF + wave * (32 * KS);
+  stage_w<K, M>(w, K, 1, Wl, WAVES * 64);
   __syncthreads();
   const int r = lane & 31, hh = lane >> 5;
   const int64_t stride = (int64_t)gridDim.x * WAVES;
@@ -253,7 +385,7 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
           for (int b = 0; b < M / 32; ++b) gv[b][i] = Elem<TG>::ld1(gr + 32 * b, goff);
         }
       }
-      tile_product<K, M>(Xt, Wl, r, hh, acc);
+      tile_mult<K, M>(Xt, Wl, r, hh, acc);
       // C[row = jrow(i,hh)][m = r + 32b]: 128-byte row segments
       uint32_t loff = (4u * hh * (uint32_t)ldy + r) * (uint32_t)sizeof(TY);
       int64_t sbase = tile * 32;
@@ -280,7 +412,7 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
     wave_sync_lds();
     store_rows<K, ACT, TX>(rg, lane, Xt);
     wave_sync_lds();
-    tile_product<K, M>(Xt, Wl, r, hh, acc);
+    tile_mult<K, M>(Xt, Wl, r, hh, acc);
 #pragma unroll
     for (int b = 0; b < M / 32; ++b)
 #pragma unroll
@@ -292,6 +424,58 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
           Elem<TY>::st1(y + row * ldy + r + 32 * b, 0u, v);
         }
       }
+  }
+}
+
+// One 32-row tile of the weight gradient: acc[a][b] (32 x 32 block of gw[M][K]) += G_tile^T X_tile, gbp[a] += column sums
+// of G.  f32 product: 16 steps of 2 rows on v_mfma_f32_32x32x2_f32.  Split-bf16 product (default): 2 steps of 16 rows on
+// v_mfma_f32_32x32x16_bf16 — both operands are data here, so both are split (three exact bf16 terms each, six partial
+// products, smallest first): per tile 96 column reads, 12 splits, 96 matrix instructions of 8 passes instead of 128 of 16.
+template <int K, int M>
+__device__ __forceinline__ void wgrad_tile(const float* Xt, const float* Gt, int r, int hh, f32x16 (&acc)[M / 32][K / 32],
+                                           float (&gbp)[M / 32]) {
+  constexpr int KS = K + 4, MS = M + 4;
+  if constexpr (kLinX3) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row0 = 16 * j + 8 * hh;
+      Split3 ga[M / 32], xb[K / 32];
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a) {
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { f[q] = Gt[(row0 + q) * MS + r + 32 * a]; gbp[a] += f[q]; }
+        ga[a] = split8(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]));
+      }
+#pragma unroll
+      for (int b = 0; b < K / 32; ++b) {
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = Xt[(row0 + q) * KS + r + 32 * b];
+        xb[b] = split8(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]));
+      }
+#define PG_W3(GT, XT)                                                                                     \
+      _Pragma("unroll") for (int a = 0; a < M / 32; ++a)                                                  \
+      _Pragma("unroll") for (int b = 0; b < K / 32; ++b)                                                  \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[a].GT, xb[b].XT, acc[a][b], 0, 0, 0);
+      PG_W3(lo, hi) PG_W3(hi, lo) PG_W3(mid, mid) PG_W3(mid, hi) PG_W3(hi, mid) PG_W3(hi, hi)
+#undef PG_W3
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = 2 * s + hh;
+      float av[M / 32], bv[K / 32];
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a) { av[a] = Gt[row * MS + r + 32 * a]; gbp[a] += av[a]; }
+#pragma unroll
+      for (int b = 0; b < K / 32; ++b) bv[b] = Xt[row * KS + r + 32 * b];
+#pragma unroll
+      for (int a = 0; a < M / 32; ++a)
+#pragma unroll
+        for (int b = 0; b < K / 32; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
   }
 }
 
@@ -336,20 +520,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const TG* __restrict_
     load_rows<K, TX>(x, ldx, n, (tile + stride) * 32, lane, rx);
     load_rows<M, TG>(g, ldg, n, (tile + stride) * 32, lane, rgm);
     wave_sync_lds();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int row = 2 * s + hh;
-      float av[M / 32], bv[K / 32];
-#pragma unroll
-      for (int a = 0; a < M / 32; ++a) { av[a] = Gt[row * MS + r + 32 * a]; gbp[a] += av[a]; }
-#pragma unroll
-      for (int b = 0; b < K / 32; ++b) bv[b] = Xt[row * KS + r + 32 * b];
-#pragma unroll
-      for (int a = 0; a < M / 32; ++a)
-#pragma unroll
-        for (int b = 0; b < K / 32; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
+    wgrad_tile<K, M>(Xt, Gt, r, hh, acc, gbp);
     wave_sync_lds();
   }
 #pragma unroll
@@ -539,15 +710,13 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void gen_linear_fwd_ker
     int64_t n_tiles) {
   constexpr int KS = K + 4;
   constexpr int WAVES = FwdGeo<K, M>::WAVES;
-  __shared__ __attribute__((aligned(16))) float lds[M * KS + WAVES * 32 * KS];
+  constexpr int WF = (WImg<K, M>::FLOATS + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float lds[WF + WAVES * 32 * KS];
   __shared__ __attribute__((aligned(16))) float acb[3 * K];
   float* Wl = lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float* Xt = lds + M * KS + wave * (32 * KS);
-  for (int i = threadIdx.x; i < M * (K / 4); i += WAVES * 64) {
-    const int m = i / (K / 4), k4 = i % (K / 4);
-    *reinterpret_cast<float4*>(Wl + m * KS + 4 * k4) = reinterpret_cast<const float4*>(w)[i];
-  }
+  float* Xt = lds + WF + wave * (32 * KS);
+  stage_w<K, M>(w, K, 1, Wl, WAVES * 64);
   gen_params<K>(w_emb, b_emb, w_in, b_in, D, acb, WAVES * 64);
   __syncthreads();
   const int q = lane % (K / 4);
@@ -565,7 +734,7 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void gen_linear_fwd_ker
     gen_store_rows<K>(rsv, lane, Xt, a4, c4, b4);
     rsv = gen_load(rvec, svec, n, (tile + stride) * 32, lane);
     wave_sync_lds();
-    tile_product<K, M>(Xt, Wl, r, hh, acc);
+    tile_mult<K, M>(Xt, Wl, r, hh, acc);
     if (tile * 32 + 32 <= n) {                     // wave-uniform: full tile, 128-byte row segments
       uint32_t loff = (4u * hh * (uint32_t)ldy + r) * (uint32_t)sizeof(float);
       int64_t sbase = tile * 32;
@@ -586,6 +755,96 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void gen_linear_fwd_ker
         }
     }
     wave_sync_lds();
+  }
+}
+
+// The forward product with the A operand generated IN REGISTERS (split-bf16 product only): lane (row r, half hh) of a
+// 32x32x16 step needs ELU(h[r][k]) for 8 consecutive k — from its own row's (r_i, s_i) and the 8 columns' (a, c, b_in),
+// read from LDS as three broadcast pairs of ds_read_b128.  No row tile, no shuffles, no wave barrier: the only LDS
+// residents are the weight images and the 3 K parameter floats, so 8 waves (two per SIMD) share a workgroup and hide each
+// other's exp / split phases.  Same values, same products, same order as gen_linear_fwd_kernel: bit-identical results.
+template <int K, int M>
+__global__ __launch_bounds__(512) void gen_linear_fwd_reg_kernel(
+    const float* __restrict__ rvec, const float* __restrict__ svec, const float* __restrict__ w_emb,
+    const float* __restrict__ b_emb, const float* __restrict__ w_in, const float* __restrict__ b_in, int D,
+    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int64_t ldy, int64_t n,
+    int64_t n_tiles) {
+  constexpr int WAVES = 8;
+  constexpr int WS = WImg<K, M>::WS, IMG = M * WS;
+  constexpr int WF = (WImg<K, M>::FLOATS + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float lds[WF];
+  __shared__ __attribute__((aligned(16))) float acb[3 * K];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  stage_w<K, M>(w, K, 1, lds, WAVES * 64);
+  gen_params<K>(w_emb, b_emb, w_in, b_in, D, acb, WAVES * 64);
+  __syncthreads();
+  const int r = lane & 31, hh = lane >> 5;
+  const unsigned short* wb = reinterpret_cast<const unsigned short*>(lds) + r * WS + 8 * hh;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  float bv[M / 32];
+#pragma unroll
+  for (int b = 0; b < M / 32; ++b) bv[b] = bias ? bias[r + 32 * b] : 0.f;
+  auto row_rs = [&](int64_t t, float& rv, float& sv) {
+    const int64_t row = t * 32 + r;
+    const bool in = row < n;
+    rv = in ? rvec[row] : 0.f;
+    sv = in ? svec[row] : 0.f;
+  };
+  float rv, sv;
+  row_rs(tile, rv, sv);
+  for (; tile < n_tiles; tile += stride) {
+    float rn, sn;
+    row_rs(tile + stride, rn, sn);
+    f32x16 acc[M / 32];
+#pragma unroll
+    for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < K / 16; ++i) {
+      const int k0 = 16 * i + 8 * hh;
+      bf16x8 wf[M / 32][3];
+#pragma unroll
+      for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) wf[b][t] = *reinterpret_cast<const bf16x8*>(wb + 32 * b * WS + 16 * i + t * IMG);
+      const float4 a0 = *reinterpret_cast<const float4*>(acb + k0), a1 = *reinterpret_cast<const float4*>(acb + k0 + 4);
+      const float4 c0 = *reinterpret_cast<const float4*>(acb + K + k0), c1 = *reinterpret_cast<const float4*>(acb + K + k0 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(acb + 2 * K + k0), b1 = *reinterpret_cast<const float4*>(acb + 2 * K + k0 + 4);
+      float4 x0, x1;
+      x0.x = elu1(gen_h(rv, sv, a0.x, c0.x, b0.x)); x0.y = elu1(gen_h(rv, sv, a0.y, c0.y, b0.y));
+      x0.z = elu1(gen_h(rv, sv, a0.z, c0.z, b0.z)); x0.w = elu1(gen_h(rv, sv, a0.w, c0.w, b0.w));
+      x1.x = elu1(gen_h(rv, sv, a1.x, c1.x, b1.x)); x1.y = elu1(gen_h(rv, sv, a1.y, c1.y, b1.y));
+      x1.z = elu1(gen_h(rv, sv, a1.z, c1.z, b1.z)); x1.w = elu1(gen_h(rv, sv, a1.w, c1.w, b1.w));
+      const Split3 a = split8(x0, x1);
+#define PG_X3(AT, WT)                                                                                     \
+      _Pragma("unroll") for (int b = 0; b < M / 32; ++b)                                                  \
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.AT, wf[b][WT], acc[b], 0, 0, 0);
+      PG_X3(lo, 0) PG_X3(hi, 2) PG_X3(mid, 1) PG_X3(mid, 0) PG_X3(hi, 1) PG_X3(hi, 0)
+#undef PG_X3
+    }
+    if (tile * 32 + 32 <= n) {                     // wave-uniform: full tile, 128-byte row segments
+      uint32_t loff = (4u * hh * (uint32_t)ldy + r) * (uint32_t)sizeof(float);
+      int64_t sbase = tile * 32;
+      pin(sbase, loff);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* yr = y + (sbase + (i & 3) + 8 * (i >> 2)) * ldy;
+#pragma unroll
+        for (int b = 0; b < M / 32; ++b) st_f32(yr + 32 * b, loff, acc[b][i] + bv[b]);
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < M / 32; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = tile * 32 + jrow(i, hh);
+          if (row < n) y[row * ldy + r + 32 * b] = acc[b][i] + bv[b];
+        }
+    }
+    rv = rn;
+    sv = sn;
   }
 }
 
@@ -632,20 +891,7 @@ __global__ __launch_bounds__(256) void gen_linear_wgrad_kernel(const float* __re
     rsv = gen_load(rvec, svec, n, (tile + stride) * 32, lane);
     load_rows<M, float>(g, ldg, n, (tile + stride) * 32, lane, rgm);
     wave_sync_lds();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int row = 2 * s + hh;
-      float av[M / 32], bv[K / 32];
-#pragma unroll
-      for (int a = 0; a < M / 32; ++a) { av[a] = Gt[row * MS + r + 32 * a]; gbp[a] += av[a]; }
-#pragma unroll
-      for (int b = 0; b < K / 32; ++b) bv[b] = Xt[row * KS + r + 32 * b];
-#pragma unroll
-      for (int a = 0; a < M / 32; ++a)
-#pragma unroll
-        for (int b = 0; b < K / 32; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
+    wgrad_tile<K, M>(Xt, Gt, r, hh, acc, gbp);
     wave_sync_lds();
   }
 #pragma unroll
@@ -685,16 +931,14 @@ __global__ __launch_bounds__((FwdGeo<KG, H>::WAVES * 64)) void gen_linear_dgrad_
     float* __restrict__ slabs) {
   constexpr int KS = KG + 4;
   constexpr int WAVES = FwdGeo<KG, H>::WAVES;
-  __shared__ __attribute__((aligned(16))) float lds[H * KS + WAVES * 32 * KS];
+  constexpr int WF = (WImg<KG, H>::FLOATS + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float lds[WF + WAVES * 32 * KS];
   __shared__ __attribute__((aligned(16))) float acb[3 * H];
   __shared__ float part[WAVES][3 * H];
   float* Wl = lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float* Xt = lds + H * KS + wave * (32 * KS);
-  for (int i = threadIdx.x; i < H * KG; i += WAVES * 64) {       // Wl[h][m] = W_out[m][h]
-    const int m = i / H, h = i % H;
-    Wl[h * KS + m] = w_out[i];
-  }
+  float* Xt = lds + WF + wave * (32 * KS);
+  stage_w<KG, H>(w_out, 1, H, Wl, WAVES * 64);                    // operand [H][KG]: element (h, m) = W_out[m][h]
   gen_params<H>(w_emb, b_emb, w_in, b_in, D, acb, WAVES * 64);
   __syncthreads();
   const int r = lane & 31, hh = lane >> 5;
@@ -716,7 +960,7 @@ __global__ __launch_bounds__((FwdGeo<KG, H>::WAVES * 64)) void gen_linear_dgrad_
     load_rows<KG, float>(g, ldg, n, (tile + stride) * 32, lane, rg);
     rsv = gen_load(rvec, svec, n, (tile + stride) * 32, lane);
     wave_sync_lds();
-    tile_product<KG, H>(Xt, Wl, r, hh, acc);
+    tile_mult<KG, H>(Xt, Wl, r, hh, acc);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = jrow(i, hh);
@@ -752,8 +996,17 @@ template <int K, int M>
 static int launch_gen_fwd(const float* r, const float* sv, const float* w_emb, const float* b_emb, const float* w_in,
                           const float* b_in, int D, const float* w, const float* bias, float* y, int64_t ldy, int64_t n,
                           hipStream_t s) {
-  constexpr int WAVES = FwdGeo<K, M>::WAVES;
   const int64_t n_tiles = (n + 31) / 32;
+  if constexpr (WImg<K, M>::X3) {
+    int64_t grid = (n_tiles + 7) / 8;
+    const int64_t cap = 2 * (int64_t)num_cus();      // two 8-wave workgroups per CU fit (weight images <= 56 KB each)
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL((gen_linear_fwd_reg_kernel<K, M>), dim3((unsigned)grid), dim3(512), 0, s, r, sv, w_emb, b_emb, w_in, b_in,
+                       D, w, bias, y, ldy, n, n_tiles);
+    PG_CHECK_LAUNCH("pangnn_embed_linear_fwd");
+    return 0;
+  }
+  constexpr int WAVES = FwdGeo<K, M>::WAVES;
   int64_t grid = (n_tiles + WAVES - 1) / WAVES;
   const int64_t cap = (int64_t)num_cus();
   if (grid > cap) grid = cap;
