@@ -439,7 +439,9 @@ def main():
                                      "six partial products; dL/dh1 and dL/dW2: the relu mask is the exact bf16 operand, the other "
                                      "operand is split three ways): logits within 1.6e-5 of an fp64 evaluation, gradients within 1e-6 "
                                      "of their scale (asserted: tests/test_hip_parity.py::test_decoder_training_kernels_vs_fp64); "
-                                     "strict_fp32 = the f32-MFMA step",
+                                     "strict_fp32 = the f32-MFMA decoder; the node-level dense layers use the same exact "
+                                     "three-term splits on the bf16 pipe (error vs fp64 1.2-2.5e-6 at unit scale, as the f32-MFMA "
+                                     "product they replaced; tools/time_linear.py)",
                        "first_layer": "conv_in(embedding(x)) evaluated by linearity: A_hat (x w^T + 1 b^T) W^T + b_in = r a^T + s c^T + "
                                       "b_in; the node vectors r = A_hat x, s = A_hat 1 come from ONE similarity-graph propagate per graph "
                                       "(in the warm-up, cached like gcn_norm); its [N, H] rows are generated inside conv_out's dense "
