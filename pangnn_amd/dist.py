@@ -444,6 +444,9 @@ class HipOps:
     def embed_conv_in(self, x_tab, w, b, w_in, b_in, st, norm):
         return PF.embed_conv_in(x_tab, w, b, w_in, b_in, st, norm)
 
+    def embed_conv_in_linear(self, x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):
+        return PF.embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm)
+
     def decoder(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3):
         return PF.decoder_mlp(p_full, q_local, st, extra, cvec, w2, b2, w3, b3)
 
@@ -588,9 +591,12 @@ class DistAlternateGCN(AlternateGCN):
             return self.ops.linear(x, w, b, in_act)
         return self.ops.linear(x, w, b, in_act, out_dtype)
 
-    def _conv(self, conv, h_local, shard, name, weight, wkey, tag, in_elu: bool = False):
-        """`in_elu`: h_local is the pre-activation of the deferred ELU (see AlternateGCN._encode_pre)"""
+    def _conv(self, conv, h_local, shard, name, weight, wkey, tag, in_elu: bool = False, dense_done: bool = False):
+        """`in_elu`: h_local is the pre-activation of the deferred ELU (see AlternateGCN._encode_pre);
+        `dense_done`: h_local already is conv.lin(...) of the layer's input (GCNConv.forward, dense_done)"""
         st, norm = self._st(shard, name), self._norm(shard, name, weight, wkey)
+        if dense_done:
+            return self.ops.propagate(self._table(h_local, shard, name), conv.bias, st, norm, tag)
         if in_elu and conv.in_channels < conv.out_channels:
             h_local, in_elu = F.elu(h_local), False
         if conv.in_channels < conv.out_channels:
@@ -602,6 +608,29 @@ class DistAlternateGCN(AlternateGCN):
         xw_full = self._table(xw, shard, name)
         return self.ops.propagate(xw_full, conv.bias, st, norm, tag)
 
+    def _xtab(self, shard, name):
+        """the scalar feature of every row the shard's `name` edges read (own + halo), exchanged once and cached"""
+        cache = shard.__dict__.setdefault("_dist_xtab", {})
+        key = (name, self.exchange)
+        if key not in cache:
+            with torch.no_grad():
+                cache[key] = self._table(shard.x.float().view(-1, 1), shard, name).view(-1).contiguous()
+        return cache[key]
+
+    def _embed_conv_in_then_dense(self, shard, name, weight, w_out, bias_out):
+        """AlternateGCN._embed_conv_in_then_dense on a shard: the first layer's rows of the OWN nodes generated inside the
+        dense layer that consumes them (node-level: no exchange involved); None where it does not apply"""
+        conv = self.conv_in
+        if self.sharded_embedding or not self.fuse_first_dense or not self._fold_elu() or not self.fuse_embedding \
+                or self.fuse_embedding == "propagate" or not hasattr(self.ops, "embed_conv_in_linear"):
+            return None
+        if w_out.shape[1] != conv.out_channels or not PF.embed_linear_supported(conv.out_channels, w_out.shape[0]) \
+                or PF.autocast_bf16(shard.x):
+            return None
+        st, norm = self._st(shard, name), self._norm(shard, name, weight, "w")
+        return self.ops.embed_conv_in_linear(self._xtab(shard, name), self.embedding.weight, self.embedding.bias,
+                                             conv.lin.weight, conv.bias, w_out, bias_out, st, norm)
+
     def _embed_conv_in(self, shard, name, weight):
         """conv_in(embedding(x)): x is constant, so the scalar features of the halo rows are exchanged once
         (cached on the shard) and the first layer runs without any per-step exchange, forward or backward."""
@@ -611,16 +640,12 @@ class DistAlternateGCN(AlternateGCN):
             return self._conv(conv, self.embedding.weight, shard, name, weight, "w", name)
         rank2 = self.fuse_embedding and self.fuse_embedding != "propagate" and hasattr(self.ops, "embed_conv_in")
         if rank2 or (conv.in_channels < conv.out_channels and self.fuse_embedding and hasattr(self.ops, "embed_propagate")):
-            cache = shard.__dict__.setdefault("_dist_xtab", {})
-            key = (name, self.exchange)
-            if key not in cache:
-                with torch.no_grad():
-                    cache[key] = self._table(shard.x.float().view(-1, 1), shard, name).view(-1).contiguous()
+            xtab = self._xtab(shard, name)
             st, norm = self._st(shard, name), self._norm(shard, name, weight, "w")
             if rank2:      # the whole layer by linearity (functional._EmbedConvIn): r = A_hat x, s = A_hat 1 of the OWN rows
-                return self.ops.embed_conv_in(cache[key], self.embedding.weight, self.embedding.bias, conv.lin.weight,
+                return self.ops.embed_conv_in(xtab, self.embedding.weight, self.embedding.bias, conv.lin.weight,
                                               conv.bias, st, norm)
-            agg = self.ops.embed_propagate(cache[key], self.embedding.weight, self.embedding.bias, st, norm, name)
+            agg = self.ops.embed_propagate(xtab, self.embedding.weight, self.embedding.bias, st, norm, name)
             return self._linear(agg, conv.lin.weight, conv.bias)
         h = shard.x.float().view(-1, 1) * self.embedding.weight.view(1, -1) + self.embedding.bias
         return self._conv(conv, h, shard, name, weight, "w", name)
@@ -636,11 +661,19 @@ class DistAlternateGCN(AlternateGCN):
                 h = self._conv(self.conv_hidden, pre(h), shard, "union", w, "w", "union", in_elu=fold)
             h = self._conv(self.conv_out, pre(h), shard, "union", None, "1", "union", in_elu=fold)
         elif fl.base_model:
-            h = self._embed_conv_in(shard, "sim", shard.edge_attr)
-            h = self._linear(pre(h), self.linear_out.weight, self.linear_out.bias, 1 if fold else 0)
+            h = self._embed_conv_in_then_dense(shard, "sim", shard.edge_attr, self.linear_out.weight, self.linear_out.bias)
+            if h is None:
+                h = self._embed_conv_in(shard, "sim", shard.edge_attr)
+                h = self._linear(pre(h), self.linear_out.weight, self.linear_out.bias, 1 if fold else 0)
         else:
-            h = self._embed_conv_in(shard, "sim", shard.edge_attr)
-            h = self._conv(self.conv_out, pre(h), shard, "nb", None, "1", "nb", in_elu=fold)
+            out = self.conv_out
+            y = self._embed_conv_in_then_dense(shard, "sim", shard.edge_attr, out.lin.weight, None) \
+                if out.in_channels >= out.out_channels else None
+            if y is not None:
+                h = self._conv(out, y, shard, "nb", None, "1", "nb", dense_done=True)
+            else:
+                h = self._embed_conv_in(shard, "sim", shard.edge_attr)
+                h = self._conv(out, pre(h), shard, "nb", None, "1", "nb", in_elu=fold)
         return h, True
 
     def encode(self, shard):
