@@ -123,6 +123,8 @@ __device__ __forceinline__ void load_rows(const T* __restrict__ src, int64_t ld,
 // ELU (alpha = 1) and its derivative, both as functions of the PRE-activation value
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) - 1.f; }   // v_exp_f32: 2 ulp, abs 1e-7
 __device__ __forceinline__ float elu1_grad(float v) { return v > 0.f ? 1.f : __expf(v); }
+// one value of the first layer by linearity, h = r a + s c + b_in (embed_conv_in_rows_kernel's two fused multiply-adds)
+__device__ __forceinline__ float gen_h(float rv, float sv, float a, float c, float b) { return fmaf(rv, a, fmaf(sv, c, b)); }
 
 // ACT = 1: the rows go through ELU on their way to LDS, i.e. the kernel multiplies elu(x) without elu(x) ever
 // existing in HBM (gnn.py:131-166: every activation of the encoder is followed by exactly one dense layer)
@@ -479,6 +481,46 @@ __device__ __forceinline__ void wgrad_tile(const float* Xt, const float* Gt, int
   }
 }
 
+// wgrad_tile's split-bf16 form with the X operand GENERATED in registers (functional._EmbedConvInLinear): lane (column
+// k = r + 32 b, row half hh) forms ELU(h[row][k]) for its 8 rows of a 16-row step from the rows' (r, s) — broadcast reads of
+// the wave's 64-float rs tile — and its own columns' (a, c, b_in).  Same values, same splits, same matrix instructions in
+// the same order as wgrad_tile over a stored tile: bit-identical accumulators, no [32][K] tile, no shuffles.
+template <int K, int M>
+__device__ __forceinline__ void gen_wgrad_tile_x3(const float* Gt, const float* rs, const float (&ca)[K / 32],
+                                                  const float (&cc)[K / 32], const float (&cb)[K / 32], int r, int hh,
+                                                  f32x16 (&acc)[M / 32][K / 32], float (&gbp)[M / 32]) {
+  constexpr int MS = M + 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row0 = 16 * j + 8 * hh;
+    const float4 R0 = *reinterpret_cast<const float4*>(rs + row0), R1 = *reinterpret_cast<const float4*>(rs + row0 + 4);
+    const float4 S0 = *reinterpret_cast<const float4*>(rs + 32 + row0), S1 = *reinterpret_cast<const float4*>(rs + 32 + row0 + 4);
+    const float rr[8] = {R0.x, R0.y, R0.z, R0.w, R1.x, R1.y, R1.z, R1.w};
+    const float ss[8] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w};
+    Split3 ga[M / 32], xb[K / 32];
+#pragma unroll
+    for (int a = 0; a < M / 32; ++a) {
+      float f[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { f[q] = Gt[(row0 + q) * MS + r + 32 * a]; gbp[a] += f[q]; }
+      ga[a] = split8(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]));
+    }
+#pragma unroll
+    for (int b = 0; b < K / 32; ++b) {
+      float f[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = elu1(gen_h(rr[q], ss[q], ca[b], cc[b], cb[b]));
+      xb[b] = split8(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]));
+    }
+#define PG_W3(GT, XT)                                                                                     \
+    _Pragma("unroll") for (int a = 0; a < M / 32; ++a)                                                    \
+    _Pragma("unroll") for (int b = 0; b < K / 32; ++b)                                                    \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[a].GT, xb[b].XT, acc[a][b], 0, 0, 0);
+    PG_W3(lo, hi) PG_W3(hi, lo) PG_W3(mid, mid) PG_W3(mid, hi) PG_W3(hi, mid) PG_W3(hi, hi)
+#undef PG_W3
+  }
+}
+
 template <int K, int M>
 struct WgradGeo {
   static constexpr int SLAB = M * K + M;     // gw | gb
@@ -680,8 +722,6 @@ __device__ __forceinline__ float gen_load(const float* __restrict__ rv, const fl
   return row < n ? p[row] : 0.f;
 }
 
-__device__ __forceinline__ float gen_h(float rv, float sv, float a, float c, float b) { return fmaf(rv, a, fmaf(sv, c, b)); }
-
 // the [32][C+4] LDS tile of ELU(h) for the 32 rows whose (r, s) sit in `rsv` (gen_load)
 template <int C>
 __device__ __forceinline__ void gen_store_rows(float rsv, int lane, float* tile, float4 a4, float4 c4, float4 b4) {
@@ -870,6 +910,9 @@ __global__ __launch_bounds__(256) void gen_linear_wgrad_kernel(const float* __re
   const float4 a4 = *reinterpret_cast<const float4*>(acb + 4 * q), c4 = *reinterpret_cast<const float4*>(acb + K + 4 * q);
   const float4 b4 = *reinterpret_cast<const float4*>(acb + 2 * K + 4 * q);
   const int r = lane & 31, hh = lane >> 5;
+  float ca[K / 32], cc[K / 32], cb[K / 32];      // (a, c, b_in) of this lane's columns r + 32 b (split-bf16 form)
+#pragma unroll
+  for (int b = 0; b < K / 32; ++b) { ca[b] = acb[r + 32 * b]; cc[b] = acb[K + r + 32 * b]; cb[b] = acb[2 * K + r + 32 * b]; }
   f32x16 acc[M / 32][K / 32];
   float gbp[M / 32];
 #pragma unroll
@@ -886,12 +929,14 @@ __global__ __launch_bounds__(256) void gen_linear_wgrad_kernel(const float* __re
   float rsv = gen_load(rvec, svec, n, tile * 32, lane);
   load_rows<M, float>(g, ldg, n, tile * 32, lane, rgm);
   for (; tile < n_tiles; tile += stride) {
-    gen_store_rows<K>(rsv, lane, Xt, a4, c4, b4);
+    if constexpr (kLinX3) Xt[lane] = rsv;                   // the tile's (r, s): the X operand is formed in registers
+    else gen_store_rows<K>(rsv, lane, Xt, a4, c4, b4);
     store_rows<M, 0, float>(rgm, lane, Gt);                 // rows >= n are zero: their generated x contributes nothing
     rsv = gen_load(rvec, svec, n, (tile + stride) * 32, lane);
     load_rows<M, float>(g, ldg, n, (tile + stride) * 32, lane, rgm);
     wave_sync_lds();
-    wgrad_tile<K, M>(Xt, Gt, r, hh, acc, gbp);
+    if constexpr (kLinX3) gen_wgrad_tile_x3<K, M>(Gt, Xt, ca, cc, cb, r, hh, acc, gbp);
+    else wgrad_tile<K, M>(Xt, Gt, r, hh, acc, gbp);
     wave_sync_lds();
   }
 #pragma unroll
