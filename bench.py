@@ -163,6 +163,11 @@ def minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd):
     for k in range(warmup):
         steps_fn[k % len(batches)]()
     torch.cuda.synchronize()
+    # a host-bound step: keep the interpreter's cyclic collector from re-walking the (large, static) heap the data set
+    # construction left behind during the timed steps — collect once now and move the survivors out of its generations
+    import gc
+    gc.collect()
+    gc.freeze()
     t0 = time.perf_counter()
     edges = 0
     for k in range(args.steps):

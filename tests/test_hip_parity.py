@@ -1177,7 +1177,8 @@ def test_fused_embedding_layer_equals_layerwise_form_and_oracle(flags, dims):
 
 # ---------------------------------------------------------------- first layer generated inside the next dense layer
 @pytest.mark.parametrize("h,m", [(64, 64), (64, 128), (128, 64)])
-@pytest.mark.parametrize("n,bias", [(1, True), (31, False), (32, True), (33, False), (1000, True), (40007, False), (70016, True)])
+@pytest.mark.parametrize("n,bias", [(1, True), (31, False), (32, True), (33, False), (1000, True), (40007, False), (70016, True),
+                                    (1000003, False)])
 def test_first_layer_generated_inside_the_next_dense_layer(h, m, n, bias):
     """functional.embed_conv_in_linear (pangnn_embed_linear_fwd / _bwd: the [N, H] rows of conv_in(embedding(x)) generated
     inside the dense layer's kernels) against the two-operator form linear(embed_conv_in(...), in_act=1): the forward and
@@ -1186,6 +1187,8 @@ def test_first_layer_generated_inside_the_next_dense_layer(h, m, n, bias):
     Row counts around the 32-row tile, one wave's share, and more tiles than one pass of the grid."""
     from pangnn_amd import functional as PF
     from pangnn_amd.graph import EdgeStructure
+    if n > 100000 and (h, m) != (128, 64):
+        pytest.skip("BASELINE's node count: the headline widths only")
     d = 64
     gen = torch.Generator().manual_seed(7 * n + h + m)
     e = max(4 * n, 8)
