@@ -420,7 +420,7 @@ def main():
         step_s = dt / args.steps
         # run-part rows written by the decoder's S (by source) and T (by target) kernels on this graph
         st_sim = getattr(graph, "_pangnn_structs", {}).get("sim", (None, None))[1]
-        ct = PF.d16_chunk()
+        ct = PF.d16_chunk(st_sim.num_edges) if st_sim is not None else PF.d16_chunk()
         pl_s = st_sim.runsum_plan(ct) if st_sim is not None else None
         pl_d = st_sim.csr_plan("dst", ct) if st_sim is not None else None
         n_parts_s = pl_s.n_parts_exact() if pl_s is not None else 0        # (the buffers are sized by an upper bound)

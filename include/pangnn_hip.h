@@ -64,7 +64,7 @@ const void* pangnn_csr_build_flag_ptr(void* workspace, int64_t num_edges);
 /* Small graphs — one mini-batch of sub-graphs (reference regime: DataLoader batches of 32 sub-graphs, pangnn.py:152-216,
  * collated by PyG's Batch): BOTH CSR orders of pangnn_csr_build (same stable order: identical rowptr / other / perm) and,
  * for each order, the int32 sorted keys and the run-sum plan over chunks of `chunk_edges` consecutive sorted positions
- * (the `part_off` / part row pointers the decoder's S / T kernels take, chunk_edges = 32 * pangnn_decoder_chunk_tiles()),
+ * (the `part_off` / part row pointers the decoder's S / T kernels take, chunk_edges = 32 * pangnn_decoder_chunk_tiles_for(E)),
  * in ONE launch.  part_off_*[ceil(E / chunk_edges)], part_rowptr_*[N+1], last_part_*[1] = number of parts - 1.
  * bad_flag[0] (device) = 1 if a node id was outside [0, N) (clamped).  Limits: pangnn_structure_small_supported(E, N). */
 int pangnn_structure_small_supported(int64_t num_edges, int64_t num_nodes);
@@ -245,7 +245,7 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  *   what lets two waves share a SIMD without spilling),
  *   rec[E][8] uint32 (required): per edge {4 dwords of relu masks, dL/dlogit_e, 3 unused} for the dgrad pass,
  *   part_buf / part_off (both NULL or both set; edge list sorted by source): sums of dL/dh1 over every
- *   (chunk, source) run, where a chunk is pangnn_decoder_chunk_tiles() (= 16) consecutive 32-edge tiles walked by
+ *   (chunk, source) run, where a chunk is pangnn_decoder_chunk_tiles_for(num_edges) (16 for E >= 1e6, down to 1 for short lists) consecutive 32-edge tiles walked by
  *   one wave with the open run carried from tile to tile: part_off[c] = index of chunk c's first part row, a new
  *   part starts at every chunk start and at every change of the key (pangnn_decoder_mlp_bwd_f32 uses the same layout
  *   with one-tile chunks).  Chunks are a property of the edge list, not of the launch: results do not depend on the
@@ -266,6 +266,10 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  * Both are reproducible (fixed-order sums, no float atomics).
  * ---------------------------------------------------------------------------------------- */
 int    pangnn_decoder_chunk_tiles(void);
+/* ... as a function of the list: pangnn_decoder_chunk_tiles() (16) for lists of >= 2048 * 16 tiles, halved until the list
+ * has at least 2048 chunks (1 for a mini-batch): the S / T kernels derive the same value from num_edges, and `part_off` /
+ * `part_buf` must be laid out for it. */
+int    pangnn_decoder_chunk_tiles_for(int64_t num_edges);
 size_t pangnn_decoder_train_workspace_bytes(void);
 int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_t ldq, int64_t num_nodes,
                              const int64_t* edge_index, int64_t ld, int64_t num_edges, const float* extra,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "pangnn_softmax_qscore_f64": (C.c_int, [_p, _p, _i64, _i64, C.c_double, C.c_double, C.c_double, _p, _p]),
     # two-wave-per-SIMD training decoder (csrc/decoder16.hip): S kernel (+ by-source run sums, per-edge records)
     "pangnn_decoder_chunk_tiles": (C.c_int, []),
+    "pangnn_decoder_chunk_tiles_for": (C.c_int, [_i64]),
     "pangnn_decoder_train_workspace_bytes": (_sz, []),
     "pangnn_decoder_train_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
                                            _p, _p, _i64, _p,                        # y, pos_weight, denom, g_logits

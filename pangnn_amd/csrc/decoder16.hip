@@ -40,18 +40,26 @@ constexpr int S_WAVES = 4;
 #else
 constexpr int S_WAVES = 8;                            // 512 threads, one workgroup per CU, two waves per SIMD
 #endif
-// Run sums are taken per CHUNK of 2^D16_CHUNK_LOG consecutive 32-edge tiles: a wave walks the tiles of a chunk in order and
+// Run sums are taken per CHUNK of 2^chunk_log consecutive 32-edge tiles: a wave walks the tiles of a chunk in order and
 // carries an open run from tile to tile, so a run only ends where its key changes or the chunk ends — one part row per
 // (chunk, key) run (N + E / 512 rows instead of one per (tile, key) run, N + E / 32), and most half tiles have no
 // boundary to handle at all.  Chunk boundaries depend on the edge list alone, never on the grid: results stay
 // independent of the number of workgroups.
-constexpr int D16_CHUNK_LOG = 4;
-constexpr int D16_CHUNK = 1 << D16_CHUNK_LOG;
+// The chunk size is a function of the edge count alone (chunk_log_for below): 16 tiles where that still gives every wave of
+// the chip several chunks (E >= 1e6), fewer for short lists — a mini-batch of 2 000 edges as ONE chunk per tile runs on 63
+// waves instead of 4 (S 138 -> 19 us, T 63 -> 15 us at E = 2 000: its waves walked 16 tiles each, one after the other).
+constexpr int D16_CHUNK_LOG_MAX = 4;
+constexpr int64_t D16_MIN_CHUNKS = 2048;               // waves of one full launch (256 CUs x 8)
+static inline int chunk_log_for(int64_t n_tiles) {
+  int c = D16_CHUNK_LOG_MAX;
+  while (c > 0 && (n_tiles >> c) < D16_MIN_CHUNKS) --c;
+  return c;
+}
 // the wave's next tile: the next one of its chunk, or the first of the chunk `cstride` chunks on
-__device__ __forceinline__ int64_t next_tile(int64_t tile, int64_t cstride, int64_t n_tiles, bool& last) {
+__device__ __forceinline__ int64_t next_tile(int64_t tile, int64_t cstride, int64_t n_tiles, bool& last, int clog) {
   const int64_t t1 = tile + 1;
-  last = (t1 & (D16_CHUNK - 1)) == 0 || t1 >= n_tiles;
-  return last ? ((tile >> D16_CHUNK_LOG) + cstride) << D16_CHUNK_LOG : t1;
+  last = (t1 & ((1 << clog) - 1)) == 0 || t1 >= n_tiles;
+  return last ? ((tile >> clog) + cstride) << clog : t1;
 }
 constexpr int T_WAVES = 16;                           // dgrad kernel: four waves per SIMD (128 registers each): its record gathers are latency bound
 
@@ -182,7 +190,7 @@ struct D16Params {
   const float* w2; const float* b2; const float* w3; const float* b3;
 };
 struct D16Loss { const float* y; const float* pos_weight; float inv_denom; };
-struct D16Run { float* part; const int32_t* part_off; };
+struct D16Run { float* part; const int32_t* part_off; int chunk_log; };   // chunk_log: tiles per chunk = 1 << chunk_log
 
 __device__ __forceinline__ float4 ld_row16(const void* table, uint32_t byte_off) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table) + byte_off);
@@ -666,25 +674,26 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   uint32_t one2 = 0x00010001u;             // opaque to the optimiser: the packed min against it stays ONE v_pk_min_u16 (a
   asm volatile("" : "+v"(one2));           // literal is rewritten as compares + selects); the statement emits no instruction
 
-  const int64_t cstride = (int64_t)gridDim.x * S_WAVES;                // in chunks of D16_CHUNK tiles
-  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) >> D16_CHUNK_LOG;
-  int64_t tile = ((int64_t)blockIdx.x * S_WAVES + wave) << D16_CHUNK_LOG;
+  const int clog = rs.chunk_log;                                        // uniform: tiles per chunk = 1 << clog
+  const int64_t cstride = (int64_t)gridDim.x * S_WAVES;                // in chunks
+  const int64_t n_chunks = (n_tiles + (1 << clog) - 1) >> clog;
+  int64_t tile = ((int64_t)blockIdx.x * S_WAVES + wave) << clog;
   HalfIn in_cur = load_half<EXTRA>(a, auxp, tile, n_tiles, 0, c);
   HalfRowsT<PQ16> rows;
   issue_half_rows(a, in_cur, g, rows);
-  int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile >> D16_CHUNK_LOG] : 0;
+  int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile >> clog] : 0;
   float carry = 0.f;
   int64_t pidx = 0;
 
   while (tile < n_tiles) {
     // chunk bookkeeping as selects (no branch in the loop body): a chunk's first tile starts from its part offset with
     // no open run; the offset of the wave's next chunk is fetched every tile (one cached dword) and taken over at the end
-    const bool first_of_chunk = (tile & (D16_CHUNK - 1)) == 0;
+    const bool first_of_chunk = (tile & ((1 << clog) - 1)) == 0;
     carry = first_of_chunk ? 0.f : carry;
     pidx = first_of_chunk ? (int64_t)__builtin_amdgcn_readfirstlane(poff_cur) : pidx;
     bool last_tile;
-    const int64_t tile_nxt = next_tile(tile, cstride, n_tiles, last_tile);
-    const int64_t chunk_nxt = (tile >> D16_CHUNK_LOG) + cstride;
+    const int64_t tile_nxt = next_tile(tile, cstride, n_tiles, last_tile, clog);
+    const int64_t chunk_nxt = (tile >> clog) + cstride;
     const int poff_nxt = RUNSUM ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
     const int live_lim = (int)min((int64_t)31, a.E - 1 - tile * 32);   // uniform: positions <= live_lim are real edges
     uint32_t* rec_tile = rec + tile * 256;                             // 8 dwords per edge (rec is required)
@@ -980,32 +989,33 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) gb2a[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int64_t cstride = (int64_t)gridDim.x * T_WAVES;                // in chunks of D16_CHUNK tiles
-  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) >> D16_CHUNK_LOG;
-  int64_t tile = ((int64_t)blockIdx.x * T_WAVES + wave) << D16_CHUNK_LOG;
+  const int clog = rs.chunk_log;
+  const int64_t cstride = (int64_t)gridDim.x * T_WAVES;                // in chunks
+  const int64_t n_chunks = (n_tiles + (1 << clog) - 1) >> clog;
+  int64_t tile = ((int64_t)blockIdx.x * T_WAVES + wave) << clog;
   // pipeline over the wave's tiles: records of tile n + 1 and ids of tile n + 2 in flight under tile n
   TIn cur[2];
   TIds ids_nxt[2];
   bool last1;
-  int64_t tile1 = next_tile(tile, cstride, n_tiles, last1);            // the wave's next tile
+  int64_t tile1 = next_tile(tile, cstride, n_tiles, last1, clog);      // the wave's next tile
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     cur[h] = load_rec<EXTRA>(rec, extra, load_ids<PERM>(perm, keys, E, tile, n_tiles, h, c), g);
     ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile1, n_tiles, h, c);
   }
-  int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile >> D16_CHUNK_LOG] : 0;
+  int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile >> clog] : 0;
   float carry = 0.f;
   int64_t pidx = 0;
   while (tile < n_tiles) {
-    const bool first_of_chunk = (tile & (D16_CHUNK - 1)) == 0;
+    const bool first_of_chunk = (tile & ((1 << clog) - 1)) == 0;
     carry = first_of_chunk ? 0.f : carry;
     pidx = first_of_chunk ? (int64_t)__builtin_amdgcn_readfirstlane(poff_cur) : pidx;
     const bool last_tile = last1;                                      // this tile ends its chunk
-    const int64_t chunk_nxt = (tile >> D16_CHUNK_LOG) + cstride;
+    const int64_t chunk_nxt = (tile >> clog) + cstride;
     const int poff_nxt = run ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
     const int live_lim = (int)min((int64_t)31, E - 1 - tile * 32);
     bool last2;
-    const int64_t tile2 = next_tile(tile1 < n_tiles ? tile1 : n_tiles - 1, cstride, n_tiles, last2);
+    const int64_t tile2 = next_tile(tile1 < n_tiles ? tile1 : n_tiles - 1, cstride, n_tiles, last2, clog);
     TIn nxt[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1225,7 +1235,10 @@ extern "C" int pangnn_debug_set_v(float* ptr) {
 }
 #endif
 
-extern "C" int pangnn_decoder_chunk_tiles(void) { return D16_CHUNK; }
+extern "C" int pangnn_decoder_chunk_tiles(void) { return 1 << D16_CHUNK_LOG_MAX; }
+extern "C" int pangnn_decoder_chunk_tiles_for(int64_t num_edges) {
+  return 1 << chunk_log_for(num_edges <= 0 ? 0 : (num_edges + 31) / 32);
+}
 
 extern "C" size_t pangnn_decoder_train_workspace_bytes(void) { return (size_t)cu_count() * SLAB16 * sizeof(float); }
 
@@ -1276,7 +1289,8 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
                who);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (num_edges + 31) / 32;
-  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) / D16_CHUNK;     // a wave takes whole chunks of tiles
+  const int clog = chunk_log_for(n_tiles);                             // = pangnn_decoder_chunk_tiles_for(num_edges)
+  const int64_t n_chunks = (n_tiles + (1 << clog) - 1) >> clog;        // a wave takes whole chunks of tiles
   int64_t grid = (n_chunks + S_WAVES - 1) / S_WAVES;
   const int cus = cu_count();
   if (grid > cus) grid = cus;
@@ -1296,7 +1310,7 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
     const uint32_t esz = pq16 ? 2u : 4u;
     D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
     const D16Loss lp{y, pos_weight, y ? 1.0f / (float)denom : 0.f};
-    const D16Run rs{part_buf, part_off};
+    const D16Run rs{part_buf, part_off, clog};
     const dim3 gd((unsigned)grid), bd(S_WAVES * 64);
 #define PG_S2(F, R, H)                                                                                              \
   do {                                                                                                              \
@@ -1359,13 +1373,14 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
   PG_CHECK_ARG(part_buf || g_b2 || g_cvec, PANGNN_E_BADARG, "%s: nothing to compute", who);
   PG_CHECK_ARG(!g_cvec || (extra && part_buf), PANGNN_E_BADARG, "%s: g_cvec needs extra and the run-sum pass", who);
   const int64_t n_tiles = (num_edges + 31) / 32;
-  const int64_t n_chunks = (n_tiles + D16_CHUNK - 1) / D16_CHUNK;
+  const int clog = chunk_log_for(n_tiles);
+  const int64_t n_chunks = (n_tiles + (1 << clog) - 1) >> clog;
   int64_t grid = (n_chunks + T_WAVES - 1) / T_WAVES;
   const int cus = cu_count();
   if (grid > cus) grid = cus;
   PG_CHECK_ARG(!(g_cvec || g_b2) || (workspace && workspace_bytes >= (size_t)grid * 128 * sizeof(float)),
                PANGNN_E_WORKSPACE, "%s: workspace too small", who);
-  const D16Run rs{part_buf, part_off};
+  const D16Run rs{part_buf, part_off, clog};
   float* cv_slabs = g_cvec ? static_cast<float*>(workspace) : nullptr;
   float* b2_slabs = g_b2 ? static_cast<float*>(workspace) + (size_t)grid * 64 : nullptr;
 #define PG_T(P, X)                                                                                                 \

@@ -357,15 +357,11 @@ def segment_sum(msg, st: EdgeStructure):
     return _SegmentSum.apply(msg, st)
 
 
-_D16_CHUNK = None
-
-
-def d16_chunk() -> int:
-    """tiles per run-sum chunk of the S / T kernels (pangnn_decoder_chunk_tiles)"""
-    global _D16_CHUNK
-    if _D16_CHUNK is None:
-        _D16_CHUNK = int(_lib.load().pangnn_decoder_chunk_tiles())
-    return _D16_CHUNK
+def d16_chunk(num_edges: Optional[int] = None) -> int:
+    """tiles per run-sum chunk of the S / T kernels for a list of `num_edges` edges (pangnn_decoder_chunk_tiles_for: 16 for
+    E >= 1e6, fewer for short lists so that a mini-batch still spreads over the chip); None: the maximum"""
+    lib = _lib.load()
+    return int(lib.pangnn_decoder_chunk_tiles() if num_edges is None else lib.pangnn_decoder_chunk_tiles_for(int(num_edges)))
 
 
 def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor) -> torch.Tensor:
@@ -385,7 +381,7 @@ def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 
     (one call per step asks for it); by = None: the parameter sums alone."""
     lib = _lib.load()
     dev = rec.device
-    plan = st.csr_plan(by, d16_chunk()) if by else None
+    plan = st.csr_plan(by, d16_chunk(st.num_edges)) if by else None
     csr = None if not by else (st.by_dst if by == "dst" else st.by_src)
     parts = None if plan is None else torch.empty(plan.n_parts, 64, dtype=torch.float32, device=dev)
     with _lib.device_guard(dev):
@@ -422,7 +418,7 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
     g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
     g_cv = None if cv is None else torch.empty_like(cv)
     rec = torch.empty(max(e, 1), 8, dtype=torch.int32, device=dev)
-    plan = st.runsum_plan(d16_chunk()) if (need_p and e > 0) else None
+    plan = st.runsum_plan(d16_chunk(e)) if (need_p and e > 0) else None
     parts = None if plan is None else torch.empty(plan.n_parts, d, dtype=torch.float32, device=dev)
     with _lib.device_guard(dev):
         ws_bytes = lib.pangnn_decoder_train_workspace_bytes()

@@ -98,7 +98,7 @@ class EdgeStructure:
         e, n = self.num_edges, self.num_nodes
         if not lib.pangnn_structure_small_supported(e, n):
             return False
-        ct = int(lib.pangnn_decoder_chunk_tiles())
+        ct = int(lib.pangnn_decoder_chunk_tiles_for(e))
         span = 32 * ct
         nc = (e + span - 1) // span
         dev = self.edge_index.device

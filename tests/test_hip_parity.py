@@ -67,7 +67,7 @@ def test_small_structure_build_equals_the_general_build(n, e, seed, sort_src):
     if sort_src:
         ei = ei[:, torch.argsort(ei[0], stable=True)]
     ei = ei.to(dev())
-    ct = PF.d16_chunk()
+    ct = PF.d16_chunk(e)
     small = G.EdgeStructure(ei, n, hints={"sorted_by_src": sort_src})
     assert small._small_build() and small._small_built
     old, G.SMALL_STRUCTURE = G.SMALL_STRUCTURE, False
@@ -865,7 +865,7 @@ def test_full_size_S_and_T_kernels_agree_on_by_source_sums(skip):
     # kernel gathers through it all the same) — and once more through S for run-to-run reproducibility
     rec = torch.empty(e, 8, dtype=torch.int32, device=dev())
     lib = PF._lib.load()
-    plan = st.runsum_plan(PF.d16_chunk())
+    plan = st.runsum_plan(PF.d16_chunk(e))
     parts = torch.empty(plan.n_parts, 64, device=dev())
     outs = [torch.empty_like(W2), torch.empty_like(w3), torch.empty_like(b3)]
     ws = torch.empty(lib.pangnn_decoder_train_workspace_bytes(), dtype=torch.uint8, device=dev())

@@ -34,7 +34,7 @@ def run(e, srt, skip, n=97, seed=None):
     t = lambda x: None if x is None else x.to(dev).contiguous()
     p_, q_, w2_, b2_, w3_, b3_, cv_, ex_, g_ = map(t, (P, Q, W2, b2, w3, b3, cv if skip else None, extra, g))
     rec = torch.zeros(e, 8, dtype=torch.int32, device=dev)
-    plan = st.runsum_plan(int(_lib.load().pangnn_decoder_chunk_tiles()))
+    plan = st.runsum_plan(int(_lib.load().pangnn_decoder_chunk_tiles_for(st.num_edges)))
     parts = None if plan is None else torch.full((plan.n_parts, d), float("nan"), device=dev)
     gw2, gb2, gw3, gb3 = torch.empty_like(w2_), torch.empty_like(b2_), torch.empty_like(w3_), torch.empty_like(b3_)
     gcv = None if not skip else torch.empty_like(cv_)

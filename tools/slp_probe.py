@@ -23,7 +23,7 @@ ONLY = set(sys.argv[3:])
 g = simulate.simulate_graph(genes, 20, 0.2, 100, 20, seed=0, device=dev)
 n, e = g.num_nodes, g.edge_index.shape[1]
 st = structure_of(g.edge_index, n, holder=g, name="sim")
-plan = st.runsum_plan(int(_lib.load().pangnn_decoder_chunk_tiles()))
+plan = st.runsum_plan(int(_lib.load().pangnn_decoder_chunk_tiles_for(st.num_edges)))
 assert plan is not None
 torch.manual_seed(0)
 P, Q = torch.randn(n, 64, device=dev), torch.randn(n, 64, device=dev)

@@ -20,7 +20,7 @@ genes = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 g = simulate.simulate_graph(genes, 20, 0.2, 100, 20, seed=0, device=dev)
 n, e = g.num_nodes, g.edge_index.shape[1]
 st = structure_of(g.edge_index, n, holder=g, name="sim")
-plan = st.runsum_plan(int(_lib.load().pangnn_decoder_chunk_tiles()))
+plan = st.runsum_plan(int(_lib.load().pangnn_decoder_chunk_tiles_for(st.num_edges)))
 torch.manual_seed(0)
 P, Q = torch.randn(n, 64, device=dev), torch.randn(n, 64, device=dev)
 W2, b2, w3, b3 = torch.randn(64, 64, device=dev) / 8, torch.randn(64, device=dev), torch.randn(64, device=dev), torch.randn(1, device=dev)
