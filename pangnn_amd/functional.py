@@ -1046,3 +1046,41 @@ def embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):
         return torch_ops.embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm)
     return _EmbedConvInLinear.apply(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm)
 
+
+class _PQOperands(torch.autograd.Function):
+    """mlp[0] = Linear(2D (+1), D) of the decoder (gnn.py:110,173-175) re-arranged for the node-level P | Q product:
+    w_pq = [W[:, :D] ; W[:, D:2D]]  ([2D, D]),  b_pq = [0 ; b]  ([2D]),  cvec = W[:, 2D]  (skip connections only).
+    Forward is two or three small copies; backward assembles dL/dW with ONE concatenation (autograd's own rules for the three
+    slices cost two zero-fills, two strided copies and two additions per step: a fifth of a replayed mini-batch step's
+    launches).  Plain data movement: the values are exactly those of the sliced form."""
+
+    @staticmethod
+    def forward(ctx, w, b, d, skip):
+        ctx.d, ctx.skip = int(d), bool(skip)
+        w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
+        b_pq = torch.nn.functional.pad(b, (d, 0))
+        cvec = w[:, 2 * d].contiguous() if skip else None
+        return w_pq, b_pq, cvec
+
+    @staticmethod
+    def backward(ctx, g_wpq, g_bpq, g_cvec):
+        d = ctx.d
+        g_w = g_b = None
+        if g_wpq is not None or g_cvec is not None:
+            cols = [g_wpq[:d] if g_wpq is not None else g_cvec.new_zeros(d, d),
+                    g_wpq[d:] if g_wpq is not None else g_cvec.new_zeros(d, d)]
+            if ctx.skip:
+                cols.append((g_cvec if g_cvec is not None else g_wpq.new_zeros(d)).reshape(d, 1))
+            g_w = torch.cat(cols, dim=1)
+        if g_bpq is not None:
+            g_b = g_bpq[d:]
+        return g_w, g_b, None, None
+
+
+def pq_operands(w, b, d: int, skip: bool):
+    """(w_pq, b_pq, cvec) of the decoder's first layer (see _PQOperands); sliced with plain autograd while a compiler traces"""
+    if torch.compiler.is_compiling():
+        return (torch.cat([w[:, :d], w[:, d:2 * d]], dim=0), torch.cat([torch.zeros_like(b), b]),
+                w[:, 2 * d].contiguous() if skip else None)
+    return _PQOperands.apply(w, b, d, skip)
+

@@ -201,9 +201,7 @@ class AlternateGCN(nn.Module):
         d = z.shape[1]
         extra = graph.edge_attr[: ei.shape[1]] if fl.skip_connections else None
         w = self.mlp[0].weight
-        cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
-        w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
-        b_pq = torch.cat([torch.zeros_like(self.mlp[0].bias), self.mlp[0].bias])
+        w_pq, b_pq, cvec = PF.pq_operands(w, self.mlp[0].bias, d, bool(fl.skip_connections))
         # bf16 mixed precision: mlp[0] is an autocast Linear, its node-level halves are stored (and gathered) as bfloat16
         pq_dtype = torch.bfloat16 if (PF.autocast_bf16(z) and d == 64 and PF.DECODER_PRECISION == 1) else None
         return PF.linear(z, w_pq, b_pq, in_act, pq_dtype), st, extra, cvec
@@ -245,10 +243,8 @@ class AlternateGCN(nn.Module):
         lin0 = self.mlp[0]
         if self.fused_decoder and d % 4 == 0:
             w = lin0.weight
-            cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
             # one node-level product gives P | Q = z [W_a ; W_b]^T + [0 ; b1]
-            w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
-            b_pq = torch.cat([torch.zeros_like(lin0.bias), lin0.bias])
+            w_pq, b_pq, cvec = PF.pq_operands(w, lin0.bias, d, bool(fl.skip_connections))
             fused = d == 64 and self.fused_decoder != "pair_add"
             pq_dtype = torch.bfloat16 if (fused and PF.autocast_bf16(z) and PF.DECODER_PRECISION == 1) else None
             pq = PF.linear(z, w_pq, b_pq, 0, pq_dtype)
