@@ -43,6 +43,16 @@ class TorchOps:
     def embed_propagate(self, x_tab, w, b, st, norm, tag=None):
         return self.propagate(x_tab.view(-1, 1) * w.view(1, -1) + b, None, st, norm)
 
+    def embed_conv_in(self, x_tab, w, b, w_in, b_in, st, norm):
+        """conv_in(embedding(x)) of the own rows (HipOps: by linearity, functional._EmbedConvIn)"""
+        return torch.nn.functional.linear(self.embed_propagate(x_tab, w, b, st, norm), w_in, b_in)
+
+    def embed_conv_in_linear(self, x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):
+        """... followed by ELU and the next dense layer (HipOps: generated inside that layer's kernels)"""
+        self.fused_first_dense_calls = getattr(self, "fused_first_dense_calls", 0) + 1
+        h = self.embed_conv_in(x_tab, w, b, w_in, b_in, st, norm)
+        return torch.nn.functional.linear(torch.nn.functional.elu(h), w_out, bias_out)
+
     def accumulate_back(self, g_local, back, plan):
         g_local.index_add_(0, plan.send_idx, back)
 
@@ -156,6 +166,10 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=Tru
             continue
         scale = float(q.grad.abs().max()) + 1e-12
         assert torch.allclose(p.grad, q.grad, atol=1e-4 * scale + 1e-8, rtol=1e-3), (k, (p.grad - q.grad).abs().max())
+    # the scalar-feature default / base topologies take the fused first-two-layers operator on every shard (forward of the
+    # parity check + forward of the train step); union (propagate-first consumer at these dims) and categorical do not
+    fused_calls = getattr(model.ops, "fused_first_dense_calls", 0)
+    assert fused_calls == (0 if (categorical or flags.get("union_edge_weights")) else 2), fused_calls
     if exchange == "halo":
         plan = model._plan(shard, "sim")
         # [sources of lower ranks | own sources | sources of higher ranks]
