@@ -40,3 +40,25 @@ def test_bench_multi_rank_line(world):
     # same seed, same initial weights, same six steps: the partitioned job follows the single-GPU loss
     assert abs(many["config"]["final_loss"] - one["config"]["final_loss"]) < 2e-3
     assert many["roofline"]["avg_launch_ms"] > 0
+
+
+def test_bench_single_gpu_line_carries_roofline_step_bytes_and_cpu_baseline():
+    """the N = 1 line of the measurement contract on a small workload: every required key, the roofline object of the
+    dominant kernel with its live launch time, the step-level byte accounting whose terms add up, the strict-fp32 extra,
+    and the CPU baseline (the oracle's train step on a bounded sample)"""
+    d = _run([sys.executable, "bench.py", "--workload", "cfg2", "--steps", "3", "--warmup", "1", "--cpu-genes", "100",
+              "--cpu-steps", "1"], {})
+    assert all(k in d for k in REQUIRED), d.keys()
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "edges/s" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert abs(d["value"] - d["config"]["sim_edges"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None                       # profiles/traffic.json holds cfg-4 entries only: no stale figure
+    assert abs(sum(d["step_alg_bytes_terms"].values()) - d["step_alg_bytes"]) < 1.0
+    assert 0 < d["step_hbm_frac"] < 1 and d["strict_fp32"]["ms_per_step"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "oracle" in c["sample"]
+    assert d["value"] > 10 * c["value"]
