@@ -101,6 +101,43 @@ def test_small_structure_build_equals_the_general_build(n, e, seed, sort_src):
         assert np.array_equal(csr.rowptr.cpu().numpy(), np.searchsorted(key[perm], np.arange(n + 1), side="left"))
 
 
+def test_small_structure_build_random_sizes_against_numpy():
+    """60 random (N, E) inside the kernel's limits, random order, hubs, duplicate edges: both CSR orders against numpy's
+    stable argsort, and the chunk plans against a direct numpy restatement of the plan definition"""
+    from pangnn_amd import graph as G
+    from pangnn_amd import functional as PF
+    rng = np.random.default_rng(20261004)
+    for trial in range(60):
+        e = int(rng.integers(1, 16385)) if trial % 3 else int(2 ** rng.integers(0, 15))
+        n = int(rng.integers(1, 65537)) if trial % 4 else int(rng.integers(1, 40))
+        ei_np = rng.integers(0, n, size=(2, e), dtype=np.int64)
+        if trial % 5 == 0:
+            ei_np[1, : e // 2] = ei_np[1, 0]                                   # a hub target
+        if trial % 2:
+            ei_np = ei_np[:, np.argsort(ei_np[0], kind="stable")]
+        st = G.EdgeStructure(torch.from_numpy(ei_np).to(dev()), n)
+        assert st._small_build()
+        ct = PF.d16_chunk(e)
+        span = 32 * ct
+        for group_by, csr, by in ((1, st.by_dst, "dst"), (0, st.by_src, "src")):
+            key = ei_np[group_by]
+            perm = np.argsort(key, kind="stable")
+            ks = key[perm]
+            assert np.array_equal(csr.perm.cpu().numpy().astype(np.int64), perm), (trial, n, e, by)
+            assert np.array_equal(csr.other.cpu().numpy().astype(np.int64), ei_np[1 - group_by][perm])
+            rowptr = np.searchsorted(ks, np.arange(n + 1), side="left")
+            assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+            plan = st.csr_plan(by, ct)
+            start = (np.arange(e) % span == 0)
+            start[1:] |= ks[1:] != ks[:-1]
+            pid = np.cumsum(start) - 1
+            assert np.array_equal(plan.keys.cpu().numpy().astype(np.int64), ks)
+            assert np.array_equal(plan.part_off.cpu().numpy().astype(np.int64), pid[::span])
+            pid_ext = np.concatenate([pid, [pid[-1] + 1]])
+            assert np.array_equal(plan.part_rowptr.cpu().numpy(), pid_ext[rowptr]), (trial, n, e, by)
+            assert plan.n_parts_exact() == pid[-1] + 1 <= plan.n_parts
+
+
 def test_small_structure_build_limits_and_bad_ids():
     from pangnn_amd import graph as G
     from pangnn_amd import _lib
