@@ -1011,14 +1011,21 @@ class _precision:
         PF.DECODER_PRECISION = self.old
 
 
-@pytest.mark.parametrize("e", [1, 33, 1000, 70001])
+@pytest.mark.parametrize("e", [1, 33, 1000, 70001, 131105, 262177, 524321, 1048609, 1048610])
 @pytest.mark.parametrize("skip", [False, True])
 @pytest.mark.parametrize("mode", [1, 0], ids=["bf16x3", "f32mfma"])
 def test_decoder_training_kernels_vs_fp64(e, skip, mode):
     """both matrix-pipe modes of the training decoder against an fp64 torch evaluation, same bounds: precision = 1
-    (bf16 terms of the fp32 operands on the matrix pipe, the default) must stay at fp32-level error"""
+    (bf16 terms of the fp32 operands on the matrix pipe, the default) must stay at fp32-level error.
+    The edge counts above 1e5 sit just behind the steps of the S / T kernels' chunk-size function (2, 4, 8, 16 tiles per
+    chunk from 4096, 8192, 16384, 32768 tiles on): runs of one source carried across the tiles of a chunk at every size,
+    on 97 nodes (every run is thousands of edges long), sorted (odd E: run sums in S) and unsorted (even: both sums in T)."""
     from pangnn_amd import functional as PF
     from pangnn_amd.graph import EdgeStructure
+    if e > 100000 and mode == 0:
+        pytest.skip("chunked run sums are the default mode's")
+    if e > 100000:
+        assert PF.d16_chunk(e) == {131105: 2, 262177: 4, 524321: 8, 1048609: 16, 1048610: 16}[e]
     torch.manual_seed(e + skip)
     n, d = 97, 64
     ei, w = random_graph(n, e, seed=e, isolated=0.0)
