@@ -130,17 +130,22 @@ def cpu_baseline(args, d, h):
                       f"train steps of oracle/gcn_oracle.py, {dt / steps * 1e3:.0f} ms/step"}
 
 
-def minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd):
+def minibatch_line(workload, dev, steps, warmup_min, seed=0, genes=None):
+    """the reference's own regime (pangnn.py:152-216): DataLoader(batch_size=32) over per-group sub-graphs, one train step
+    per mini-batch.  cfg2mb: one captured HIP graph per batch, replayed; cfg2mb_fresh: a fresh Batch every step (collation,
+    both CSR orders, degree norms, run-sum plans, the first layer's r / s inside the timed step)."""
     import pangnn_amd
     from pangnn_amd import simulate
     from pangnn_amd.train import make_optimizer, train_step
-    ds = simulate.simulate_subgraph_dataset(genes, G, frac, frags, shuf, seed=args.seed, device=dev)
+    g0, G, frac, frags, shuf, d, h = WORKLOADS[workload]
+    genes = genes or g0
+    ds = simulate.simulate_subgraph_dataset(genes, G, frac, frags, shuf, seed=seed, device=dev)
     n_train = int(len(ds) * 0.7)                                       # split_data((0.7, 0.15, 0.01))
     batches = [ds.batch(i, min(i + 32, n_train)) for i in range(0, n_train, 32)]
     pw = ds.class_balance()
     torch.manual_seed(0)
     model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h])
-    fresh = args.workload == "cfg2mb_fresh"
+    fresh = workload == "cfg2mb_fresh"
     graphed = os.environ.get("PANGNN_HIPGRAPH", "1") != "0" and not fresh
     opt = make_optimizer(model, capturable=graphed)
     if graphed:
@@ -159,7 +164,7 @@ def minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd):
         steps_fn = [(lambda b=b: train_step(model, opt, b, b.y, pw)) for b in batches]
     # every batch has its own tensor sizes: the untimed steps cover one pass over the batches, so that the timed ones see the
     # steady state of the caching allocator (and of the kernels' code objects), as every epoch after the first does
-    warmup = max(args.warmup, len(batches))
+    warmup = max(warmup_min, len(batches))
     for k in range(warmup):
         steps_fn[k % len(batches)]()
     torch.cuda.synchronize()
@@ -170,22 +175,80 @@ def minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd):
     gc.freeze()
     t0 = time.perf_counter()
     edges = 0
-    for k in range(args.steps):
+    for k in range(steps):
         loss, _ = steps_fn[k % len(batches)]()
         edges += batches[k % len(batches)].edge_index.shape[1]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    line = {"metric": "edges/sec in GNN forward+backward (link-pred train step)", "value": edges / dt,
-            "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    gc.unfreeze()
+    return {"metric": "edges/sec in GNN forward+backward (link-pred train step)", "value": edges / dt,
+            "unit": "edges/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"--simulate_dataset {genes} {G} {frac} {frags} {shuf} --train, mini-batches of 32 "
                                    f"per-group sub-graphs ({len(batches)} batches, {n_train} train sub-graphs), "
                                    f"node_dim={d} hidden_dim={h}" + (", one captured HIP graph per batch" if graphed else "") +
                                    (", a fresh Batch per step: collation + structure build (2 CSR orders, degree norms) inside "
                                     "the timed step" if fresh else ""),
-                       "mean_edges_per_batch": edges / args.steps, "final_loss": float(loss.item())}}
+                       "mean_edges_per_batch": edges / steps, "final_loss": float(loss.item())}}
+
+
+def minibatch_bench(args, dev, json_fd):
+    line = minibatch_line(args.workload, dev, args.steps, args.warmup, seed=args.seed, genes=args.genes)
     os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
+def _mb_sibling(workload, dev, seed):
+    ln = minibatch_line(workload, dev, 200, 3, seed=seed)
+    return {"what": ln["config"]["workload"], "steps": ln["steps"], "ms_per_step": ln["ms_per_step"], "value": ln["value"],
+            "unit": "edges/s", "mean_edges_per_batch": ln["config"]["mean_edges_per_batch"],
+            "final_loss": ln["config"]["final_loss"]}
+
+
+def cfg5slice_sibling(dev, steps, seed=0):
+    """one GPU's share of BASELINE config 5 (6 of its 50 genomes with config 5's negative-edge law, --skip_connections
+    --categorical_node, bf16 autocast) timed in this process after the headline: the categorical embedding keeps the *
+    propagate and its transpose inside every step"""
+    import pangnn_amd
+    from pangnn_amd import functional as PF
+    from pangnn_amd import simulate
+    from pangnn_amd.train import make_optimizer, train_step
+    genes, G, frac, frags, shuf, d, h = WORKLOADS["cfg5slice"]
+    t0 = time.perf_counter()
+    g = simulate.simulate_graph(genes, G, frac, frags, shuf, seed=seed, device=dev, mean_neg=220, adjacent_only=True)
+    n, e_sim = g.num_nodes, g.edge_index.shape[1]
+    g.x = torch.arange(n, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    torch.manual_seed(0)
+    model = pangnn_amd.AlternateGCN(dev, None, True, dims=[d, h], num_nodes=n, skip_connections=True)
+    opt = make_optimizer(model)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16)
+
+    def step():
+        with amp:
+            return train_step(model, opt, g, g.y, g.class_balance)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    old, PF.KERNEL_TIMER = PF.KERNEL_TIMER, {"sim.fwd": [], "sim.bwd": [], "dec.bwd": [], "dec.dgrad": []}
+    try:
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            loss, _ = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        tm = PF.KERNEL_TIMER
+    finally:
+        PF.KERNEL_TIMER = old
+    avg = lambda tag: (sum(a.elapsed_time(b) for a, b in tm[tag]) / steps) if tm.get(tag) else None     # noqa: E731  ms per step
+    return {"what": "--simulate_dataset 200000 6 0.1 500 50 with m = 220 negatives per gene (config 5's law), "
+                    "--skip_connections --categorical_node, bf16 autocast, whole slice as one batch on one GPU",
+            "nodes": n, "sim_edges": e_sim, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": e_sim * steps / dt,
+            "unit": "edges/s", "dtype": "bf16 rows / f32", "graph_build_s": round(t_gen, 3),
+            "propagate_fwd_ms_per_step": avg("sim.fwd"), "propagate_bwd_ms_per_step": avg("sim.bwd"),
+            "decoder_S_ms_per_step": avg("dec.bwd"), "decoder_T_ms_per_step": avg("dec.dgrad"),
+            "final_loss": float(loss.item())}
 
 
 def main():
@@ -198,7 +261,8 @@ def main():
     ap.add_argument("--cpu-genes", type=int, default=2500, help="genes per genome of the CPU-baseline sample (1/20 of cfg 4)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the strict-fp32 step and the transposed-propagate timing")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sibling timings (general-feature step, strict fp32, cfg5slice, mini-batch regimes)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -247,7 +311,7 @@ def main():
     if args.genes:
         genes = args.genes
     if args.workload in ("cfg2mb", "cfg2mb_fresh"):
-        return minibatch_bench(args, dev, genes, G, frac, frags, shuf, d, h, json_fd)
+        return minibatch_bench(args, dev, json_fd)
     force_dist = os.environ.get("PANGNN_FORCE_DIST") == "1"      # exercise the partitioned path at world = 1
     if force_dist and world == 1:
         import torch.distributed as dist
@@ -374,16 +438,35 @@ def main():
     if world == 1 and not force_dist and not args.no_extras and not cfg5:
         old_mode = PF.DECODER_PRECISION
         try:
+            # (i) general-feature step: the same graph, the same model layer by layer (fuse_embedding=False) — the * propagate
+            # over the similarity graph and its transpose run inside every step, as they do for --categorical_node, the union /
+            # hidden layers and any non-constant node feature
             PF.KERNEL_TIMER = {"sim.fwd": [], "sim.bwd": []}
             m2 = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h], fuse_embedding=False)
             o2 = make_optimizer(m2)
-            for _ in range(4):
+            for _ in range(3):
                 train_step(m2, o2, graph, labels, pos_weight)
             torch.cuda.synchronize()
+            PF.KERNEL_TIMER = {"sim.fwd": [], "sim.bwd": []}
+            n_gen = max(args.steps // 2, 5)
+            t1 = time.perf_counter()
+            for _ in range(n_gen):
+                l2, _ = train_step(m2, o2, graph, labels, pos_weight)
+            torch.cuda.synchronize()
+            dt_gen = time.perf_counter() - t1
             extra["bwd_avg_launch_ms"] = _avg("sim.bwd", PF.KERNEL_TIMER) * 1e3
             extra["prop_fwd_s"] = _avg("sim.fwd", PF.KERNEL_TIMER)
+            extra["general_features"] = {
+                "what": "the same cfg-4 step evaluated layer by layer (fuse_embedding=False): conv_in's similarity-graph propagate "
+                        "(the * kernel, spmm_row_kernel) and its transpose inside every step — the step of --categorical_node, of "
+                        "the union / hidden layers and of any non-constant node feature",
+                "steps": n_gen, "ms_per_step": dt_gen / n_gen * 1e3, "value": e_sim * n_gen / dt_gen, "unit": "edges/s",
+                "propagate_fwd_ms": extra["prop_fwd_s"] * 1e3, "propagate_bwd_ms": extra["bwd_avg_launch_ms"],
+                "propagate_share_of_step": (extra["prop_fwd_s"] + extra["bwd_avg_launch_ms"] * 1e-3) / (dt_gen / n_gen),
+                "final_loss": float(l2.item())}
             del m2, o2
             PF.KERNEL_TIMER = None
+            # (ii) strict fp32: every decoder product on the f32 matrix instructions
             PF.DECODER_PRECISION = 0
             for _ in range(2):
                 step_fn()
@@ -404,6 +487,18 @@ def main():
         finally:                                                  # whatever happened, the process is back in the mode
             PF.DECODER_PRECISION = old_mode                       # the emitted line describes
             PF.KERNEL_TIMER = None
+        # (iii) the other regimes of the path, timed in this process after the headline (each builds its own data):
+        # config 5's per-GPU slice, and the reference's mini-batch regime replayed / with a fresh Batch per step
+        if args.workload == "cfg4" and not args.genes:
+            for key, fn in (("cfg5slice", lambda: cfg5slice_sibling(dev, max(args.steps // 2, 5), args.seed)),
+                            ("cfg2mb", lambda: _mb_sibling("cfg2mb", dev, args.seed)),
+                            ("cfg2mb_fresh", lambda: _mb_sibling("cfg2mb_fresh", dev, args.seed))):
+                try:
+                    extra[key] = fn()
+                except Exception as ex:
+                    extra[key] = {"error": repr(ex)}
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
 
     if rank == 0:
         rows_local = getattr(graph, "n_local", n)
@@ -479,7 +574,9 @@ def main():
             b_dec = e_local * 556.0 + n_parts_s * 256.0
             ent = traffic_entry(prof, "decoder_train", args.workload, world, e_sim)
             line["roofline"] = {
-                "bound": "hbm", "kernel": "decoder_train16_kernel<fused loss, run sums> (largest kernel of the step)",
+                "bound": "issue", "kernel": "decoder_train16_kernel<fused loss, run sums> (largest kernel of the step)",
+                "bound_note": "what binds is vector-instruction issue (what_binds); achieved / peak / frac stay the prescribed "
+                              "byte figures against the 8 TB/s HBM roof, the nearer of the kernel's two hardware roofs",
                 "achieved": b_dec / t_dec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": b_dec / t_dec / HBM_PEAK,
                 "frac_note": "algorithmic bytes per step's worth of S launches / launch time / 8 TB/s: HBM is the nearer of the "
                              "kernel's two roofs (useful matrix flops are at mfma.useful_frac of the bf16 peak)",
@@ -500,7 +597,7 @@ def main():
             b_dg = e_local * 28.0 + n_parts_d * 256.0        # perm 4 + key 4 + record 20 per edge, part rows written
             ent = traffic_entry(prof, "decoder_dgrad", args.workload, world, e_sim)
             line["roofline_dgrad"] = {
-                "bound": "hbm", "kernel": "decoder_dgrad16_kernel (dL/dh1 run sums by target from the per-edge records)",
+                "bound": "issue", "kernel": "decoder_dgrad16_kernel (dL/dh1 run sums by target from the per-edge records)",
                 "launches_per_step": n_dgr, "avg_launch_ms": t_dgr * 1e3, "alg_bytes_per_launch": b_dg,
                 "achieved": b_dg / t_dgr / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": b_dg / t_dgr / HBM_PEAK,
                 "mfma_tflops": 24 * 16384.0 / 16.0 * e_local / t_dgr / 1e12,
@@ -532,7 +629,7 @@ def main():
                            "once per graph (r = A_hat x, s = A_hat 1: conv_in(embedding(x)) = r a^T + s c^T + b_in by linearity, "
                            "functional._EmbedConvIn); timed here on the layer-by-layer model, outside the headline",
                 "bwd_avg_launch_ms": extra.get("bwd_avg_launch_ms", (_avg("sim.bwd") or 0) * 1e3 or None)}
-        for k_ in ("strict_fp32", "extras_error"):
+        for k_ in ("general_features", "strict_fp32", "cfg5slice", "cfg2mb", "cfg2mb_fresh", "extras_error"):
             if k_ in extra:
                 line[k_] = extra[k_]
         if not args.no_cpu_baseline and world == 1:

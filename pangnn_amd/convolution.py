@@ -11,8 +11,9 @@ torch_geometric, with the same names, argument meaning and state_dict layout:
     `bias [out]` then `lin.weight [out,in]` (PyG >= 2.0 key order).
   * `EdgeConv(in_channels, out_channels)` — convolution.py:5-23, body unchanged.
 
-Every gather / scatter / reduction runs in libpangnn_hip.so (pangnn_amd/csrc).  Dense node-level
-GEMMs (`lin`) stay in PyTorch (hipBLASLt).  There is no CPU path.
+Every gather / scatter / reduction runs in libpangnn_hip.so (pangnn_amd/csrc), and so do the dense
+node-level products (`lin`: csrc/linear.hip, `pangnn_linear_*`, for in / out widths in {64, 128};
+any other width goes to hipBLASLt through torch).  There is no CPU path.
 """
 from __future__ import annotations
 

@@ -26,7 +26,7 @@ namespace pangnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifdef PANGNN_ABLATE_MFMA   // diagnostic builds only (tools/ablate_decoder.sh): one VALU op per MFMA
+#ifdef PANGNN_ABLATE_MFMA   // diagnostic builds only (hipcc -DPANGNN_ABLATE_MFMA, loaded through PANGNN_HIP_LIB): one VALU op per MFMA
 __device__ __forceinline__ f32x16 fake_mfma(float a, float b, f32x16 c) { c[0] = fmaf(a, b, c[0]); return c; }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) fake_mfma(a, b, c)
 #endif

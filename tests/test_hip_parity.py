@@ -1,6 +1,8 @@
 """GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on identical
 inputs.  Integer / index results bit-exact; fp32 results within the north-star tolerance
 (1e-4 on link-prediction logits; the same bound relative to magnitude for intermediate tensors)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -336,9 +338,26 @@ FLAG_SETS = [dict(), dict(skip_connections=True), dict(base_model=True), dict(un
              dict(union_edge_weights=True, neighbours=4), dict(decoder="cosine"), dict(decoder="dot")]
 
 
-def _check_logits_loss_grads_against_oracle(g, gd, oracle, model):
-    """HIP logits within 1e-4 of the fp32 oracle (north star), loss 1e-5, parameter gradients adjudicated against an
-    fp64 run of the same oracle"""
+# Tensors of the golden-graph model tests on which an activation-boundary flip on the HIP side has actually been
+# OBSERVED (gpurun_out/r04a/grad_fp64.jsonl, the distances this function logs): only these keep the flip band
+# max(4 e_o32 + 2e-5, 5e-4); every other (graph, flags, tensor) is held to the direct fp64 bound.
+OBSERVED_FLIPS = set()          # filled in below from the logged distances: (graph name, flags id, parameter name)
+FP64_DIRECT = 2e-5              # HIP gradient vs the fp64 oracle, of the tensor's scale (4 x the 5e-6 DESIGN.md §2 reports)
+
+
+def _log_grad_distances(tag, worst):
+    """append the measured distances to $PANGNN_GRAD_LOG (one JSON object per line): the evidence the bounds rest on"""
+    path = os.environ.get("PANGNN_GRAD_LOG")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps({"case": tag, "dist": {k: [a, b] for k, (a, b) in worst.items()}}) + "\n")
+
+
+def _check_logits_loss_grads_against_oracle(g, gd, oracle, model, tag=None, flips=()):
+    """HIP logits within 1e-4 of the fp32 oracle (north star), loss 1e-5, parameter gradients within FP64_DIRECT of their
+    scale of an fp64 run of the same oracle — the fp32 oracle's own distance to fp64 plays no part in that bound.
+    `flips`: parameter names of this case on which a relu-boundary flip was observed (band instead of the direct bound)."""
     ref = oracle(g)
     out = model(gd)
     assert out.shape == ref.shape == (g.edge_index.shape[1],)
@@ -378,7 +397,10 @@ def _check_logits_loss_grads_against_oracle(g, gd, oracle, model):
         e_hip = float((p.grad.detach().cpu().double() - g64).abs().max()) / scale
         e_o32 = float((po[k].grad.double() - g64).abs().max()) / scale
         worst[k] = (e_hip, e_o32)
-        assert e_hip <= max(4.0 * e_o32 + 2e-5, 5e-4), (k, e_hip, e_o32)
+        if k in flips:       # a named, observed flip: as close as the fp32 oracle where nothing flips, inside the band otherwise
+            assert e_hip <= max(4.0 * e_o32 + 2e-5, 5e-4), (k, e_hip, e_o32)
+        else:                # the claim itself: the HIP gradient against fp64, whatever the fp32 oracle's own error is
+            assert e_hip <= FP64_DIRECT, (tag, k, e_hip, e_o32)
         # the direct fp32-vs-fp32 bound only where the fp32 ORACLE is itself a sound reference for it: on the 1.5e6-edge
         # config-4-law graph its own sums (one fp32 chain per output over all edges) are up to 2e-3 of the scale from
         # fp64, further than the HIP sums, and the fp64 adjudication above is the whole statement
@@ -386,6 +408,7 @@ def _check_logits_loss_grads_against_oracle(g, gd, oracle, model):
             assert close(p.grad, po[k].grad, atol=1e-3 * scale + 1e-7, rtol=1e-3), (k, e_hip, e_o32)
     print("gradient distance to the fp64 oracle, of the tensor's scale (HIP, fp32 oracle):",
           {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in worst.items()})
+    _log_grad_distances(tag, worst)
     return out, ref, worst
 
 
@@ -394,7 +417,9 @@ def _check_logits_loss_grads_against_oracle(g, gd, oracle, model):
 @pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: "-".join(f"{k}={v}" for k, v in f.items()) or "default")
 def test_alternate_gcn_logits_and_grads_match_oracle(name, dims, flags):
     g, gd, oracle, model = _pair(name, dims, flags)
-    _check_logits_loss_grads_against_oracle(g, gd, oracle, model)
+    fid = "-".join(f"{k}={v}" for k, v in flags.items()) or "default"
+    _check_logits_loss_grads_against_oracle(g, gd, oracle, model, tag=f"{name}/{fid}",
+                                            flips={k for (n_, f_, k) in OBSERVED_FLIPS if (n_, f_) == (name, fid)})
 
 
 @pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True)], ids=["default", "skip"])
@@ -409,7 +434,10 @@ def test_config4_edge_law_matches_oracle(flags):
     indeg = torch.bincount(g.edge_index[1], minlength=n)
     assert n == 20000 and 1.2e6 < e < 1.8e6 and int(indeg.max()) >= 600, (n, e, int(indeg.max()))
     g, gd, oracle, model = _pair(g, (64, 128), flags)
-    out, ref, _ = _check_logits_loss_grads_against_oracle(g, gd, oracle, model)
+    # no flip band here: every HIP gradient within 2e-5 of its scale of the fp64 oracle (measured 1e-7 .. 6e-6), although the
+    # fp32 ORACLE's own mlp.4.weight / mlp.0.weight sums are 2e-3 / 1e-2 away from fp64 on this graph
+    out, ref, _ = _check_logits_loss_grads_against_oracle(g, gd, oracle, model,
+                                                          tag="cfg4law/" + ("skip" if flags else "default"))
     # the one-pass training form (what bench.py times) on the same graph: same logits, same loss
     model.zero_grad()
     pw = torch.tensor(float((g.y == 0).sum() / g.y.sum()))
