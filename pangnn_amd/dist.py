@@ -135,6 +135,11 @@ def _all_to_all_v(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_spli
             w.wait()
 
 
+def force_exchange() -> bool:
+    """PANGNN_FORCE_EXCHANGE=1: test hook that makes a ONE-rank run exchange rows with itself (HaloPlan.__init__)"""
+    return os.environ.get("PANGNN_FORCE_EXCHANGE") == "1"
+
+
 class HaloPlan:
     """Which owned rows every peer needs from this rank, and the local edge list re-indexed into the
     compact table [halo rows of lower ranks | owned rows | halo rows of higher ranks].  Table order is
@@ -147,7 +152,14 @@ class HaloPlan:
         dev = ei_local.device
         src = ei_local[0]
         hi = lo + n_local
-        remote = (src < lo) | (src >= hi)
+        # Test hook (PANGNN_FORCE_EXCHANGE=1, one rank only): the lower and upper quarter of the node range count as
+        # "remote" rows — owned by rank 0 itself — so that every exchange of the N > 1 path (all-to-all-v with split
+        # lists, the side-stream decoder exchange, the halo gradient return, the flat all-reduce) executes on the real
+        # back end (RCCL on a one-GPU box) and can be compared with the single-GPU model.  Sources are then read from
+        # the halo COPIES of those rows, their gradients return through the back-exchange like any boundary row's.
+        q = n_local // 4 if (world == 1 and force_exchange()) else 0
+        lo_own, hi_own = lo + q, hi - q                                    # sources in [lo_own, hi_own) are read in place
+        remote = (src < lo_own) | (src >= hi_own)
         need = torch.unique(src[remote])                                   # sorted global ids
         if bounds is None:
             owner = torch.div(need, n_local, rounding_mode="floor")
@@ -171,9 +183,9 @@ class HaloPlan:
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < n_local)
         self.n_local, self.n_halo = n_local, int(need.numel())
         self.n_table = n_local + self.n_halo
-        self.n_low = int((need < lo).sum())                       # halo rows owned by lower ranks
+        self.n_low = int((need < lo_own).sum())                   # halo rows owned by lower ranks
         pos = torch.searchsorted(need, src)                       # rank of a remote source among the needed ids
-        new_src = torch.where(remote, torch.where(src < lo, pos, pos + n_local), src - lo + self.n_low)
+        new_src = torch.where(remote, torch.where(src < lo_own, pos, pos + n_local), src - lo + self.n_low)
         self.edge_index = torch.stack([new_src, ei_local[1]]).contiguous()
         self.group = group
         # A source-sorted list is [sources of lower ranks | own sources | sources of higher ranks]: the middle range
@@ -759,18 +771,29 @@ class DistAlternateGCN(AlternateGCN):
         return self.load_state_dict(sd, strict=strict)
 
     def sync_gradients(self):
-        """one flat all-reduce (sum) of every parameter gradient: 216 KB at default dims"""
+        """one flat all-reduce (sum) of every parameter gradient: 216 KB at default dims.  The gradients are gathered into
+        ONE persistent buffer by a single multi-tensor copy, reduced there, and the parameters' `.grad`s become views of
+        it (no copy back): 2 launches + the collective per step instead of a concatenation and one copy per parameter."""
         local = self.embedding.weight if self.sharded_embedding else None      # rank-local rows: nothing to reduce
-        grads = [p.grad for p in self.parameters() if p.grad is not None and p is not local]
-        if not grads:
+        params = [p for p in self.parameters() if p.grad is not None and p is not local]
+        if not params:
             return
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        key = tuple((id(p), p.grad.dtype) for p in params)
+        cache = self.__dict__.get("_flat_grads")
+        if cache is None or cache[0] != key:
+            if len({p.grad.dtype for p in params}) != 1:
+                raise RuntimeError("gradient all-reduce: mixed gradient dtypes")
+            flat = torch.empty(sum(p.numel() for p in params), dtype=params[0].grad.dtype, device=params[0].device)
+            views, off = [], 0
+            for p in params:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            cache = self.__dict__["_flat_grads"] = (key, flat, views)
+        _, flat, views = cache
+        torch._foreach_copy_(views, [p.grad for p in params])
         _all_reduce_sum_(flat, self.group)
-        off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
+        for p, v in zip(params, views):
+            p.grad = v
 
 
 def train_step(model: DistAlternateGCN, optimizer, shard, labels, pos_weight):

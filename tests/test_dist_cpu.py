@@ -87,9 +87,11 @@ class TorchOps:
                                                                     reduction="sum") / denom
 
 
-def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=True, uneven=False):
+def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=True, uneven=False, force=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if force:          # one rank that exchanges its outer quarters with itself (dist.force_exchange)
+        os.environ["PANGNN_FORCE_EXCHANGE"] = "1"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     from pangnn_amd import dist as pdist
     g = whole_graph_from_golden("sim_200x4")
@@ -126,7 +128,7 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=Tru
         first = model.embedding.weight[0].detach().clone()
         others = [torch.zeros_like(first) for _ in range(world)]
         dist.all_gather(others, first)
-        assert not torch.equal(others[0], others[1])
+        assert world == 1 or not torch.equal(others[0], others[1])
     # reference-layout checkpoint in, this rank's rows of the categorical embedding kept (a rank holds the embedding
     # rows of its own nodes); and back out: every rank reassembles the reference's [N, D] table
     model.load_full_state_dict(sd)
@@ -183,9 +185,13 @@ def _worker(rank, world, init_file, flags, out_dir, exchange="halo", overlap=Tru
         assert torch.equal(plan.merge_edge_values(a, b), shard.y)
         # the halo is exactly the set of remote sources this rank's edges reference
         src = shard.edge_index[0]
-        rem = (src < shard.lo) | (src >= shard.lo + shard.n_local)
+        qf = shard.n_local // 4 if force else 0            # forced self-exchange: the outer quarters count as remote
+        rem = (src < shard.lo + qf) | (src >= shard.lo + shard.n_local - qf)
         assert plan.n_halo == int(torch.unique(src[rem]).numel())
-        assert plan.n_halo < n - shard.n_local or world == 2
+        assert plan.n_halo < n - shard.n_local or world == 2 or force
+        if force:
+            assert plan.any_exchange and plan.n_halo > 0 and plan.n_low > 0 and plan.e_lo > 0 and plan.e_hi < ts.numel()
+            assert plan.send_splits == [plan.n_halo] and plan.recv_splits == [plan.n_halo]
         assert sum(plan.recv_splits) == plan.n_halo and int(plan.edge_index[0].max()) < plan.n_table
     # owned-edge bookkeeping: every similarity edge has exactly one owner
     cnt = shard.owned_mask.to(torch.int32).clone()
@@ -235,6 +241,18 @@ def test_partitioned_model_on_eight_ranks(uneven):
         init_file = os.path.join(d, "rdzv")
         mp.spawn(_worker, args=(8, init_file, dict(skip_connections=True), d, "halo", True, uneven), nprocs=8, join=True)
         assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(8))
+
+
+@pytest.mark.parametrize("flags,overlap", [(dict(), True), (dict(), False), (dict(union_edge_weights=True), True),
+                                           (dict(skip_connections=True, categorical_nodes=True), True)],
+                         ids=["default", "default-gather-first", "union", "cfg5-skip-categorical"])
+def test_one_rank_forced_self_exchange_matches_oracle(flags, overlap):
+    """PANGNN_FORCE_EXCHANGE=1 (the hook tests/test_dist_gpu.py uses to run the N > 1 code over RCCL on a one-GPU box): a
+    single rank treats the outer quarters of its node range as remote rows owned by itself — every exchange of the
+    partitioned path runs (here over gloo) and the result is still the single-process oracle's"""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(1, os.path.join(d, "rdzv"), flags, d, "halo", overlap, False, True), nprocs=1, join=True)
+        assert os.path.exists(os.path.join(d, "ok0"))
 
 
 @pytest.mark.parametrize("flags", [dict(), dict(union_edge_weights=True)], ids=["default", "union"])
