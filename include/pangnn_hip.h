@@ -243,7 +243,9 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  *   is set.  Outputs: the parameter gradients g_w2[D,D], g_w3[D], g_b3[1], g_cvec[D] (nullable) — dL/db2 comes
  *   out of the dgrad pass (it needs only the records; keeping its per-lane partial sums out of this kernel is
  *   what lets two waves share a SIMD without spilling),
- *   rec[E][8] uint32 (required): per edge {4 dwords of relu masks, dL/dlogit_e, 3 unused} for the dgrad pass,
+ *   rec[E][8] uint32 (required): per edge {4 dwords of relu masks — the h2 mask in the low byte of each half, the h1
+ *             mask in the high byte —, dL/dlogit_e replicated into dwords 4 .. 7} for the dgrad pass, whose lane group g
+ *             reads mask dword g and dL/dlogit through one address (offsets 0 and 16),
  *   part_buf / part_off (both NULL or both set; edge list sorted by source): sums of dL/dh1 over every
  *   (chunk, source) run, where a chunk is pangnn_decoder_chunk_tiles_for(num_edges) (16 for E >= 1e6, down to 1 for short lists) consecutive 32-edge tiles walked by
  *   one wave with the open run carried from tile to tile: part_off[c] = index of chunk c's first part row, a new
@@ -259,10 +261,11 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  * pangnn_decoder_dgrad_f32  ("T"): dL/dh1 summed over runs of equal keys in a permuted edge order, from `rec`:
  *   position k of the order is edge perm[k] (NULL = identity) with run key keys[k] (non-decreasing, e.g. the
  *   target id in by-target CSR order); part_buf / part_off as above for THIS order.  dL/dQ[t] is then the sum
- *   of the consecutive parts of target t (pangnn_spmm_csr_f32 with idx == NULL).  g_cvec (nullable, needs
- *   `extra`) = sum_e extra_e dL/dh1[e];  g_b2[D] (nullable) = dL/db2 = w3[j] sum_e g_e [h2[j][e] > 0] — ask for it
- *   in exactly one dgrad call per step.  part_buf / part_off / keys may all be NULL to get the parameter sums
- *   alone.  workspace (with g_cvec or g_b2): pangnn_decoder_dgrad_workspace_bytes().
+ *   of the consecutive parts of target t (pangnn_spmm_csr_f32 with idx == NULL).  `extra` / `g_cvec` are RESERVED and
+ *   must be NULL (dL/dcvec always comes out of pangnn_decoder_train_*; round 3's instances that recomputed it here were
+ *   never launched and spilled registers);  g_b2[D] (nullable) = dL/db2 = w3[j] sum_e g_e [h2[j][e] > 0] — ask for it
+ *   in exactly one dgrad call per step.  part_buf / part_off / keys may all be NULL to get the parameter sum
+ *   alone.  workspace (with g_b2): pangnn_decoder_dgrad_workspace_bytes().
  * Both are reproducible (fixed-order sums, no float atomics).
  * ---------------------------------------------------------------------------------------- */
 int    pangnn_decoder_chunk_tiles(void);

@@ -243,7 +243,7 @@ __device__ __forceinline__ void stage_weights16(const float* w2, const float* b2
 // product itself is left to the consumer — the run sums take it as a fused multiply-add (run_sums), so a half tile
 // without a run boundary costs 16 FMAs instead of 16 multiplies + 12 adds.
 __device__ __forceinline__ void dgrad_masks(const char* recl, const char* gl, int c, int g, f32x4 (&gm)[4]) {
-  const int bitpos = 16 * (c & 1) + 7 - ((c & 7) >> 1);
+  const int bitpos = 16 * (c & 1) + 15 - ((c & 7) >> 1);      // m1 bits: the high byte of each half of a record dword
   const char* rrow = recl + 64 * g + 4 * (c >> 3);      // edge 4 g + i at + 16 i; dwords (c >> 3) and 2 + (c >> 3)
 #if defined(PANGNN_D16_PROBE_GE_SCALAR) || defined(PANGNN_D16_PROBE_WAIT0)
   // diagnostic builds (tools/slp_probe.sh): the same arithmetic with (a) g_e read as four dwords instead of one
@@ -382,6 +382,10 @@ __device__ __forceinline__ void dgrad_tile2(const char* lds, const bf16x8 (&a2)[
 // in ONE register per lane.  m16: bit e set = edge e of this half is the last of its run.  Layout of every summed
 // row: lane (c, g) holds column colp = 16 kRow4[g] + c (what red4 leaves in row g).
 // The rows are given as factors: row value = v[kb][i] * gm[kb][i] (dgrad_masks) — multiplied inside the sums.
+// part row `pidx` (wave-uniform: a scalar base), column `col` (32-bit lane offset): the saddr form of global_store
+__device__ __forceinline__ void part_store(float* part, int64_t pidx, int col, float x) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(part + pidx * D16) + 4u * (uint32_t)col) = x;
+}
 __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], const f32x4 (&gm)[4], unsigned m16, float& carry, float* part,
                                          int64_t& pidx, char* wv, int lane, int c, int g, int colp) {
   const unsigned inner = m16 & 0x7fffu;
@@ -401,7 +405,7 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], const f32x4 (&gm)[
     }
     const float s = carry + red4(x[0], x[1], x[2], x[3]);
     if (m16 & 0x8000u) {
-      part[pidx * D16 + colp] = s;
+      part_store(part, pidx, colp, s);
       ++pidx;
       carry = 0.f;
     } else {
@@ -427,10 +431,10 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], const f32x4 (&gm)[
     }
     const float lo = carry + red4(a[0], a[1], a[2], a[3]);
     const float hi = red4(b[0], b[1], b[2], b[3]);
-    part[pidx * D16 + colp] = lo;
+    part_store(part, pidx, colp, lo);
     ++pidx;
     if (m16 & 0x8000u) {
-      part[pidx * D16 + colp] = hi;
+      part_store(part, pidx, colp, hi);
       ++pidx;
       carry = 0.f;
     } else {
@@ -452,7 +456,7 @@ __device__ __forceinline__ void run_sums(const f32x4 (&v)[4], const f32x4 (&gm)[
     for (int e = 0; e < 16; ++e) {
       sum += tile[e * 64 + lane];
       if ((m16 >> e) & 1u) {
-        part[pidx * D16 + lane] = sum;
+        part_store(part, pidx, lane, sum);
         sum = 0.f;
         ++pidx;
       }
@@ -487,17 +491,20 @@ __device__ __forceinline__ HalfIn load_half(const D16Params& a, const float* aux
   const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
   const int64_t e_tile = tc * 32;
   const int64_t rest = a.E - 1 - e_tile;
-  const int lim = (int)(rest < 31 ? rest : 31);            // uniform: last valid position inside the tile
-  const int k = min(16 * hx + c, lim);
-  const int kn = (int)min((int64_t)k + 1, rest);           // the edge after k: position 32 = first edge of the next tile
-  const int64_t* ei = a.ei + e_tile;
-  const int64_t s = ei[k], d = ei[a.ld + k];
+  const uint32_t lim = (uint32_t)(rest < 31 ? rest : 31);  // uniform: last valid position inside the tile
+  const uint32_t lim_n = (uint32_t)(rest < 32 ? rest : 32);  // position 32 = first edge of the next tile
+  const uint32_t k = min((uint32_t)(16 * hx + c), lim);
+  const uint32_t kn = min(k + 1u, lim_n);                  // the edge after k
+  // uniform tile bases + 32-bit lane byte offsets: the saddr form of global_load, no 64-bit vector arithmetic
+  const char* es = reinterpret_cast<const char*>(a.ei + e_tile);
+  const char* ed = reinterpret_cast<const char*>(a.ei + a.ld + e_tile);
+  const int64_t s = *reinterpret_cast<const int64_t*>(es + 8u * k), d = *reinterpret_cast<const int64_t*>(ed + 8u * k);
   h.key = (int)s;
-  h.key_nxt = (int)ei[kn];
+  h.key_nxt = (int)*reinterpret_cast<const int64_t*>(es + 8u * kn);
   h.poff = (uint32_t)s * a.ldp_b;
   h.qoff = (uint32_t)d * a.ldq_b;
-  h.aux = (aux + e_tile)[k];
-  h.w_e = EXTRA ? (a.extra + e_tile)[k] : 0.f;
+  h.aux = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(aux + e_tile) + 4u * k);
+  h.w_e = EXTRA ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.extra + e_tile) + 4u * k) : 0.f;
   return h;
 }
 __device__ __forceinline__ void issue_half_rows(const D16Params& a, const HalfIn& in, int g, HalfRowsT<false>& r) {
@@ -725,17 +732,19 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
         const float y_e = in_cur.aux;
         const float scale = live ? lp.inv_denom : 0.f;
         const float lw = 1.f + (pw - 1.f) * y_e;
-        const float t = expf(-fabsf(xv));             // in (0, 1]
+        // t = exp(-|x|) in (0, 1] as ONE v_exp_f32 of -|x| log2(e) (no over / underflow to guard on this side; the single
+        // rounding of the scaled argument moves t by <= |x| 2^-24 relative, i.e. sigmoid by <= 2e-8 absolute at its worst
+        // point |x| = 1): the library expf's two-term range reduction and its range selects were 11 more instructions
+        const float t = __expf(-fabsf(xv));
         const float u = 1.f + t;
         float ru = __builtin_amdgcn_rcpf(u);
         ru = ru * (2.f - u * ru);                     // 1 / (1 + t): one Newton step on the hardware reciprocal
         const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
         g_raw = ((1.f - y_e) - lw * sig_neg) * lp.inv_denom;
         g_e = live ? g_raw : 0.f;
-        const float um1 = u - 1.f;                    // log1p(t) = log(u) t / (u - 1), = t when u == 1
-        float rm = __builtin_amdgcn_rcpf(um1);
-        rm = rm * (2.f - um1 * rm);
-        const float l1p = um1 == 0.f ? t : logf(u) * (t * rm);
+        // log1p(t) = -log(1 / (1 + t)) off the reciprocal the gradient needs anyway: absolute error <= 1e-7 per term of a
+        // MEAN of O(1) terms (the loss value only; round 3 evaluated log(u) t / (u - 1) with a second Newton reciprocal)
+        const float l1p = -__logf(ru);
         lossp = fmaf((1.f - y_e) * xv + lw * (l1p + fmaxf(-xv, 0.f)), scale, lossp);
       } else {
         g_raw = in_cur.aux;
@@ -743,7 +752,8 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       }
       gb3p += g_e;
       const int posc = min(pos, live_lim);
-      if (FUSED_LOSS || logits != nullptr) logit_tile[posc] = xv;         // four lane groups, same value
+      if (FUSED_LOSS || logits != nullptr)                                // four lane groups, same value
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(logit_tile) + 4u * (uint32_t)posc) = xv;
 
       // ---- m2 = [h2 > 0] as bf16 0/1 (A operand of P2 and, transposed through LDS, of P3); gw3 partials
       bf16x8 a2[2];
@@ -806,14 +816,18 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       D16_SETPRIO(1);
       p3_block(0);
       write_hg(1);
-      const uint32_t recw = (m1 & 0x00ff00ffu) | ((m2 & 0x00ff00ffu) << 8);
+      // record dword g of the edge: m2 bits in the low byte of each half (bit 7 - n / 23 - n for the pair n), m1 bits in the
+      // high byte — the T kernel turns the m2 bits into bf16 0 / 1 with one AND + one 24-bit multiply per dword
+      const uint32_t recw = (m2 & 0x00ff00ffu) | ((m1 & 0x00ff00ffu) << 8);
       *reinterpret_cast<uint32_t*>(wv + WV_REC + 16 * c + 4 * g) = recw;
       *reinterpret_cast<float*>(wv + WV_GL + 4 * c) = g_e;               // the four lane groups write the same value
       if (has_extra) *reinterpret_cast<float*>(wv + WV_WL + 4 * c) = in_cur.w_e;
       {
-        uint32_t* r = rec_tile + posc * 8;
-        r[g] = recw;
-        r[4] = __builtin_bit_cast(uint32_t, g_raw);                       // four lane groups, same value
+        // scalar tile base + 32-bit lane offset (saddr stores); dL/dlogit goes into dwords 4 .. 7: lane group g of the T
+        // kernel reads its mask dword and g_e through ONE address (offsets 0 and 16)
+        char* r = reinterpret_cast<char*>(rec_tile) + (32u * (uint32_t)posc + 4u * (uint32_t)g);
+        *reinterpret_cast<uint32_t*>(r) = recw;
+        *reinterpret_cast<uint32_t*>(r + 16) = __builtin_bit_cast(uint32_t, g_raw);
       }
       wave_sync();
       p3_block(1);
@@ -931,47 +945,54 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 // Two dependent loads per position (perm[k], then the record of edge perm[k]): a two-stage pipeline — the ids of half
 // tile n + 2 and the records of half tile n + 1 are in flight while half tile n is multiplied, so each of the two
 // random-access latencies has a whole iteration to land.
+// Addressing (round 4): every per-position load is `scalar tile base + 32-bit lane offset` (the saddr form of
+// global_load: no 64-bit vector arithmetic), and a record is read through ONE 64-bit address per lane — mask dword g at
+// +0, g_e at +16 (S replicates dL/dlogit into dwords 4 .. 7) — instead of three 64-bit adds per load.
 struct TIds { uint32_t e; int key, key_nxt; };
-struct TIn { uint32_t recw; float g_e, w_e; int key, key_nxt; };
-template <bool PERM>
+struct TIn { uint32_t recw; float g_e; int key, key_nxt; };
+template <bool PERM, bool KEYS>
 __device__ __forceinline__ TIds load_ids(const int32_t* perm, const int32_t* keys, int64_t E, int64_t tile, int64_t n_tiles,
                                          int hx, int c) {
   TIds t;
   const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
   const int64_t p_tile = tc * 32;
   const int64_t rest = E - 1 - p_tile;
-  const int lim = (int)(rest < 31 ? rest : 31);
-  const int k = min(16 * hx + c, lim);
-  const int kn = (int)min((int64_t)k + 1, rest);           // position 32 = first position of the next tile
-  const int32_t* kt = keys + p_tile;
-  t.key = kt[k];
-  t.key_nxt = kt[kn];
-  t.e = PERM ? (uint32_t)(perm + p_tile)[k] : (uint32_t)(p_tile + k);
+  const uint32_t lim = (uint32_t)(rest < 31 ? rest : 31);                 // uniform: last valid position inside the tile
+  const uint32_t lim_n = (uint32_t)(rest < 32 ? rest : 32);               // position 32 = first position of the next tile
+  const uint32_t k = min((uint32_t)(16 * hx + c), lim);
+  const uint32_t kn = min(k + 1u, lim_n);
+  t.key = t.key_nxt = 0;
+  if (KEYS) {                                                             // (the parameter sums alone take no keys: NULL)
+    const char* kt = reinterpret_cast<const char*>(keys + p_tile);        // uniform base, 32-bit lane offsets
+    t.key = *reinterpret_cast<const int32_t*>(kt + 4u * k);
+    t.key_nxt = *reinterpret_cast<const int32_t*>(kt + 4u * kn);
+  }
+  t.e = PERM ? (uint32_t) * reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(perm + p_tile) + 4u * k)
+             : (uint32_t)p_tile + k;
   return t;
 }
-template <bool EXTRA>
-__device__ __forceinline__ TIn load_rec(const uint32_t* rec, const float* extra, const TIds& id, int g) {
+// recg: the record table + 4 g bytes (this lane's mask dword of record 0)
+__device__ __forceinline__ TIn load_rec(const char* recg, const TIds& id) {
   TIn t;
-  const uint32_t* r = rec + (uint64_t)id.e * 8;
-  t.recw = r[g];
-  t.g_e = __builtin_bit_cast(float, r[4]);
-  t.w_e = EXTRA ? extra[id.e] : 0.f;
+  const char* r = recg + ((uint64_t)(id.e << 1) << 4);     // e < 2^31; a shift of 4 folds into v_lshl_add_u64, one of 5 does not
+  t.recw = *reinterpret_cast<const uint32_t*>(r);
+  t.g_e = *reinterpret_cast<const float*>(r + 16);
   t.key = id.key;
   t.key_nxt = id.key_nxt;
   return t;
 }
 
-// PERM / EXTRA: permutation given, skip feature given — compile-time, so that the loads of the loop body sit in
-// straight-line code (as runtime-uniform branches they cut it into ~20 basic blocks).  Whether dL/db2 is wanted stays
-// a runtime branch: as a template parameter the scheduler's longer reach costs its 16 accumulators 17 spills.
-template <bool PERM, bool EXTRA, bool RUN>
+// PERM (a permutation is given) / RUN (run sums wanted; false: the parameter sums alone) are compile-time, so that the
+// loads of the loop body sit in straight-line code.  Whether dL/db2 is wanted stays a runtime-uniform branch: as a template
+// parameter the scheduler's longer reach costs its 16 accumulators 25 spilled registers at the 128-register cap.
+template <bool PERM, bool RUN>
 __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     const uint32_t* __restrict__ rec, const int32_t* __restrict__ perm, const int32_t* __restrict__ keys,
-    const float* __restrict__ extra, const float* __restrict__ w2, const float* __restrict__ w3, int64_t E,
-    D16Run rs, float* __restrict__ gcv_slabs, float* __restrict__ gb2_slabs, int64_t n_tiles) {
-  // LDS: W2'^T hi | mid | lo, (b2 w3 cvec: unused here), per wave: run-sum tile [17][64] floats | recl | gl | wl of
-  // both halves of the wave's 32-edge tile
-  constexpr int TW_REC = 17 * 64 * 4, TW_GL = TW_REC + 2 * 256, TW_WL = TW_GL + 2 * 64, TW_BYTES = TW_WL + 2 * 64;
+    const float* __restrict__ w2, const float* __restrict__ w3, int64_t E, D16Run rs, float* __restrict__ gb2_slabs,
+    int64_t n_tiles) {
+  // LDS: W2'^T hi | mid | lo, (b2 w3 cvec: w3 used by the dL/db2 finish), per wave: run-sum tile [17][64] floats | recl |
+  // gl of both halves of the wave's 32-edge tile
+  constexpr int TW_REC = 17 * 64 * 4, TW_GL = TW_REC + 2 * 256, TW_BYTES = TW_GL + 2 * 64;
   constexpr int T_VEC = 3 * W_IMG, T_WAVE0 = T_VEC + 3 * 64 * 4;
   constexpr int T_LDS = T_WAVE0 + T_WAVES * TW_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[T_LDS];
@@ -982,9 +1003,7 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
   __syncthreads();
   const int wfrag0 = c * 128 + ((g ^ wsw(c)) << 4), wfrag1 = wfrag0 ^ 64;
   const int colp = 16 * (((g & 1) << 1) | (g >> 1)) + c;
-  constexpr bool has_extra = EXTRA;
-  constexpr bool run = RUN;                 // run sums wanted (false: the parameter sums alone)
-  float gcv[4] = {0.f, 0.f, 0.f, 0.f};
+  const char* recg = reinterpret_cast<const char*>(rec) + 4 * g;
   f32x4 gb2a[4];                           // per (j = 16 jb + 4 g + i, edge slot c): sum of g_e m2[j][e] over tiles
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) gb2a[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1000,10 +1019,10 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
   int64_t tile1 = next_tile(tile, cstride, n_tiles, last1, clog);      // the wave's next tile
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    cur[h] = load_rec<EXTRA>(rec, extra, load_ids<PERM>(perm, keys, E, tile, n_tiles, h, c), g);
-    ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile1, n_tiles, h, c);
+    cur[h] = load_rec(recg, load_ids<PERM, RUN>(perm, keys, E, tile, n_tiles, h, c));
+    ids_nxt[h] = load_ids<PERM, RUN>(perm, keys, E, tile1, n_tiles, h, c);
   }
-  int poff_cur = (run && tile < n_tiles) ? rs.part_off[tile >> clog] : 0;
+  int poff_cur = (RUN && tile < n_tiles) ? rs.part_off[tile >> clog] : 0;
   float carry = 0.f;
   int64_t pidx = 0;
   while (tile < n_tiles) {
@@ -1012,67 +1031,66 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     pidx = first_of_chunk ? (int64_t)__builtin_amdgcn_readfirstlane(poff_cur) : pidx;
     const bool last_tile = last1;                                      // this tile ends its chunk
     const int64_t chunk_nxt = (tile >> clog) + cstride;
-    const int poff_nxt = run ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
+    const int poff_nxt = RUN ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
     const int live_lim = (int)min((int64_t)31, E - 1 - tile * 32);
     bool last2;
     const int64_t tile2 = next_tile(tile1 < n_tiles ? tile1 : n_tiles - 1, cstride, n_tiles, last2, clog);
     TIn nxt[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      nxt[h] = load_rec<EXTRA>(rec, extra, ids_nxt[h], g);
-      ids_nxt[h] = load_ids<PERM>(perm, keys, E, tile2, n_tiles, h, c);
+      nxt[h] = load_rec(recg, ids_nxt[h]);
+      ids_nxt[h] = load_ids<PERM, RUN>(perm, keys, E, tile2, n_tiles, h, c);
     }
     bf16x8 a2[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const float g_e = 16 * h + c <= live_lim ? cur[h].g_e : 0.f;
-      *reinterpret_cast<uint32_t*>(wv + TW_REC + 256 * h + 16 * c + 4 * g) = cur[h].recw;
+      const uint32_t recw = cur[h].recw;
+      *reinterpret_cast<uint32_t*>(wv + TW_REC + 256 * h + 16 * c + 4 * g) = recw;
       *reinterpret_cast<float*>(wv + TW_GL + 64 * h + 4 * c) = g_e;
-      if (has_extra) *reinterpret_cast<float*>(wv + TW_WL + 64 * h + 4 * c) = cur[h].w_e;
-      // m2 bits of lane (c, g): dword qd of K-step t holds elements (2 qd, 2 qd + 1) at bits 15 - n and 31 - n, n = 4 t + qd
+      // m2 bits of lane (c, g): pair n = 4 t + qd (elements 2 qd, 2 qd + 1 of K-step t) sits at bits 7 - n and 23 - n:
+      // (recw & (0x10001 << p)) * (0x3f80 >> p) = bf16 1.0 / 0.0 in each half (p <= 7: the products stay inside their halves)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         u32x4 w;
+        uint32_t yb[4];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) w[qd] = ((cur[h].recw >> (15 - (4 * t + qd))) & 0x00010001u) * 0x3f80u;
+        for (int qd = 0; qd < 4; ++qd) {
+          const int p = 7 - (4 * t + qd);
+          yb[qd] = recw & (0x00010001u << p);
+          asm volatile("" : "+v"(yb[qd]));      // opaque: keeps ONE and per pair (the optimiser otherwise re-derives byte 0
+          w[qd] = __umul24(yb[qd], 0x3f80u >> p);     //                                  from recw with a second and below)
+        }
         a2[h][t] = __builtin_bit_cast(bf16x8, w);
         if (gb2_slabs != nullptr) {
-          // the halves of w are bf16 1.0 / 0.0: as fp32 bit patterns they are the mask value itself
+          // dL/db2 partials: the masked record bits themselves as floats — byte 0 / byte 2 of (recw & (0x10001 << p)) is
+          // 2^p or 0, one v_cvt_f32_ubyte each — so accumulator (jb, i) carries 2^p times its sum, p = 7 - 2 jb - (i >> 1),
+          // an exact scale taken out once at the end.  (Round 3 rebuilt 1.0 / 0.0 from the bf16 operand: the optimiser
+          // folded that into a v_mul_lo_u32 per pair, a quarter-rate instruction, 16 per tile.)
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             const int jb = 2 * t + (qd >> 1), i0 = 2 * (qd & 1);
-            gb2a[jb][i0] = fmaf(__builtin_bit_cast(float, w[qd] << 16), g_e, gb2a[jb][i0]);
-            gb2a[jb][i0 + 1] = fmaf(__builtin_bit_cast(float, w[qd] & 0xffff0000u), g_e, gb2a[jb][i0 + 1]);
+            gb2a[jb][i0] = fmaf((float)(yb[qd] & 0xffu), g_e, gb2a[jb][i0]);
+            gb2a[jb][i0 + 1] = fmaf((float)((yb[qd] >> 16) & 0xffu), g_e, gb2a[jb][i0 + 1]);
           }
         }
       }
     }
     wave_sync();
-    if (run) {
+    if (RUN) {
       f32x4 v[2][4];
       dgrad_tile2(lds, a2, wfrag0, wfrag1, v);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         f32x4 gm[4];
         dgrad_masks(wv + TW_REC + 256 * h, wv + TW_GL + 64 * h, c, g, gm);
-        if (has_extra && gcv_slabs != nullptr) {
-          f32x4 pv[4];
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) pv[kb] = v[h][kb];
-          dgrad_apply(pv, gm);
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + TW_WL + 64 * h + 16 * g);
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gcv[kb] = fmaf(w4[i], pv[kb][i], gcv[kb]);
-        }
         const bool closes = cur[h].key != cur[h].key_nxt || (h == 1 && c == 15 && last_tile);   // key change, or end of the chunk
         const unsigned long long bal = __ballot(closes);
         const unsigned m16 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bal & 0xffffull));
         run_sums(v[h], gm, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
       }
     }
-    wave_sync();          // the next tile overwrites recl / gl / wl
+    wave_sync();          // the next tile overwrites recl / gl
 #pragma unroll
     for (int h = 0; h < 2; ++h) cur[h] = nxt[h];
     poff_cur = last_tile ? poff_nxt : poff_cur;
@@ -1080,10 +1098,8 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     tile1 = tile2;
     last1 = last2;
   }
-  if (gcv_slabs != nullptr || gb2_slabs != nullptr) {
-    // parameter-gradient partials of the workgroup in fixed wave order: [gcvec 64 | gb2 64]
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) gcv[kb] = xsum32(xsum16(gcv[kb]));
+  if (gb2_slabs != nullptr) {
+    // dL/db2 partials of the workgroup in fixed wave order
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
@@ -1095,25 +1111,19 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     float* red = reinterpret_cast<float*>(lds + T_WAVE0);
     const float* w3v = reinterpret_cast<const float*>(lds + T_VEC) + 64;
     for (int w = 0; w < T_WAVES; ++w) {
-      if (wave == w) {
-        if (g == 0) {
+      if (wave == w && c == 0) {
 #pragma unroll
-          for (int kb = 0; kb < 4; ++kb) red[16 * kb + c] = (w == 0 ? 0.f : red[16 * kb + c]) + gcv[kb];
-        }
-        if (c == 0) {
+        for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-          for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int j = 16 * jb + 4 * g + i;
-              red[64 + j] = (w == 0 ? 0.f : red[64 + j]) + w3v[j] * gb2a[jb][i];
-            }
-        }
+          for (int i = 0; i < 4; ++i) {
+            const int j = 16 * jb + 4 * g + i;
+            const float unscale = __builtin_bit_cast(float, (uint32_t)(127 - (7 - 2 * jb - (i >> 1))) << 23);   // 2^-p
+            red[j] = (w == 0 ? 0.f : red[j]) + w3v[j] * (gb2a[jb][i] * unscale);
+          }
       }
       __syncthreads();
     }
-    if (threadIdx.x < 64 && gcv_slabs != nullptr) gcv_slabs[(int64_t)blockIdx.x * 64 + threadIdx.x] = red[threadIdx.x];
-    if (threadIdx.x < 64 && gb2_slabs != nullptr) gb2_slabs[(int64_t)blockIdx.x * 64 + threadIdx.x] = red[64 + threadIdx.x];
+    if (threadIdx.x < 64) gb2_slabs[(int64_t)blockIdx.x * 64 + threadIdx.x] = red[threadIdx.x];
   }
 }
 
@@ -1351,7 +1361,7 @@ extern "C" int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float
                                     part_off, g_w2, g_w3, g_b3, g_cvec, workspace, workspace_bytes, stream);
 }
 
-extern "C" size_t pangnn_decoder_dgrad_workspace_bytes(void) { return (size_t)cu_count() * 128 * sizeof(float); }
+extern "C" size_t pangnn_decoder_dgrad_workspace_bytes(void) { return (size_t)cu_count() * 64 * sizeof(float); }
 
 extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys,
                                         const float* extra, const float* w2, const float* w3, int64_t num_edges,
@@ -1359,49 +1369,42 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
                                         void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
   const char* who = "pangnn_decoder_dgrad_f32";
   PG_CHECK_ARG(num_edges >= 0, PANGNN_E_BADARG, "%s: bad size", who);
+  PG_CHECK_ARG(extra == nullptr && g_cvec == nullptr, PANGNN_E_BADARG,
+               "%s: extra / g_cvec are reserved and must be NULL (dL/dcvec comes out of pangnn_decoder_train_*)", who);
   hipStream_t s = (hipStream_t)stream;
   if (num_edges == 0) {
-    for (float* z : {g_cvec, g_b2})
-      if (z) {
-        hipError_t e = hipMemsetAsync(z, 0, 64 * sizeof(float), s);
-        PG_CHECK_ARG(e == hipSuccess, (int)e, "%s: memset failed", who);
-      }
+    if (g_b2) {
+      hipError_t e = hipMemsetAsync(g_b2, 0, 64 * sizeof(float), s);
+      PG_CHECK_ARG(e == hipSuccess, (int)e, "%s: memset failed", who);
+    }
     return 0;
   }
   PG_CHECK_ARG(rec && w2 && w3 && (part_buf == nullptr) == (part_off == nullptr) && (!part_buf || keys),
                PANGNN_E_BADARG, "%s: null pointer", who);
-  PG_CHECK_ARG(part_buf || g_b2 || g_cvec, PANGNN_E_BADARG, "%s: nothing to compute", who);
-  PG_CHECK_ARG(!g_cvec || (extra && part_buf), PANGNN_E_BADARG, "%s: g_cvec needs extra and the run-sum pass", who);
+  PG_CHECK_ARG(part_buf || g_b2, PANGNN_E_BADARG, "%s: nothing to compute", who);
   const int64_t n_tiles = (num_edges + 31) / 32;
   const int clog = chunk_log_for(n_tiles);
   const int64_t n_chunks = (n_tiles + (1 << clog) - 1) >> clog;
   int64_t grid = (n_chunks + T_WAVES - 1) / T_WAVES;
   const int cus = cu_count();
   if (grid > cus) grid = cus;
-  PG_CHECK_ARG(!(g_cvec || g_b2) || (workspace && workspace_bytes >= (size_t)grid * 128 * sizeof(float)),
-               PANGNN_E_WORKSPACE, "%s: workspace too small", who);
+  PG_CHECK_ARG(!g_b2 || (workspace && workspace_bytes >= (size_t)grid * 64 * sizeof(float)), PANGNN_E_WORKSPACE,
+               "%s: workspace too small", who);
   const D16Run rs{part_buf, part_off, clog};
-  float* cv_slabs = g_cvec ? static_cast<float*>(workspace) : nullptr;
-  float* b2_slabs = g_b2 ? static_cast<float*>(workspace) + (size_t)grid * 64 : nullptr;
-#define PG_T(P, X)                                                                                                 \
-  do {                                                                                                             \
-    if (part_buf)                                                                                                  \
-      hipLaunchKernelGGL((decoder_dgrad16_kernel<P, X, true>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, \
-                         keys, extra, w2, w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles);                         \
-    else                                                                                                           \
-      hipLaunchKernelGGL((decoder_dgrad16_kernel<P, X, false>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec,      \
-                         perm, keys, extra, w2, w3, num_edges, rs, cv_slabs, b2_slabs, n_tiles);                   \
-  } while (0)
-  if (perm) { if (extra) PG_T(true, true); else PG_T(true, false); }
-  else { if (extra) PG_T(false, true); else PG_T(false, false); }
+  float* b2_slabs = g_b2 ? static_cast<float*>(workspace) : nullptr;
+#define PG_T(P, R)                                                                                                   \
+  hipLaunchKernelGGL((decoder_dgrad16_kernel<P, R>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, keys, \
+                     w2, w3, num_edges, rs, b2_slabs, n_tiles)
+  if (part_buf) {
+    if (perm) PG_T(true, true); else PG_T(false, true);
+  } else {
+    PG_T(false, false);                   // the parameter sum alone: the order of the positions does not matter
+  }
 #undef PG_T
   PG_CHECK_LAUNCH(who);
-  for (int x = 0; x < 2; ++x) {
-    float* out = x ? g_b2 : g_cvec;
-    if (out) {
-      hipLaunchKernelGGL(gcv_reduce_kernel, dim3(1), dim3(kSumThreads), 0, s, x ? b2_slabs : cv_slabs, (int)grid, out);
-      PG_CHECK_LAUNCH(who);
-    }
+  if (g_b2) {
+    hipLaunchKernelGGL(gcv_reduce_kernel, dim3(1), dim3(kSumThreads), 0, s, b2_slabs, (int)grid, g_b2);
+    PG_CHECK_LAUNCH(who);
   }
   return 0;
 }

@@ -55,7 +55,11 @@ def test_bench_single_gpu_line_carries_roofline_step_bytes_and_cpu_baseline():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # `bound` names what binds the kernel (vector-instruction issue); achieved / peak / frac stay the byte figures
+    assert r["bound"] == "issue" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    gf = d["general_features"]                        # the same step with the * propagate and its transpose inside it
+    assert gf["ms_per_step"] > 0 and gf["propagate_fwd_ms"] > 0 and gf["propagate_bwd_ms"] > 0
+    assert 0 < gf["propagate_share_of_step"] < 1 and abs(gf["final_loss"] - d["config"]["final_loss"]) < 0.5
     assert r["traffic"] is None                       # profiles/traffic.json holds cfg-4 entries only: no stale figure
     assert abs(sum(d["step_alg_bytes_terms"].values()) - d["step_alg_bytes"]) < 1.0
     assert 0 < d["step_hbm_frac"] < 1 and d["strict_fp32"]["ms_per_step"] > 0

@@ -341,7 +341,19 @@ FLAG_SETS = [dict(), dict(skip_connections=True), dict(base_model=True), dict(un
 # Tensors of the golden-graph model tests on which an activation-boundary flip on the HIP side has actually been
 # OBSERVED (gpurun_out/r04a/grad_fp64.jsonl, the distances this function logs): only these keep the flip band
 # max(4 e_o32 + 2e-5, 5e-4); every other (graph, flags, tensor) is held to the direct fp64 bound.
-OBSERVED_FLIPS = set()          # filled in below from the logged distances: (graph name, flags id, parameter name)
+_ALL12 = ("conv_hidden.bias", "conv_hidden.lin.weight", "conv_in.bias", "conv_in.lin.weight", "conv_out.bias",
+          "conv_out.lin.weight", "embedding.bias", "embedding.weight", "mlp.0.bias", "mlp.0.weight", "mlp.2.bias", "mlp.2.weight")
+OBSERVED_FLIPS = {              # (graph, flags id, parameter): 3 of the 28 cases; the other 25 measure <= 2.7e-6 on every tensor
+    # HIP side flips alone (fma(w, c, p + q) vs (p + q) + w c at a relu boundary): HIP 4e-5 .. 1.7e-4, fp32 oracle <= 7e-7
+    **{("sim_200x4", "skip_connections=True", k): "hip" for k in (
+        "conv_in.bias", "conv_in.lin.weight", "conv_out.bias", "conv_out.lin.weight", "embedding.bias", "embedding.weight",
+        "mlp.0.bias", "mlp.2.bias", "mlp.2.weight")},
+    # the fp64 referee sits on the other side of a boundary from BOTH fp32 evaluations (HIP == fp32 oracle to 3 digits):
+    # 2.4e-5 .. 6.8e-5 and 1.7e-4 .. 8.4e-4 of the scale on either side
+    **{("cfg2_sim_1000x5", "union_edge_weights=True-neighbours=4", k): "fp64" for k in _ALL12 if k not in (
+        "conv_hidden.lin.weight", "mlp.0.weight")},
+    **{("cfg3_5genomes", "union_edge_weights=True", k): "fp64" for k in _ALL12},
+}
 FP64_DIRECT = 2e-5              # HIP gradient vs the fp64 oracle, of the tensor's scale (4 x the 5e-6 DESIGN.md §2 reports)
 
 
