@@ -261,11 +261,16 @@ int pangnn_decoder_mlp_loss_f32(const float* p, int64_t ldp, const float* q, int
  * pangnn_decoder_dgrad_f32  ("T"): dL/dh1 summed over runs of equal keys in a permuted edge order, from `rec`:
  *   position k of the order is edge perm[k] (NULL = identity) with run key keys[k] (non-decreasing, e.g. the
  *   target id in by-target CSR order); part_buf / part_off as above for THIS order.  dL/dQ[t] is then the sum
- *   of the consecutive parts of target t (pangnn_spmm_csr_f32 with idx == NULL).  `extra` / `g_cvec` are RESERVED and
- *   must be NULL (dL/dcvec always comes out of pangnn_decoder_train_*; round 3's instances that recomputed it here were
- *   never launched and spilled registers);  g_b2[D] (nullable) = dL/db2 = w3[j] sum_e g_e [h2[j][e] > 0] — ask for it
- *   in exactly one dgrad call per step.  part_buf / part_off / keys may all be NULL to get the parameter sum
- *   alone.  workspace (with g_b2): pangnn_decoder_dgrad_workspace_bytes().
+ *   of the consecutive parts of target t (pangnn_spmm_csr_f32 with idx == NULL).  (dL/dcvec always comes out of
+ *   pangnn_decoder_train_*; round 3's instances that recomputed it here were never launched and are gone.)
+ *   g_b2[D] (nullable) = dL/db2 = w3[j] sum_e g_e [h2[j][e] > 0] — ask for it in exactly one dgrad call per step.
+ *   part_buf / part_off / keys may all be NULL to get the parameter sum alone.  workspace (with g_b2):
+ *   pangnn_decoder_dgrad_workspace_bytes().
+ * live_edges (both entry points; nullable, DEVICE int64[1]): the list is a fixed-shape batch whose first *live_edges edges
+ *   are real and whose tail is padding (a mini-batch collated by pangnn_collate_subgraphs_padded so that one captured
+ *   HIP graph serves every batch): in S the padded edges keep their own logit / record slots but get dL/dlogit = 0 and
+ *   the fused loss is the mean over *live_edges edges (`denom` is ignored); in T the positions >= *live_edges of the
+ *   order are the padding (the pads must sort last: their endpoints are the largest node id).  NULL: every edge is real.
  * Both are reproducible (fixed-order sums, no float atomics).
  * ---------------------------------------------------------------------------------------- */
 int    pangnn_decoder_chunk_tiles(void);
@@ -280,7 +285,8 @@ int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float* q, int64_
                              const float* b3, int32_t D, const float* y, const float* pos_weight,
                              int64_t denom, const float* g_logits, float* logits, float* loss, uint32_t* rec,
                              float* part_buf, const int32_t* part_off, float* g_w2, float* g_w3, float* g_b3,
-                             float* g_cvec, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+                             float* g_cvec, const int64_t* live_edges, void* workspace, size_t workspace_bytes,
+                             pangnn_stream_t stream);
 /* bf16-storage mode of the gather (config 5, bf16 mixed precision: mlp[0] is an autocast Linear, src/gnn.py:173, so
  * its node-level halves P and Q are bf16 tensors): pq_dtype = PANGNN_DTYPE_BF16 reads p and q as bfloat16 rows
  * (ldp / ldq in elements, multiples of 8; half the gather bytes).  bf16 -> f32 is exact, so logits, loss and all
@@ -292,17 +298,17 @@ int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void* q, int64_
                                const float* w3, const float* b3, int32_t D, const float* y, const float* pos_weight,
                                int64_t denom, const float* g_logits, float* logits, float* loss, uint32_t* rec,
                                float* part_buf, const int32_t* part_off, float* g_w2, float* g_w3, float* g_b3,
-                               float* g_cvec, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+                               float* g_cvec, const int64_t* live_edges, void* workspace, size_t workspace_bytes,
+                               pangnn_stream_t stream);
 int pangnn_decoder_mlp_infer_mixed(const void* p, int64_t ldp, const void* q, int64_t ldq, int32_t pq_dtype,
                                    int64_t num_nodes, const int64_t* edge_index, int64_t ld, int64_t num_edges,
                                    const float* extra, const float* cvec, const float* w2, const float* b2,
                                    const float* w3, const float* b3, int32_t D, float* logits,
                                    pangnn_stream_t stream);
 size_t pangnn_decoder_dgrad_workspace_bytes(void);
-int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys, const float* extra,
-                             const float* w2, const float* w3, int64_t num_edges, float* part_buf,
-                             const int32_t* part_off, float* g_cvec, float* g_b2, void* workspace,
-                             size_t workspace_bytes, pangnn_stream_t stream);
+int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys, const float* w2,
+                             const float* w3, int64_t num_edges, float* part_buf, const int32_t* part_off, float* g_b2,
+                             const int64_t* live_edges, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node-level dense layers with a short inner dimension, K (in) and M (out) in {64, 128}

@@ -89,15 +89,15 @@ SIGNATURES = {
     "pangnn_decoder_train_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
                                            _p, _p, _i64, _p,                        # y, pos_weight, denom, g_logits
                                            _p, _p, _p, _p, _p,                      # logits, loss, rec, part_buf, part_off
-                                           _p, _p, _p, _p,                          # g_w2, g_w3, g_b3, g_cvec
+                                           _p, _p, _p, _p, _p,                      # g_w2, g_w3, g_b3, g_cvec, live_edges
                                            _p, _sz, _p]),
     "pangnn_decoder_train_mixed": (C.c_int, [_p, _i64, _p, _i64, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i32,
-                                             _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+                                             _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pangnn_decoder_mlp_infer_mixed": (C.c_int, [_p, _i64, _p, _i64, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p,
                                                  _i32, _p, _p]),
     # T kernel: dL/dh1 run sums in a permuted (CSR) edge order from the records
     "pangnn_decoder_dgrad_workspace_bytes": (_sz, []),
-    "pangnn_decoder_dgrad_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "pangnn_decoder_dgrad_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

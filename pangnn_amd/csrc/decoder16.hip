@@ -188,6 +188,10 @@ struct D16Params {
   const int64_t* ei; int64_t ld; int64_t E;
   const float* extra; const float* cvec;
   const float* w2; const float* b2; const float* w3; const float* b3;
+  // e_live (nullable, device): the first *e_live edges of the list are real, the rest is padding (a fixed-shape batch whose
+  // tail is inert, train.ReplayedFreshStep): padded positions keep their own logit / record slots but enter no sum
+  // (dL/dlogit = 0) and the fused loss is the mean over *e_live edges.
+  const int64_t* e_live;
 };
 struct D16Loss { const float* y; const float* pos_weight; float inv_denom; };
 struct D16Run { float* part; const int32_t* part_off; int chunk_log; };   // chunk_log: tiles per chunk = 1 << chunk_log
@@ -676,6 +680,8 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   float gb3p = 0.f, lossp = 0.f;
   const float b3v = a.b3[0];
   const float pw = (FUSED_LOSS && lp.pos_weight) ? lp.pos_weight[0] : 1.f;
+  const int64_t e_live = a.e_live ? min(a.e_live[0], a.E) : a.E;                       // uniform (one scalar load)
+  const float inv_denom = a.e_live ? 1.0f / (float)max(e_live, (int64_t)1) : lp.inv_denom;
   constexpr bool has_extra = EXTRA;              // skip connections: compile-time, like the other shape switches
   const float* auxp = FUSED_LOSS ? lp.y : g_logits;
   uint32_t one2 = 0x00010001u;             // opaque to the optimiser: the packed min against it stays ONE v_pk_min_u16 (a
@@ -702,7 +708,8 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     const int64_t tile_nxt = next_tile(tile, cstride, n_tiles, last_tile, clog);
     const int64_t chunk_nxt = (tile >> clog) + cstride;
     const int poff_nxt = RUNSUM ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
-    const int live_lim = (int)min((int64_t)31, a.E - 1 - tile * 32);   // uniform: positions <= live_lim are real edges
+    const int store_lim = (int)min((int64_t)31, a.E - 1 - tile * 32);  // uniform: positions <= store_lim exist in the list
+    const int live_lim = (int)min((int64_t)store_lim, e_live - 1 - tile * 32);   // ... <= live_lim are real edges (may be < 0)
     uint32_t* rec_tile = rec + tile * 256;                             // 8 dwords per edge (rec is required)
     float* logit_tile = logits + tile * 32;                            // (required with the fused loss, optional otherwise)
 #pragma unroll 1
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       float g_e, g_raw;
       if (FUSED_LOSS) {
         const float y_e = in_cur.aux;
-        const float scale = live ? lp.inv_denom : 0.f;
+        const float scale = live ? inv_denom : 0.f;
         const float lw = 1.f + (pw - 1.f) * y_e;
         // t = exp(-|x|) in (0, 1] as ONE v_exp_f32 of -|x| log2(e) (no over / underflow to guard on this side; the single
         // rounding of the scaled argument moves t by <= |x| 2^-24 relative, i.e. sigmoid by <= 2e-8 absolute at its worst
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
         float ru = __builtin_amdgcn_rcpf(u);
         ru = ru * (2.f - u * ru);                     // 1 / (1 + t): one Newton step on the hardware reciprocal
         const float sig_neg = xv >= 0.f ? t * ru : ru;                              // sigmoid(-x)
-        g_raw = ((1.f - y_e) - lw * sig_neg) * lp.inv_denom;
+        g_raw = ((1.f - y_e) - lw * sig_neg) * inv_denom;
         g_e = live ? g_raw : 0.f;
         // log1p(t) = -log(1 / (1 + t)) off the reciprocal the gradient needs anyway: absolute error <= 1e-7 per term of a
         // MEAN of O(1) terms (the loss value only; round 3 evaluated log(u) t / (u - 1) with a second Newton reciprocal)
@@ -751,7 +758,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
         g_e = live ? g_raw : 0.f;
       }
       gb3p += g_e;
-      const int posc = min(pos, live_lim);
+      const int posc = min(pos, store_lim);
       if (FUSED_LOSS || logits != nullptr)                                // four lane groups, same value
         *reinterpret_cast<float*>(reinterpret_cast<char*>(logit_tile) + 4u * (uint32_t)posc) = xv;
 
@@ -988,8 +995,8 @@ __device__ __forceinline__ TIn load_rec(const char* recg, const TIds& id) {
 template <bool PERM, bool RUN>
 __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     const uint32_t* __restrict__ rec, const int32_t* __restrict__ perm, const int32_t* __restrict__ keys,
-    const float* __restrict__ w2, const float* __restrict__ w3, int64_t E, D16Run rs, float* __restrict__ gb2_slabs,
-    int64_t n_tiles) {
+    const float* __restrict__ w2, const float* __restrict__ w3, int64_t E, const int64_t* __restrict__ e_live_p, D16Run rs,
+    float* __restrict__ gb2_slabs, int64_t n_tiles) {
   // LDS: W2'^T hi | mid | lo, (b2 w3 cvec: w3 used by the dL/db2 finish), per wave: run-sum tile [17][64] floats | recl |
   // gl of both halves of the wave's 32-edge tile
   constexpr int TW_REC = 17 * 64 * 4, TW_GL = TW_REC + 2 * 256, TW_BYTES = TW_GL + 2 * 64;
@@ -1004,6 +1011,8 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
   const int wfrag0 = c * 128 + ((g ^ wsw(c)) << 4), wfrag1 = wfrag0 ^ 64;
   const int colp = 16 * (((g & 1) << 1) | (g >> 1)) + c;
   const char* recg = reinterpret_cast<const char*>(rec) + 4 * g;
+  // positions >= e_live of the order are padding (the pads of a fixed-shape batch sort last): dL/dlogit = 0 there
+  const int64_t e_live = e_live_p ? min(e_live_p[0], E) : E;
   f32x4 gb2a[4];                           // per (j = 16 jb + 4 g + i, edge slot c): sum of g_e m2[j][e] over tiles
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) gb2a[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1032,7 +1041,7 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
     const bool last_tile = last1;                                      // this tile ends its chunk
     const int64_t chunk_nxt = (tile >> clog) + cstride;
     const int poff_nxt = RUN ? rs.part_off[chunk_nxt < n_chunks ? chunk_nxt : n_chunks - 1] : 0;
-    const int live_lim = (int)min((int64_t)31, E - 1 - tile * 32);
+    const int live_lim = (int)min((int64_t)31, e_live - 1 - tile * 32);
     bool last2;
     const int64_t tile2 = next_tile(tile1 < n_tiles ? tile1 : n_tiles - 1, cstride, n_tiles, last2, clog);
     TIn nxt[2];
@@ -1222,7 +1231,8 @@ static int launch_infer16_any(const void* p, int64_t ldp, const void* q, int64_t
   const int cus = cu_count();
   if (grid > cus) grid = cus;
   const uint32_t esz = pq16 ? 2u : 4u;
-  D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+  D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3,
+              nullptr};
 #define PG_I(H, X) hipLaunchKernelGGL((decoder_infer16_kernel<H, X>), dim3((unsigned)grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles)
   if (pq16) { if (extra) PG_I(true, true); else PG_I(true, false); }
   else { if (extra) PG_I(false, true); else PG_I(false, false); }
@@ -1280,8 +1290,9 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
                                           const float* w3, const float* b3, int32_t D, const float* y,
                                           const float* pos_weight, int64_t denom, const float* g_logits, float* logits,
                                           float* loss, uint32_t* rec, float* part_buf, const int32_t* part_off,
-                                          float* g_w2, float* g_w3, float* g_b3, float* g_cvec, void* workspace,
-                                          size_t workspace_bytes, pangnn_stream_t stream) {
+                                          float* g_w2, float* g_w3, float* g_b3, float* g_cvec,
+                                          const int64_t* live_edges, void* workspace, size_t workspace_bytes,
+                                          pangnn_stream_t stream) {
   const char* who = "pangnn_decoder_train";
   const bool pq16 = pq_dtype == PANGNN_DTYPE_BF16;
   PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16", who);
@@ -1318,7 +1329,8 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
                  who);
     PG_CHECK_ARG(rec && aligned16(rec), PANGNN_E_ALIGN, "%s: rec is required and must be 16-byte aligned", who);
     const uint32_t esz = pq16 ? 2u : 4u;
-    D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3};
+    D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3,
+                live_edges};
     const D16Loss lp{y, pos_weight, y ? 1.0f / (float)denom : 0.f};
     const D16Run rs{part_buf, part_off, clog};
     const dim3 gd((unsigned)grid), bd(S_WAVES * 64);
@@ -1354,23 +1366,21 @@ extern "C" int pangnn_decoder_train_f32(const float* p, int64_t ldp, const float
                                         const float* b3, int32_t D, const float* y, const float* pos_weight,
                                         int64_t denom, const float* g_logits, float* logits, float* loss,
                                         uint32_t* rec, float* part_buf, const int32_t* part_off, float* g_w2,
-                                        float* g_w3, float* g_b3, float* g_cvec, void* workspace,
-                                        size_t workspace_bytes, pangnn_stream_t stream) {
+                                        float* g_w3, float* g_b3, float* g_cvec, const int64_t* live_edges,
+                                        void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
   return pangnn_decoder_train_mixed(p, ldp, q, ldq, PANGNN_DTYPE_F32, num_nodes, edge_index, ld, num_edges, extra, cvec,
                                     w2, b2, w3, b3, D, y, pos_weight, denom, g_logits, logits, loss, rec, part_buf,
-                                    part_off, g_w2, g_w3, g_b3, g_cvec, workspace, workspace_bytes, stream);
+                                    part_off, g_w2, g_w3, g_b3, g_cvec, live_edges, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t pangnn_decoder_dgrad_workspace_bytes(void) { return (size_t)cu_count() * 64 * sizeof(float); }
 
-extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys,
-                                        const float* extra, const float* w2, const float* w3, int64_t num_edges,
-                                        float* part_buf, const int32_t* part_off, float* g_cvec, float* g_b2,
-                                        void* workspace, size_t workspace_bytes, pangnn_stream_t stream) {
+extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int32_t* keys, const float* w2,
+                                        const float* w3, int64_t num_edges, float* part_buf, const int32_t* part_off,
+                                        float* g_b2, const int64_t* live_edges, void* workspace, size_t workspace_bytes,
+                                        pangnn_stream_t stream) {
   const char* who = "pangnn_decoder_dgrad_f32";
   PG_CHECK_ARG(num_edges >= 0, PANGNN_E_BADARG, "%s: bad size", who);
-  PG_CHECK_ARG(extra == nullptr && g_cvec == nullptr, PANGNN_E_BADARG,
-               "%s: extra / g_cvec are reserved and must be NULL (dL/dcvec comes out of pangnn_decoder_train_*)", who);
   hipStream_t s = (hipStream_t)stream;
   if (num_edges == 0) {
     if (g_b2) {
@@ -1394,7 +1404,7 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
   float* b2_slabs = g_b2 ? static_cast<float*>(workspace) : nullptr;
 #define PG_T(P, R)                                                                                                   \
   hipLaunchKernelGGL((decoder_dgrad16_kernel<P, R>), dim3((unsigned)grid), dim3(T_WAVES * 64), 0, s, rec, perm, keys, \
-                     w2, w3, num_edges, rs, b2_slabs, n_tiles)
+                     w2, w3, num_edges, live_edges, rs, b2_slabs, n_tiles)
   if (part_buf) {
     if (perm) PG_T(true, true); else PG_T(false, true);
   } else {
