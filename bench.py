@@ -147,8 +147,21 @@ def minibatch_line(workload, dev, steps, warmup_min, seed=0, genes=None):
     model = pangnn_amd.AlternateGCN(dev, None, False, dims=[d, h])
     fresh = workload == "cfg2mb_fresh"
     graphed = os.environ.get("PANGNN_HIPGRAPH", "1") != "0" and not fresh
-    opt = make_optimizer(model, capturable=graphed)
-    if graphed:
+    # a fresh batch per step as ONE captured HIP graph over fixed-shape padded buffers (train.ReplayedFreshStep);
+    # PANGNN_FRESH_REPLAY=0: round 3's eagerly launched fresh step
+    replayed = fresh and os.environ.get("PANGNN_FRESH_REPLAY", "1") != "0"
+    opt = make_optimizer(model, capturable=graphed or replayed)
+    edge_counts = [int(b.edge_index.shape[1]) for b in batches]
+    if replayed:
+        from pangnn_amd.train import ReplayedFreshStep
+        # DataLoader(shuffle=True): a random permutation of the training sub-graphs, 32 consecutive ids per batch
+        perm = torch.randperm(n_train, generator=torch.Generator().manual_seed(seed)).tolist()
+        id_lists = [perm[i:i + 32] for i in range(0, n_train, 32)]
+        rstep = ReplayedFreshStep(model, opt, ds, pw, 32, graphs=range(n_train))
+        eo = ds._host().edge
+        edge_counts = [sum(eo[i + 1] - eo[i] for i in ids) for ids in id_lists]
+        steps_fn = [(lambda ids=ids: rstep(ids)) for ids in id_lists]
+    elif graphed:
         from pangnn_amd.train import GraphedTrainStep
         steps_fn = [GraphedTrainStep(model, opt, b, b.y, pw) for b in batches]     # one HIP graph per batch
     elif fresh:
@@ -177,7 +190,7 @@ def minibatch_line(workload, dev, steps, warmup_min, seed=0, genes=None):
     edges = 0
     for k in range(steps):
         loss, _ = steps_fn[k % len(batches)]()
-        edges += batches[k % len(batches)].edge_index.shape[1]
+        edges += edge_counts[k % len(batches)]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gc.unfreeze()
@@ -189,7 +202,10 @@ def minibatch_line(workload, dev, steps, warmup_min, seed=0, genes=None):
                                    f"per-group sub-graphs ({len(batches)} batches, {n_train} train sub-graphs), "
                                    f"node_dim={d} hidden_dim={h}" + (", one captured HIP graph per batch" if graphed else "") +
                                    (", a fresh Batch per step: collation + structure build (2 CSR orders, degree norms) inside "
-                                    "the timed step" if fresh else ""),
+                                    "the timed step" if fresh else "") +
+                                   (", shuffled sub-graph order, ONE captured HIP graph over fixed-shape padded buffers "
+                                    f"(max graphs / nodes / edges / neighbour edges = {rstep.spec}) serving every batch"
+                                    if replayed else ""),
                        "mean_edges_per_batch": edges / steps, "final_loss": float(loss.item())}}
 
 

@@ -87,6 +87,27 @@ int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e, int64_t e0
                              int64_t* out_edge_index, int64_t* out_nb_index, int64_t* out_ptr, int64_t* out_batch,
                              float* out_x, pangnn_stream_t stream);
 
+/* Fixed-shape collation (train.ReplayedFreshStep: ONE captured HIP graph for every mini-batch of the reference's
+ * DataLoader(batch_size=32, shuffle=True) loop, pangnn.py:152-216): the disjoint union of the sub-graphs whose ids are in the
+ * DEVICE list graph_ids[max_graphs] (entries outside [0, num_graphs_total) are unused slots), in list order, written into
+ * buffers of the fixed sizes max_edges / max_nb / max_nodes and padded with an inert tail: padded similarity and neighbour
+ * edges are self loops (max_nodes - 1, max_nodes - 1) of a node that is never real (max_nodes must exceed every batch's
+ * node count), with weight 1 and label 0; out_ptr entries beyond the batch = n, out_batch of padded nodes = g, out_x = 1.
+ * node_off / edge_off / nb_off are the data set's [num_graphs_total + 1] offset tables (device); edge_attr / y its flat
+ * per-edge arrays.  out_live[5] (device) = real similarity edges, neighbour edges, nodes, graphs, and 1 if the batch did
+ * not fit (everything is then padding).  out_live is what the decoder entry points take as `live_edges`. */
+int pangnn_collate_subgraphs_padded(const int64_t* edge_index, int64_t ld_e, const int64_t* nb_index, int64_t ld_b,
+                                    const float* edge_attr, const float* y, const int64_t* node_off,
+                                    const int64_t* edge_off, const int64_t* nb_off, int64_t num_graphs_total,
+                                    const int64_t* graph_ids, int32_t max_graphs, int64_t max_edges, int64_t max_nb,
+                                    int64_t max_nodes, int64_t* out_edge_index, int64_t* out_nb_index,
+                                    float* out_edge_attr, float* out_y, int64_t* out_ptr, int64_t* out_batch,
+                                    float* out_x, int64_t* out_live, pangnn_stream_t stream);
+/* dst[0 .. n) (device) = host_values[0 .. n), n <= 64, carried in the kernel arguments of one tiny launch: ordered with the
+ * stream like any kernel and safe to call again before it ran (no pinned staging buffer to overwrite) — how the host hands
+ * the next batch's sub-graph ids to a captured graph. */
+int pangnn_set_i64(int64_t* dst, const int64_t* host_values, int32_t n, pangnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * gcn_norm (k1-k3; PyG gcn_norm as called by GCNConv.forward, src/gnn.py:158):
  *   deg[i]  = sum over in-edges of w        (w = 1 when edge_weight == NULL, src/gnn.py:165)

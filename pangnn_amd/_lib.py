@@ -25,6 +25,9 @@ SIGNATURES = {
     "pangnn_csr_build_flag_ptr": (_p, [_p, _i64]),
     "pangnn_structure_small_supported": (C.c_int, [_i64, _i64]),
     "pangnn_structure_small": (C.c_int, [_p, _i64, _i64, _i64, _i32] + [_p] * 15 + [_p]),
+    "pangnn_collate_subgraphs_padded": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i32, _i64, _i64, _i64,
+                                                  _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pangnn_set_i64": (C.c_int, [_p, _p, _i32, _p]),
     "pangnn_collate_subgraphs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i32, _i64, _i64,
                                            _p, _p, _p, _p, _p, _p]),
     "pangnn_embed_linear_supported": (C.c_int, [_i32, _i32]),

@@ -389,3 +389,145 @@ extern "C" int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e,
   PG_CHECK_LAUNCH("pangnn_collate_subgraphs");
   return 0;
 }
+
+// ==============================================================================================================
+// Fixed-shape collation (round 4): the same disjoint union, of ANY list of sub-graphs (a shuffled DataLoader batch,
+// pangnn.py:152-153), written into buffers sized to the data set's maxima and padded with an inert tail, so that every
+// kernel behind it runs on one shape and ONE captured HIP graph serves every mini-batch (train.ReplayedFreshStep).  The
+// list of sub-graph ids lives in device memory (rewritten between replays by pangnn_set_i64); per-graph counts are turned
+// into offsets by every workgroup itself (<= kMaxPadGraphs entries), then a grid-stride walk fills every output.
+//   padding: similarity / neighbour edges (N_max - 1, N_max - 1) — self loops of the last node, which is never a real
+//   node (the caller sizes max_nodes > any real node count), so no real row sees them; weight 1, label 0; ptr entries
+//   beyond the batch = n, batch id of padded nodes = g; x = 1 everywhere.  live[0..3] = real edges / neighbour edges /
+//   nodes / graphs, live[4] = 1 if the batch did not fit the maxima (the outputs are then truncated and must not be used).
+// ==============================================================================================================
+namespace pangnn {
+constexpr int kMaxPadGraphs = 256;
+
+__global__ __launch_bounds__(kBlock) void collate_padded_kernel(
+    const int64_t* __restrict__ ei, int64_t ld_e, const int64_t* __restrict__ nb, int64_t ld_b,
+    const float* __restrict__ w, const float* __restrict__ y, const int64_t* __restrict__ node_off,
+    const int64_t* __restrict__ edge_off, const int64_t* __restrict__ nb_off, const int64_t* __restrict__ ids, int max_g,
+    int64_t num_graphs_total, int64_t max_e, int64_t max_b, int64_t max_n, int64_t* __restrict__ out_ei,
+    int64_t* __restrict__ out_nb, float* __restrict__ out_w, float* __restrict__ out_y, int64_t* __restrict__ ptr,
+    int64_t* __restrict__ batch, float* __restrict__ x, int64_t* __restrict__ live) {
+  __shared__ int64_t gid[kMaxPadGraphs], cn[kMaxPadGraphs + 1], ce[kMaxPadGraphs + 1], cb[kMaxPadGraphs + 1];
+  __shared__ int g_sh;
+  if (threadIdx.x == 0) {
+    int g = 0;
+    int64_t n = 0, e = 0, b = 0;
+    cn[0] = ce[0] = cb[0] = 0;
+    for (int k = 0; k < max_g; ++k) {
+      const int64_t id = ids[k];
+      if (id < 0 || id >= num_graphs_total) continue;        // unused slot
+      gid[g] = id;
+      n += node_off[id + 1] - node_off[id];
+      e += edge_off[id + 1] - edge_off[id];
+      b += nb_off[id + 1] - nb_off[id];
+      ++g;
+      cn[g] = n; ce[g] = e; cb[g] = b;
+    }
+    g_sh = g;
+  }
+  __syncthreads();
+  const int g = g_sh;
+  const int64_t n = cn[g], e = ce[g], b = cb[g];
+  const bool fits = e <= max_e && b <= max_b && n < max_n;
+  const int64_t dummy = max_n - 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    live[0] = fits ? e : 0; live[1] = fits ? b : 0; live[2] = fits ? n : 0; live[3] = g; live[4] = fits ? 0 : 1;
+  }
+  const int64_t e_r = fits ? e : 0, b_r = fits ? b : 0, n_r = fits ? n : 0;       // a batch that does not fit is all padding
+  // slot of position k among the cumulative counts c[0..g]: the j with c[j] <= k < c[j + 1]
+  auto slot = [&](const int64_t* c, int64_t k) {
+    int lo = 0, hi = g - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (c[mid] <= k) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  const int64_t total = 2 * max_e + 2 * max_b + (max_g + 1) + max_n;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int64_t k = i;
+    if (k < 2 * max_e) {
+      const int64_t row = k >= max_e, col = k - row * max_e;
+      int64_t v = dummy;
+      if (col < e_r) {
+        const int j = slot(ce, col);
+        const int64_t id = gid[j];
+        v = ei[row * ld_e + edge_off[id] + (col - ce[j])] - node_off[id] + cn[j];
+        if (row == 0) {
+          out_w[col] = w[edge_off[id] + (col - ce[j])];
+          out_y[col] = y[edge_off[id] + (col - ce[j])];
+        }
+      } else if (row == 0) {
+        out_w[col] = 1.0f;
+        out_y[col] = 0.0f;
+      }
+      out_ei[k] = v;
+      continue;
+    }
+    k -= 2 * max_e;
+    if (k < 2 * max_b) {
+      const int64_t row = k >= max_b, col = k - row * max_b;
+      int64_t v = dummy;
+      if (col < b_r) {
+        const int j = slot(cb, col);
+        const int64_t id = gid[j];
+        v = nb[row * ld_b + nb_off[id] + (col - cb[j])] - node_off[id] + cn[j];
+      }
+      out_nb[k] = v;
+      continue;
+    }
+    k -= 2 * max_b;
+    if (k <= max_g) {
+      ptr[k] = k <= g ? cn[k] : n_r;
+      continue;
+    }
+    k -= max_g + 1;
+    batch[k] = k < n_r ? slot(cn, k) : g;
+    x[k] = 1.0f;
+  }
+}
+
+struct I64x64 { int64_t v[64]; };
+__global__ void set_i64_kernel(int64_t* __restrict__ dst, I64x64 vals, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
+}  // namespace pangnn
+
+extern "C" int pangnn_collate_subgraphs_padded(const int64_t* edge_index, int64_t ld_e, const int64_t* nb_index,
+                                               int64_t ld_b, const float* edge_attr, const float* y,
+                                               const int64_t* node_off, const int64_t* edge_off, const int64_t* nb_off,
+                                               int64_t num_graphs_total, const int64_t* graph_ids, int32_t max_graphs,
+                                               int64_t max_edges, int64_t max_nb, int64_t max_nodes,
+                                               int64_t* out_edge_index, int64_t* out_nb_index, float* out_edge_attr,
+                                               float* out_y, int64_t* out_ptr, int64_t* out_batch, float* out_x,
+                                               int64_t* out_live, pangnn_stream_t stream) {
+  const char* who = "pangnn_collate_subgraphs_padded";
+  PG_CHECK_ARG(max_graphs >= 1 && max_graphs <= kMaxPadGraphs, PANGNN_E_BADARG, "%s: max_graphs must be in [1, %d]", who,
+               kMaxPadGraphs);
+  PG_CHECK_ARG(max_edges >= 1 && max_nb >= 1 && max_nodes >= 2 && num_graphs_total >= 0 && ld_e >= 0 && ld_b >= 0,
+               PANGNN_E_BADARG, "%s: bad size", who);
+  PG_CHECK_ARG(edge_index && nb_index && edge_attr && y && node_off && edge_off && nb_off && graph_ids && out_edge_index &&
+                   out_nb_index && out_edge_attr && out_y && out_ptr && out_batch && out_x && out_live,
+               PANGNN_E_BADARG, "%s: null pointer", who);
+  const int64_t total = 2 * max_edges + 2 * max_nb + (max_graphs + 1) + max_nodes;
+  hipLaunchKernelGGL(collate_padded_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, edge_index, ld_e,
+                     nb_index, ld_b, edge_attr, y, node_off, edge_off, nb_off, graph_ids, (int)max_graphs, num_graphs_total,
+                     max_edges, max_nb, max_nodes, out_edge_index, out_nb_index, out_edge_attr, out_y, out_ptr, out_batch,
+                     out_x, out_live);
+  PG_CHECK_LAUNCH(who);
+  return 0;
+}
+
+extern "C" int pangnn_set_i64(int64_t* dst, const int64_t* host_values, int32_t n, pangnn_stream_t stream) {
+  PG_CHECK_ARG(dst && host_values && n >= 1 && n <= 64, PANGNN_E_BADARG, "pangnn_set_i64: 1 <= n <= 64 values");
+  I64x64 vals;
+  for (int i = 0; i < 64; ++i) vals.v[i] = i < n ? host_values[i] : 0;
+  hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, vals, (int)n);
+  PG_CHECK_LAUNCH("pangnn_set_i64");
+  return 0;
+}

@@ -375,7 +375,7 @@ def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor) -> 
     return out
 
 
-def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 0, out=None, g_b2=None):
+def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 0, out=None, g_b2=None, live=None):
     """dL/dh1 summed over the rows of CSR order `by` ("src" / "dst") from the per-edge records of the training
     kernel: pangnn_decoder_dgrad_f32 (run parts) + the short contiguous part sum.  `g_b2`: also filled with dL/db2
     (one call per step asks for it); by = None: the parameter sums alone."""
@@ -389,10 +389,11 @@ def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         ev = _timer_start("dec.dgrad")
         _lib.check(lib.pangnn_decoder_dgrad_f32(rec.data_ptr(), None if csr is None else _lib.ptr(csr.perm),
-                                                None if plan is None else plan.keys.data_ptr(), None,
+                                                None if plan is None else plan.keys.data_ptr(),
                                                 w2.data_ptr(), w3.data_ptr(), st.num_edges, _lib.ptr(parts),
-                                                None if plan is None else plan.part_off.data_ptr(), None,
-                                                _lib.ptr(g_b2), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                                                None if plan is None else plan.part_off.data_ptr(),
+                                                _lib.ptr(g_b2), _lib.ptr(live), _lib.ptr(ws), ws_bytes,
+                                                _lib.stream_ptr()),
                    "pangnn_decoder_dgrad_f32")
         _timer_stop("dec.dgrad", ev)
     if plan is None:
@@ -401,13 +402,15 @@ def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 
 
 
 def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw=None, denom=0, g_logits=None,
-                     out_p=None, out_q=None, need_p=True, need_q=True, after_p=None):
+                     out_p=None, out_q=None, need_p=True, need_q=True, after_p=None, live=None):
     """Two-wave-per-SIMD training decoder (csrc/decoder16.hip).  One pass over the edges in the caller's order (S):
     logits, loss (y given) or the given dL/dlogits, every parameter gradient, per-source run sums when the list is
     source-sorted, and a 32-byte record per edge; then dL/dQ (and dL/dP for unsorted lists) from the records in CSR
     order (T).  No [E, 64] tensor exists.  Returns (loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3).
     `after_p(gp)` is called once dL/dP is enqueued and before the T pass (the partitioned model starts the return
-    exchange of the halo rows' gradients there, so that it runs under T)."""
+    exchange of the halo rows' gradients there, so that it runs under T).
+    `live` (device int64[1], optional): the list is a fixed-shape padded batch whose first live[0] edges are real
+    (include/pangnn_hip.h, live_edges): the padding enters no sum and the fused loss is the mean over live[0] edges."""
     lib = _lib.load()
     dev = p.device
     e, d = st.num_edges, p.shape[1]
@@ -431,7 +434,7 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
             st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
             b3.data_ptr(), d, _lib.ptr(y), _lib.ptr(pw), int(denom), _lib.ptr(g_logits), _lib.ptr(logits),
             _lib.ptr(loss), rec.data_ptr(), _lib.ptr(parts), None if plan is None else plan.part_off.data_ptr(),
-            g_w2.data_ptr(), g_w3.data_ptr(), g_b3.data_ptr(), _lib.ptr(g_cv), ws.data_ptr(),
+            g_w2.data_ptr(), g_w3.data_ptr(), g_b3.data_ptr(), _lib.ptr(g_cv), _lib.ptr(live), ws.data_ptr(),
             ws_bytes, _lib.stream_ptr()), "pangnn_decoder_train_mixed")
         _timer_stop("dec.bwd", ev)
     gp = gq = None
@@ -442,7 +445,7 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
         elif plan is not None:
             gp = _sum_parts(plan, parts, p.shape[0], out_p if out_p is not None else torch.empty(p.shape[0], d, device=dev))
         else:
-            gp = _dgrad_sum(rec, st, "src", w2, w3, p.shape[0], out_p, g_b2=b2_out)
+            gp = _dgrad_sum(rec, st, "src", w2, w3, p.shape[0], out_p, g_b2=b2_out, live=live)
             b2_out = None
         if after_p is not None:
             after_p(gp)
@@ -450,13 +453,13 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
         if e == 0:
             gq = (out_q if out_q is not None else torch.empty(q.shape[0], d, device=dev)).zero_()
         else:
-            gq = _dgrad_sum(rec, st, "dst", w2, w3, q.shape[0], out_q, g_b2=b2_out)
+            gq = _dgrad_sum(rec, st, "dst", w2, w3, q.shape[0], out_q, g_b2=b2_out, live=live)
             b2_out = None
     if b2_out is not None:
         if e == 0:
             g_b2.zero_()
         else:
-            _dgrad_sum(rec, st, None, w2, w3, g_b2=b2_out)
+            _dgrad_sum(rec, st, None, w2, w3, g_b2=b2_out, live=live)
     return loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
 
 
@@ -633,9 +636,11 @@ class _DecoderLoss(torch.autograd.Function):
     only scales the stored gradients by the upstream gradient of the loss."""
 
     @staticmethod
-    def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, pq_joint):
+    def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, pq_joint, live=None):
         lib = _lib.load()
         _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3, y, pos_weight)
+        if live is not None and (DECODER_PRECISION != 1 or live.dtype != torch.int64 or not live.is_cuda):
+            raise ValueError("live= (a padded fixed-shape batch) needs the default decoder mode and a device int64 tensor")
         rows = _rows_any if DECODER_PRECISION == 1 else _rows_f32      # bf16-stored tables: gathered as stored
         if pq_joint:
             pq = rows(p)
@@ -655,11 +660,12 @@ class _DecoderLoss(torch.autograd.Function):
             if pq_joint:
                 g_pq = torch.empty(p.shape[0], 2 * d, dtype=torch.float32, device=dev)
                 loss, logits, _, _, g_cv, g_w2, g_b2, g_w3, g_b3 = _decoder_train16(
-                    p, q, st, ex, cv, w2, b2, w3, b3, y=y, pw=pw, denom=denom, out_p=g_pq[:, :d], out_q=g_pq[:, d:])
+                    p, q, st, ex, cv, w2, b2, w3, b3, y=y, pw=pw, denom=denom, out_p=g_pq[:, :d], out_q=g_pq[:, d:],
+                    live=live)
                 gp, gq = g_pq, None
             else:
                 loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = _decoder_train16(
-                    p, q, st, ex, cv, w2, b2, w3, b3, y=y, pw=pw, denom=denom)
+                    p, q, st, ex, cv, w2, b2, w3, b3, y=y, pw=pw, denom=denom, live=live)
             ctx.has_cv, ctx.has_q = g_cv is not None, gq is not None
             ctx.save_for_backward(gp, gq if gq is not None else gp.new_empty(0),
                                   g_cv if g_cv is not None else gp.new_empty(0), g_w2, g_b2, g_w3, g_b3)
@@ -712,21 +718,23 @@ class _DecoderLoss(torch.autograd.Function):
         gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
         if is_unit_grad(go):         # `loss.backward(unit_grad(device))` (train.train_step): nothing to scale
             return (gp, gq if ctx.has_q else None, None, None, g_cv if ctx.has_cv else None,
-                    g_w2, g_b2, g_w3, g_b3, None, None, None, None)
+                    g_w2, g_b2, g_w3, g_b3, None, None, None, None, None)
         return (gp * go, (gq * go) if ctx.has_q else None, None, None, (g_cv * go) if ctx.has_cv else None,
-                g_w2 * go, g_b2 * go, g_w3 * go, g_b3 * go, None, None, None, None)
+                g_w2 * go, g_b2 * go, g_w3 * go, g_b3 * go, None, None, None, None, None)
 
 
 def decoder_loss(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
-    return _DecoderLoss.apply(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, False)
+    return _DecoderLoss.apply(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, False, None)
 
 
-def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, live=None):
+    """`live` (device int64[1]): a padded fixed-shape batch whose first live[0] edges are real (train.ReplayedFreshStep):
+    the loss is their mean and the padding contributes to no gradient"""
     _lib.require_device(pq, extra, cvec, w2, b2, w3, b3, y, pos_weight)
-    if _via_ops(st) and DECODER_PRECISION == 1:
+    if live is None and _via_ops(st) and DECODER_PRECISION == 1:
         from . import torch_ops
         return torch_ops.decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
-    return _DecoderLoss.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, True)
+    return _DecoderLoss.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, True, live)
 
 
 class _Linear(torch.autograd.Function):

@@ -217,9 +217,12 @@ class AlternateGCN(nn.Module):
             z, pending = (self.activation_fct(z) if pending else z), False
         if fused:
             pq, st, extra, cvec = self._decoder_inputs(z, graph, 1 if pending else 0)
+            # a padded fixed-shape batch (SubGraphDataset.padded_buffers) carries the number of its real edges on the device
             return PF.decoder_loss_pq(pq, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
                                       self.mlp[4].weight.view(-1), self.mlp[4].bias, labels, pos_weight,
-                                      labels.shape[0])
+                                      labels.shape[0], live=getattr(graph, "live_edges", None))
+        if getattr(graph, "live_edges", None) is not None:
+            raise NotImplementedError("a padded fixed-shape batch needs the fused training decoder (mlp decoder, node_dim 64)")
         out = self._decode(z, graph)
         return criterion(out, labels, pos_weight), out.detach()
 

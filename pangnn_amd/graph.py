@@ -73,8 +73,9 @@ class EdgeStructure:
         and global source ids (pangnn_amd/dist.py).
         `hints` (optional; set by producers that KNOW them, e.g. SubGraphDataset.batch): {"valid_ids": True} — every id
         is inside [0, num_nodes), skip the range check and its host read-back; {"sorted_by_src": bool} — whether the
-        list is source-sorted, skip that test's host read-back.  With both a structure is built without any
-        device -> host synchronisation (a fresh mini-batch per step, pangnn.py:152-216)."""
+        list is source-sorted, skip that test's host read-back; {"band_width": k} — whether the list is the whole-graph
+        positional-neighbour pattern (0: it is not), skip that comparison's host read-back.  With all of them a structure
+        is built without any device -> host synchronisation (a fresh mini-batch per step, pangnn.py:152-216)."""
         self.hints = dict(hints or {})
         self._key_tensor = edge_index        # the caches are keyed on THIS tensor's address: keep it alive
         self.edge_index = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
@@ -155,6 +156,8 @@ class EdgeStructure:
         (dataset.py:356-361: edges (i, j), j in [i - k, i + k] within [0, N), self loops included, in nested-loop order) —
         a band matrix, propagated without index arrays (pangnn_band_propagate); 0 for any other list.  Decided once per
         structure by comparing with the generated pattern (one host sync)."""
+        if self._band is None and "band_width" in self.hints:      # the producer knows (a collated batch: 0), no host sync
+            self._band = int(self.hints["band_width"])
         if self._band is None:
             self._band = 0
             n, e = self.num_nodes, self.num_edges

@@ -244,6 +244,103 @@ class SubGraphDataset:
     def graph(self, i: int):
         return self.batch(i, i + 1)
 
+    # ---- fixed-shape batches (train.ReplayedFreshStep): one set of buffers, one captured HIP graph, every mini-batch
+    def padded_spec(self, batch_size: int = 32, graphs=None, slack: Optional[float] = None):
+        """(max_graphs, max_nodes, max_edges, max_nb): shapes that hold the disjoint union of ANY `batch_size` sub-graphs out
+        of `graphs` (default: all) — the sums of the `batch_size` largest counts, plus the one node that is never real
+        (the padding's endpoint).  `slack`: instead `slack` times the MEAN batch (capped by the worst case) — what a
+        shuffled batch needs in practice (the sum of 32 draws concentrates around its mean); a batch that does not fit is
+        refused by `set_graph_ids`, and the caller keeps a worst-case set of buffers for it (train.ReplayedFreshStep).
+        Host arithmetic on the offset tables, which are read back once per data set."""
+        h = self._host()
+        idx = list(range(self.num_graphs)) if graphs is None else [int(i) for i in graphs]
+        bs = int(batch_size)
+
+        def cap(off):
+            sizes = sorted((off[i + 1] - off[i] for i in idx), reverse=True)
+            worst = sum(sizes[:bs])
+            if slack is None or not sizes:
+                return worst
+            return min(worst, int(float(slack) * bs * sum(sizes) / len(sizes)) + 1)
+        return bs, cap(h.node) + 1, max(cap(h.edge), 1), max(cap(h.nb), 1)
+
+    def fits(self, spec, ids) -> bool:
+        """whether the disjoint union of the sub-graphs `ids` fits the padded shapes `spec` (host arithmetic)"""
+        h = self._host()
+        ids = [int(i) for i in ids]
+        return len(ids) <= spec[0] and sum(h.node[i + 1] - h.node[i] for i in ids) < spec[1] \
+            and sum(h.edge[i + 1] - h.edge[i] for i in ids) <= spec[2] and sum(h.nb[i + 1] - h.nb[i] for i in ids) <= spec[3]
+
+    def padded_buffers(self, spec):
+        """the fixed buffers of a padded batch + the device list of sub-graph ids it is collated from"""
+        g, n, e, b = spec
+        dev = self.edge_index.device
+        i64 = torch.empty(2 * e + 2 * b + (g + 1) + n + 8 + g + 16, dtype=torch.int64, device=dev)
+        f32 = torch.empty(2 * e + n + 16, dtype=torch.float32, device=dev)
+        o = [0]
+
+        def take(buf, k):                       # segments start on 16-byte boundaries
+            v = buf[o[0]:o[0] + k]
+            o[0] += -(-k * buf.element_size() // 16) * 16 // buf.element_size()
+            return v
+        ei, nb = take(i64, 2 * e).view(2, e), take(i64, 2 * b).view(2, b)
+        ptr, bid, live, ids = take(i64, g + 1), take(i64, n), take(i64, 8), take(i64, g)
+        ids.fill_(-1)
+        live.zero_()
+        o[0] = 0
+        w, y, x = take(f32, e), take(f32, e), take(f32, n).view(n, 1)
+        hints = {"sim": {"valid_ids": True, "sorted_by_src": self._host().sorted_by_src, "band_width": 0},
+                 "nb": {"valid_ids": True, "band_width": 0}}
+        return SimpleNamespace(_pangnn_hints=hints, x=x, edge_index=ei, edge_attr=w, y=y, neighbour_edge_index=nb, ptr=ptr,
+                               batch=bid, live=live, live_edges=live[:1], graph_ids=ids, spec=tuple(spec), num_graphs=g)
+
+    def collate_padded(self, buf):
+        """(re)fill the padded batch `buf` from the sub-graph ids in buf.graph_ids (device): ONE launch, no host read-back;
+        capturable — a replay collates whatever ids the list holds at that moment"""
+        from . import _lib
+        lib = _lib.load()
+        g, n, e, b = buf.spec
+        src_ei, src_nb = self.edge_index, self.neighbour_edge_index
+        if not (src_ei.is_contiguous() and src_nb.is_contiguous() and self.node_off.is_contiguous()
+                and self.edge_off.is_contiguous() and self.nb_off.is_contiguous() and self.edge_attr.is_contiguous()
+                and self.y.is_contiguous()):
+            raise ValueError("SubGraphDataset tensors must be contiguous")
+        if self.edge_attr.dtype != torch.float32 or self.y.dtype != torch.float32:
+            raise ValueError("edge_attr / y must be float32")
+        with _lib.device_guard(src_ei.device):
+            _lib.check(lib.pangnn_collate_subgraphs_padded(
+                src_ei.data_ptr(), src_ei.shape[1], src_nb.data_ptr(), src_nb.shape[1], self.edge_attr.data_ptr(),
+                self.y.data_ptr(), self.node_off.data_ptr(), self.edge_off.data_ptr(), self.nb_off.data_ptr(),
+                self.num_graphs, buf.graph_ids.data_ptr(), g, e, b, n, buf.edge_index.data_ptr(),
+                buf.neighbour_edge_index.data_ptr(), buf.edge_attr.data_ptr(), buf.y.data_ptr(), buf.ptr.data_ptr(),
+                buf.batch.data_ptr(), buf.x.data_ptr(), buf.live.data_ptr(), _lib.stream_ptr()),
+                "pangnn_collate_subgraphs_padded")
+        return buf
+
+    def set_graph_ids(self, buf, ids):
+        """hand the next batch's sub-graph ids (host ints, at most buf.spec[0] and 64) to the device list: one tiny launch whose
+        arguments carry the values (no staging buffer that a later call could overwrite before it is read); returns the
+        batch's real (nodes, edges, neighbour edges) — host arithmetic"""
+        import ctypes
+        from . import _lib
+        g = buf.spec[0]
+        ids = [int(i) for i in ids]
+        if not 0 < len(ids) <= min(g, 64) or g > 64:
+            raise ValueError(f"a padded batch takes 1..{min(g, 64)} sub-graph ids")
+        if min(ids) < 0 or max(ids) >= self.num_graphs:
+            raise ValueError("sub-graph id out of range")
+        h = self._host()
+        n = sum(h.node[i + 1] - h.node[i] for i in ids)
+        e = sum(h.edge[i + 1] - h.edge[i] for i in ids)
+        b = sum(h.nb[i + 1] - h.nb[i] for i in ids)
+        if n >= buf.spec[1] or e > buf.spec[2] or b > buf.spec[3]:
+            raise ValueError(f"batch ({n} nodes, {e} edges, {b} neighbour edges) does not fit the padded shapes {buf.spec}")
+        vals = (ctypes.c_int64 * g)(*(ids + [-1] * (g - len(ids))))
+        with _lib.device_guard(buf.graph_ids.device):
+            _lib.check(_lib.load().pangnn_set_i64(buf.graph_ids.data_ptr(), ctypes.cast(vals, ctypes.c_void_p), g,
+                                                  _lib.stream_ptr()), "pangnn_set_i64")
+        return n, e, b
+
     def class_balance(self):
         pos = self.y.sum().clamp_min(1)
         return ((self.y == 0).sum() / pos).to(torch.float32)

@@ -268,3 +268,25 @@ def test_balanced_bounds_give_every_rank_the_same_share_of_edges(n, G, world):
     if (G, world) == (3, 3):              # one genome per rank: the middle one has twice the in-edges
         assert float(eq.max() / eq.mean()) > 1.4
     assert balanced_bounds(n, G, 1) == [0, n * G]
+
+
+def test_padded_batch_shapes_are_host_arithmetic_on_the_offset_tables():
+    """SubGraphDataset.padded_spec / fits (train.ReplayedFreshStep's fixed shapes): the worst case holds ANY 32 sub-graphs,
+    the slack form holds slack x the mean batch, and `fits` agrees with the sums (no GPU involved)"""
+    from pangnn_amd import simulate
+    ds = simulate.simulate_subgraph_dataset(200, 4, 0.3, 10, 2, seed=0, device="cpu")
+    h = ds._host()
+    sizes = lambda off: [off[i + 1] - off[i] for i in range(ds.num_graphs)]     # noqa: E731
+    g, n, e, b = ds.padded_spec(32)
+    assert g == 32 and n == sum(sorted(sizes(h.node))[-32:]) + 1 and e == sum(sorted(sizes(h.edge))[-32:])
+    assert b == sum(sorted(sizes(h.nb))[-32:])
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(20):
+        ids = torch.randperm(ds.num_graphs, generator=gen)[:32].tolist()
+        assert ds.fits((g, n, e, b), ids)
+    tight = ds.padded_spec(32, slack=1.3)
+    assert tight[1] <= n and tight[2] <= e and tight[3] <= b and tight[2] >= 32 * sum(sizes(h.edge)) / ds.num_graphs
+    big = sorted(range(ds.num_graphs), key=lambda i: -(h.edge[i + 1] - h.edge[i]))[:32]
+    assert ds.fits((g, n, e, b), big) and not ds.fits(tight, big) and not ds.fits((g, n, e, b), list(range(33)))
+    sub = ds.padded_spec(8, graphs=range(20))
+    assert sub[0] == 8 and sub[2] == sum(sorted(sizes(h.edge)[:20])[-8:])

@@ -827,6 +827,106 @@ def test_hip_graph_replay_equals_eager_steps():
         assert torch.equal(a, b)
 
 
+def _padded_reference_batch(ds, ids):
+    """the disjoint union of the sub-graphs `ids` built with torch index ops on the host (what Batch.from_data_list does)"""
+    h = ds._host()
+    ei, nb, w, y, n = [], [], [], [], 0
+    for i in ids:
+        n0, e0, e1, b0, b1 = h.node[i], h.edge[i], h.edge[i + 1], h.nb[i], h.nb[i + 1]
+        ei.append(ds.edge_index[:, e0:e1] - n0 + n)
+        nb.append(ds.neighbour_edge_index[:, b0:b1] - n0 + n)
+        w.append(ds.edge_attr[e0:e1]); y.append(ds.y[e0:e1])
+        n += h.node[i + 1] - n0
+    return torch.cat(ei, 1), torch.cat(nb, 1), torch.cat(w), torch.cat(y), n
+
+
+def test_padded_collation_is_the_disjoint_union_plus_an_inert_tail():
+    """pangnn_collate_subgraphs_padded on a SHUFFLED id list: the real part equals the index-op union entry for entry,
+    the tail is self loops of the last (never real) node with weight 1 / label 0, live counts are the real counts"""
+    from pangnn_amd import simulate
+    ds = simulate.simulate_subgraph_dataset(300, 4, 0.3, 10, 2, seed=5, device=dev())
+    spec = ds.padded_spec(32)
+    buf = ds.padded_buffers(spec)
+    gen = torch.Generator().manual_seed(1)
+    for count in (32, 7, 1):
+        ids = torch.randperm(ds.num_graphs, generator=gen)[:count].tolist()
+        n, e, b = ds.set_graph_ids(buf, ids)
+        ds.collate_padded(buf)
+        ei, nb, w, y, n_ref = _padded_reference_batch(ds, ids)
+        assert (n, e, b) == (n_ref, ei.shape[1], nb.shape[1])
+        assert buf.live.tolist()[:5] == [e, b, n, count, 0]
+        assert torch.equal(buf.edge_index[:, :e], ei) and torch.equal(buf.neighbour_edge_index[:, :b], nb)
+        assert torch.equal(buf.edge_attr[:e], w) and torch.equal(buf.y[:e], y)
+        last = spec[1] - 1
+        assert bool((buf.edge_index[:, e:] == last).all()) and bool((buf.neighbour_edge_index[:, b:] == last).all())
+        assert bool((buf.edge_attr[e:] == 1).all()) and bool((buf.y[e:] == 0).all()) and bool((buf.x == 1).all())
+        assert n < spec[1] and int(buf.edge_index[:, :e].max()) < n
+        ptr = buf.ptr.tolist()
+        assert ptr[0] == 0 and ptr[count] == n and all(v == n for v in ptr[count:])
+        bid = buf.batch[:n]
+        assert torch.equal(bid, torch.searchsorted(buf.ptr[1:count + 1].contiguous(), torch.arange(n, device=dev()), right=True))
+        assert bool((buf.batch[n:] == count).all())
+    with pytest.raises(ValueError):
+        ds.set_graph_ids(ds.padded_buffers((32, 10, 10, 10)), list(range(32)))          # does not fit: refused on the host
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True)], ids=["default", "skip"])
+def test_replayed_fresh_step_serves_every_batch(flags):
+    """train.ReplayedFreshStep — the reference's DataLoader(batch_size=32, shuffle=True) loop (pangnn.py:152-216) as ONE
+    captured HIP graph over fixed-shape padded buffers:
+      (i)  replaying it over a shuffled schedule == running the same padded step eagerly, bit for bit (loss, logits,
+           parameters after every step), including a batch that overflows the everyday buffers (worst-case slot) and a
+           short last batch;
+      (ii) the padded step == the unpadded fresh step (train_step on the index-op union) to fp32 re-association:
+           loss 1e-6, logits 1e-5, parameter gradients 1e-5 of their scale."""
+    import pangnn_amd
+    from types import SimpleNamespace
+    from pangnn_amd import simulate
+    from pangnn_amd.train import ReplayedFreshStep, make_optimizer, train_step
+    ds = simulate.simulate_subgraph_dataset(300, 4, 0.3, 10, 2, seed=5, device=dev())
+    pw = ds.class_balance()
+    gen = torch.Generator().manual_seed(3)
+    perm = torch.randperm(ds.num_graphs, generator=gen).tolist()
+    schedule = [perm[i:i + 32] for i in range(0, len(perm), 32)]
+    h = ds._host()
+    big = sorted(range(ds.num_graphs), key=lambda i: h.edge[i] - h.edge[i + 1])[:32]      # the 32 largest sub-graphs
+    schedule = schedule[:4] + [big] + schedule[4:7] + [perm[:5]]
+
+    def make(capture):
+        torch.manual_seed(0)
+        model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], **flags)
+        opt = make_optimizer(model, capturable=True)
+        return model, opt, ReplayedFreshStep(model, opt, ds, pw, 32, capture=capture, warmup=1, slack=1.2)
+
+    ma, oa, sa = make(True)
+    mb, ob, sb = make(False)
+    assert not ds.fits(sa.spec, big) and ds.fits(sa.spec_worst, big)        # the schedule does exercise the second slot
+    for k, ids in enumerate(schedule):
+        la, xa = sa(ids)
+        lb, xb = sb(ids)
+        assert xa.shape == xb.shape == (sum(h.edge[i + 1] - h.edge[i] for i in ids),)
+        assert torch.equal(la, lb) and torch.equal(xa, xb), (k, float(la), float(lb))
+        for p, q in zip(ma.parameters(), mb.parameters()):
+            assert torch.equal(p, q), k
+    assert len(sa._slots) == 2
+
+    # (ii) against the unpadded step on the same union, from the same parameters (one step each, gradients compared)
+    torch.manual_seed(0)
+    mc = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], **flags)
+    oc = make_optimizer(mc, capturable=True)
+    for ids in (schedule[0], schedule[-1]):
+        mc.load_state_dict(mb.state_dict())
+        ei, nb, w, y, n = _padded_reference_batch(ds, ids)
+        batch = SimpleNamespace(x=torch.ones(n, 1, device=dev()), edge_index=ei.contiguous(), edge_attr=w.contiguous(),
+                                y=y.contiguous(), neighbour_edge_index=nb.contiguous())
+        lc, xc = train_step(mc, oc, batch, batch.y, pw)
+        lb, xb = sb(ids)
+        assert close(lb, lc, atol=1e-6, rtol=1e-6) and close(xb, xc, atol=1e-5, rtol=1e-5)
+        for (k, p), (_, q) in zip(mb.named_parameters(), mc.named_parameters()):
+            scale = float(q.grad.abs().max()) + 1e-12
+            assert close(p.grad, q.grad, atol=1e-5 * scale + 1e-9, rtol=1e-4), k
+
+
 @pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True)], ids=["default", "skip"])
 def test_fused_loss_pass_equals_forward_criterion_backward(flags):
     """model.loss_and_logits (one decoder pass: logits + BCE + all gradients) vs model() + criterion +
@@ -951,7 +1051,7 @@ def test_full_size_S_and_T_kernels_agree_on_by_source_sums(skip):
         P.data_ptr(), 64, Q.data_ptr(), 64, 0, n, st.edge_index.data_ptr(), e, e, PF._lib.ptr(ex), PF._lib.ptr(cv),
         W2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), 64, g.y.data_ptr(), pw.data_ptr(), e, None, lg.data_ptr(),
         ls.data_ptr(), rec.data_ptr(), parts.data_ptr(), plan.part_off.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
-        outs[2].data_ptr(), None if cv is None else torch.empty_like(cv).data_ptr(), ws.data_ptr(), ws.numel(),
+        outs[2].data_ptr(), None if cv is None else torch.empty_like(cv).data_ptr(), None, ws.data_ptr(), ws.numel(),
         PF._lib.stream_ptr()), "pangnn_decoder_train_mixed")
     gp_s2 = PF._sum_parts(plan, parts, n, torch.empty(n, 64, device=dev()))
     assert torch.equal(gp_s2, gp_s) and torch.equal(lg, logits)

@@ -50,17 +50,17 @@ def run(e, srt, skip, n=97, seed=None):
                                             _lib.ptr(ex_), _lib.ptr(cv_), w2_.data_ptr(), b2_.data_ptr(), w3_.data_ptr(),
                                             b3_.data_ptr(), 64, None, None, 0, g_.data_ptr(), None, None, rec.data_ptr(),
                                             _lib.ptr(parts), None if plan is None else plan.part_off.data_ptr(),
-                                            gw2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(), _lib.ptr(gcv),
+                                            gw2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(), _lib.ptr(gcv), None,
                                             ws.data_ptr(), wsb, _lib.stream_ptr()), "train")
     torch.cuda.synchronize()
     msg = f"E={e} sorted={srt} skip={skip}:"
     # mask flips: m1 bits of the records vs fp64 sign
     r = rec.cpu()
     m1_ref = (h1p > 0)
-    # bit for k = 32 ks + 8 g' + s in dword g': 16 (s & 1) + 7 - (4 ks + (s >> 1))
+    # bit for k = 32 ks + 8 g' + s in dword g': 16 (s & 1) + 15 - (4 ks + (s >> 1))   (round 4: m1 in the high byte of each half)
     k = torch.arange(64)
     ks, gq, s = k >> 5, (k >> 3) & 3, k & 7
-    bit = 16 * (s & 1) + 7 - (4 * ks + (s >> 1))
+    bit = 16 * (s & 1) + 15 - (4 * ks + (s >> 1))
     words = r[:, :4].long() & 0xffffffff
     m1 = ((words[:, gq] >> bit) & 1).bool()
     flips = (m1 != m1_ref).nonzero()

@@ -63,7 +63,7 @@ def run(lib, fused, skip=False, pq16=False, timing=None):
         w3.data_ptr(), b3.data_ptr(), 64, g.y.data_ptr() if fused else None, pw.data_ptr() if fused else None,
         e if fused else 0, None if fused else gl.data_ptr(), logits.data_ptr(), loss.data_ptr() if fused else None,
         rec.data_ptr(), parts.data_ptr(), plan.part_off.data_ptr(), gw2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(),
-        gcv.data_ptr() if skip else None, ws.data_ptr(), wsb, _lib.stream_ptr())
+        gcv.data_ptr() if skip else None, None, ws.data_ptr(), wsb, _lib.stream_ptr())
     ev1.record()
     assert rc == 0, lib.pangnn_last_error()
     torch.cuda.synchronize()

@@ -50,7 +50,7 @@ def run(name):
         P.data_ptr(), 64, Q.data_ptr(), 64, 0, n, st.edge_index.data_ptr(), e, e, extra.data_ptr(), cv.data_ptr(),
         W2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), 64, None, None, 0, gl.data_ptr(), logits.data_ptr(), None,
         rec.data_ptr(), parts.data_ptr(), plan.part_off.data_ptr(), gw2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(),
-        gcv.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+        gcv.data_ptr(), None, ws.data_ptr(), wsb, _lib.stream_ptr())
     assert rc == 0, lib.pangnn_last_error()
     torch.cuda.synchronize()
     return dump, rec
