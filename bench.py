@@ -277,6 +277,9 @@ def main():
     ap.add_argument("--cpu-genes", type=int, default=2500, help="genes per genome of the CPU-baseline sample (1/20 of cfg 4)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-siblings", action="store_true",
+                    help="keep the general-feature and strict-fp32 timings but skip the siblings that build their own data "
+                         "(cfg5slice, mini-batch regimes): what the counter passes of tools/pmc_traffic.sh want")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sibling timings (general-feature step, strict fp32, cfg5slice, mini-batch regimes)")
     ap.add_argument("--seed", type=int, default=0)
@@ -505,7 +508,7 @@ def main():
             PF.KERNEL_TIMER = None
         # (iii) the other regimes of the path, timed in this process after the headline (each builds its own data):
         # config 5's per-GPU slice, and the reference's mini-batch regime replayed / with a fresh Batch per step
-        if args.workload == "cfg4" and not args.genes:
+        if args.workload == "cfg4" and not args.genes and not args.no_siblings:
             for key, fn in (("cfg5slice", lambda: cfg5slice_sibling(dev, max(args.steps // 2, 5), args.seed)),
                             ("cfg2mb", lambda: _mb_sibling("cfg2mb", dev, args.seed)),
                             ("cfg2mb_fresh", lambda: _mb_sibling("cfg2mb_fresh", dev, args.seed))):

@@ -91,8 +91,10 @@ int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e, int64_t e0
  * DataLoader(batch_size=32, shuffle=True) loop, pangnn.py:152-216): the disjoint union of the sub-graphs whose ids are in the
  * DEVICE list graph_ids[max_graphs] (entries outside [0, num_graphs_total) are unused slots), in list order, written into
  * buffers of the fixed sizes max_edges / max_nb / max_nodes and padded with an inert tail: padded similarity and neighbour
- * edges are self loops (max_nodes - 1, max_nodes - 1) of a node that is never real (max_nodes must exceed every batch's
- * node count), with weight 1 and label 0; out_ptr entries beyond the batch = n, out_batch of padded nodes = g, out_x = 1.
+ * edges are self loops of the padded nodes [n, max_nodes) — never real (max_nodes must exceed every batch's node count) —
+ * spread evenly over them with non-decreasing ids (the lists stay source-sorted, the padding sorts last in both CSR orders
+ * and no padded row is long), with weight 1 and label 0; out_ptr entries beyond the batch = n, out_batch of padded nodes =
+ * g, out_x = 1.
  * node_off / edge_off / nb_off are the data set's [num_graphs_total + 1] offset tables (device); edge_attr / y its flat
  * per-edge arrays.  out_live[5] (device) = real similarity edges, neighbour edges, nodes, graphs, and 1 if the batch did
  * not fit (everything is then padding).  out_live is what the decoder entry points take as `live_edges`. */

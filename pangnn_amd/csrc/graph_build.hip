@@ -396,9 +396,9 @@ extern "C" int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e,
 // kernel behind it runs on one shape and ONE captured HIP graph serves every mini-batch (train.ReplayedFreshStep).  The
 // list of sub-graph ids lives in device memory (rewritten between replays by pangnn_set_i64); per-graph counts are turned
 // into offsets by every workgroup itself (<= kMaxPadGraphs entries), then a grid-stride walk fills every output.
-//   padding: similarity / neighbour edges (N_max - 1, N_max - 1) — self loops of the last node, which is never a real
-//   node (the caller sizes max_nodes > any real node count), so no real row sees them; weight 1, label 0; ptr entries
-//   beyond the batch = n, batch id of padded nodes = g; x = 1 everywhere.  live[0..3] = real edges / neighbour edges /
+//   padding: similarity / neighbour edges are self loops of the padded nodes [n, N_max) — never real nodes (the caller
+//   sizes max_nodes > any real node count), so no real row sees them —, spread evenly over them in non-decreasing id
+//   order; weight 1, label 0; ptr entries beyond the batch = n, batch id of padded nodes = g; x = 1 everywhere.  live[0..3] = real edges / neighbour edges /
 //   nodes / graphs, live[4] = 1 if the batch did not fit the maxima (the outputs are then truncated and must not be used).
 // ==============================================================================================================
 namespace pangnn {
@@ -433,11 +433,14 @@ __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
   const int g = g_sh;
   const int64_t n = cn[g], e = ce[g], b = cb[g];
   const bool fits = e <= max_e && b <= max_b && n < max_n;
-  const int64_t dummy = max_n - 1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     live[0] = fits ? e : 0; live[1] = fits ? b : 0; live[2] = fits ? n : 0; live[3] = g; live[4] = fits ? 0 : 1;
   }
   const int64_t e_r = fits ? e : 0, b_r = fits ? b : 0, n_r = fits ? n : 0;       // a batch that does not fit is all padding
+  // padded edge j of P goes to padded node n_r + floor(j (max_n - n_r) / P): non-decreasing ids >= n_r (the lists stay
+  // source-sorted, the pads sort last in both CSR orders) and spread evenly — ONE padded node would be a row of
+  // thousands of entries that a single lane group of the thin-row propagate walks serially (0.6 ms per step, measured)
+  const int64_t n_padn = max_n - n_r, p_e = max_e - e_r, p_b = max_b - b_r;
   // slot of position k among the cumulative counts c[0..g]: the j with c[j] <= k < c[j + 1]
   auto slot = [&](const int64_t* c, int64_t k) {
     int lo = 0, hi = g - 1;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
     int64_t k = i;
     if (k < 2 * max_e) {
       const int64_t row = k >= max_e, col = k - row * max_e;
-      int64_t v = dummy;
+      int64_t v = n_r + ((col - e_r) * n_padn) / (p_e > 0 ? p_e : 1);
       if (col < e_r) {
         const int j = slot(ce, col);
         const int64_t id = gid[j];
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
     k -= 2 * max_e;
     if (k < 2 * max_b) {
       const int64_t row = k >= max_b, col = k - row * max_b;
-      int64_t v = dummy;
+      int64_t v = n_r + ((col - b_r) * n_padn) / (p_b > 0 ? p_b : 1);
       if (col < b_r) {
         const int j = slot(cb, col);
         const int64_t id = gid[j];

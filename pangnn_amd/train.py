@@ -125,7 +125,7 @@ class ReplayedFreshStep:
     therefore bound by the host's launch path (0.7-0.86 ms per step).  Here all of it is captured once:
       * the batch lives in buffers of FIXED shapes sized to the data set's maxima (`SubGraphDataset.padded_spec`), collated
         on the device from a device-resident list of sub-graph ids by `pangnn_collate_subgraphs_padded`, with an inert padded
-        tail (self loops of a node that is never real; the decoder kernels take the number of real edges from device memory:
+        tail (self loops spread over the padded nodes, which are never real; the decoder kernels take the number of real edges from device memory:
         padded edges get dL/dlogit = 0 and the loss is the mean over the real ones);
       * so every kernel of the step runs on one shape, none of them needs a host-known size of the batch, and nothing reads
         back: the step is capturable, and a replay collates and trains on whatever ids the list holds at that moment.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the training decoder kernel (two rocprofv3 --pmc passes over tools/time_decoder_modes.py).
+# SQ counters of the training decoder kernel (two rocprofv3 --pmc passes over tools/time_decoder_ab.py).
 # usage (on the GPU box, from the repo root): bash tools/pmc_decoder.sh <out_dir> [kernel-name substring]
 set -e
 OUT=${1:-gpurun_out/pmc_dec}
@@ -8,11 +8,11 @@ ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-  --kernel-trace -d /tmp/pmcA -o a --output-format csv -- python3 "$ROOT/tools/time_decoder_modes.py" > "$ROOT/$OUT/passA.log" 2>&1
+  --kernel-trace -d /tmp/pmcA -o a --output-format csv -- python3 "$ROOT/tools/time_decoder_ab.py" > "$ROOT/$OUT/passA.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD \
-  --kernel-trace -d /tmp/pmcB -o b --output-format csv -- python3 "$ROOT/tools/time_decoder_modes.py" > "$ROOT/$OUT/passB.log" 2>&1
+  --kernel-trace -d /tmp/pmcB -o b --output-format csv -- python3 "$ROOT/tools/time_decoder_ab.py" > "$ROOT/$OUT/passB.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
-  --kernel-trace -d /tmp/pmcC -o c --output-format csv -- python3 "$ROOT/tools/time_decoder_modes.py" > "$ROOT/$OUT/passC.log" 2>&1 || true
+  --kernel-trace -d /tmp/pmcC -o c --output-format csv -- python3 "$ROOT/tools/time_decoder_ab.py" > "$ROOT/$OUT/passC.log" 2>&1 || true
 cd "$ROOT"
 for p in A B C; do
   f=$(find /tmp/pmc$p -name '*counter_collection.csv' | head -1)
