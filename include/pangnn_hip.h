@@ -98,13 +98,33 @@ int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e, int64_t e0
  * node_off / edge_off / nb_off are the data set's [num_graphs_total + 1] offset tables (device); edge_attr / y its flat
  * per-edge arrays.  out_live[5] (device) = real similarity edges, neighbour edges, nodes, graphs, and 1 if the batch did
  * not fit (everything is then padding).  out_live is what the decoder entry points take as `live_edges`. */
+/* One CSR order (by target / by source) of one edge list of a padded batch.  `rank` (in, per FLAT edge of the data set):
+ * the edge's position among its own sub-graph's edges in this order (stable: equal keys keep list order) — a property of the
+ * data set, computed once.  Outputs (device): rowptr [max_nodes + 1], other / perm / keys [max list length] as
+ * pangnn_structure_small writes them; part_off / part_rowptr / last_part (nullable together): the run-sum plan of the order. */
+typedef struct pangnn_batch_order {
+  const int32_t* rank;
+  int64_t* rowptr; int32_t* other; int32_t* perm; int32_t* keys;
+  int32_t* part_off; int64_t* part_rowptr; int64_t* last_part;
+} pangnn_batch_order;
+/* `orders` of pangnn_collate_subgraphs_padded (nullable): also emit both CSR orders of both lists of the batch — without a
+ * sort: sub-graph j's nodes all precede those of sub-graph j + 1, so the batch's order is the sub-graphs' own (static) orders
+ * one after the other, sorted position = first edge of the sub-graph + rank; the padding is in order behind them.  The same
+ * tables, entry for entry, as pangnn_structure_small on the collated lists (which costs a 70 us one-workgroup bitonic sort per
+ * list).  chunk_edges: 32 * pangnn_decoder_chunk_tiles_for(max_edges).  Needs max_edges, max_nb, max_nodes within
+ * pangnn_structure_small_supported. */
+typedef struct pangnn_batch_orders {
+  int32_t chunk_edges;
+  pangnn_batch_order sim_dst, sim_src, nb_dst, nb_src;
+} pangnn_batch_orders;
 int pangnn_collate_subgraphs_padded(const int64_t* edge_index, int64_t ld_e, const int64_t* nb_index, int64_t ld_b,
                                     const float* edge_attr, const float* y, const int64_t* node_off,
                                     const int64_t* edge_off, const int64_t* nb_off, int64_t num_graphs_total,
                                     const int64_t* graph_ids, int32_t max_graphs, int64_t max_edges, int64_t max_nb,
                                     int64_t max_nodes, int64_t* out_edge_index, int64_t* out_nb_index,
                                     float* out_edge_attr, float* out_y, int64_t* out_ptr, int64_t* out_batch,
-                                    float* out_x, int64_t* out_live, pangnn_stream_t stream);
+                                    float* out_x, int64_t* out_live, const pangnn_batch_orders* orders,
+                                    pangnn_stream_t stream);
 /* dst[0 .. n) (device) = host_values[0 .. n), n <= 64, carried in the kernel arguments of one tiny launch: ordered with the
  * stream like any kernel and safe to call again before it ran (no pinned staging buffer to overwrite) — how the host hands
  * the next batch's sub-graph ids to a captured graph. */

@@ -26,7 +26,7 @@ SIGNATURES = {
     "pangnn_structure_small_supported": (C.c_int, [_i64, _i64]),
     "pangnn_structure_small": (C.c_int, [_p, _i64, _i64, _i64, _i32] + [_p] * 15 + [_p]),
     "pangnn_collate_subgraphs_padded": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i32, _i64, _i64, _i64,
-                                                  _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+                                                  _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pangnn_set_i64": (C.c_int, [_p, _p, _i32, _p]),
     "pangnn_collate_subgraphs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i32, _i64, _i64,
                                            _p, _p, _p, _p, _p, _p]),

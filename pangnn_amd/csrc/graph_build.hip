@@ -403,6 +403,8 @@ extern "C" int pangnn_collate_subgraphs(const int64_t* edge_index, int64_t ld_e,
 // ==============================================================================================================
 namespace pangnn {
 constexpr int kMaxPadGraphs = 256;
+struct BatchOrder { const int32_t* rank; int32_t* other; int32_t* perm; int32_t* keys; };
+struct BatchOrders { int enabled; BatchOrder sim_dst, sim_src, nb_dst, nb_src; };
 
 __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
     const int64_t* __restrict__ ei, int64_t ld_e, const int64_t* __restrict__ nb, int64_t ld_b,
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
     const int64_t* __restrict__ edge_off, const int64_t* __restrict__ nb_off, const int64_t* __restrict__ ids, int max_g,
     int64_t num_graphs_total, int64_t max_e, int64_t max_b, int64_t max_n, int64_t* __restrict__ out_ei,
     int64_t* __restrict__ out_nb, float* __restrict__ out_w, float* __restrict__ out_y, int64_t* __restrict__ ptr,
-    int64_t* __restrict__ batch, float* __restrict__ x, int64_t* __restrict__ live) {
+    int64_t* __restrict__ batch, float* __restrict__ x, int64_t* __restrict__ live, BatchOrders ord) {
   __shared__ int64_t gid[kMaxPadGraphs], cn[kMaxPadGraphs + 1], ce[kMaxPadGraphs + 1], cb[kMaxPadGraphs + 1];
   __shared__ int g_sh;
   if (threadIdx.x == 0) {
@@ -450,6 +452,37 @@ __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
     }
     return lo;
   };
+  // ---- both CSR orders of both lists WITHOUT a sort (round 4): inside a sub-graph the by-target / by-source order of its
+  // edges never changes, so the data set holds every edge's position inside its sub-graph in each order (`rank`, computed
+  // once); the batch's order is the sub-graphs' orders one after the other (sub-graph j's node ids all precede those of
+  // j + 1), i.e. sorted position = first edge of the sub-graph + rank.  The padding is already in order behind them.
+  // Emits perm / other / keys of each order; rowptr and the run-sum plans follow from the sorted keys (order_walk_kernel).
+  if (ord.enabled) {
+    const int64_t tot_o = max_e + max_b;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < tot_o; i += (int64_t)gridDim.x * kBlock) {
+      const bool sim = i < max_e;
+      const int64_t col = sim ? i : i - max_e;
+      const int64_t real = sim ? e_r : b_r, p_l = sim ? p_e : p_b;
+      const BatchOrder od = sim ? ord.sim_dst : ord.nb_dst, os = sim ? ord.sim_src : ord.nb_src;
+      if (col < real) {
+        const int64_t* c = sim ? ce : cb;
+        const int j = slot(c, col);
+        const int64_t id = gid[j];
+        const int64_t t = (sim ? edge_off[id] : nb_off[id]) + (col - c[j]);            // flat edge
+        const int64_t shift = cn[j] - node_off[id];
+        const int64_t* src_l = sim ? ei : nb;
+        const int64_t ld = sim ? ld_e : ld_b;
+        const int32_t sv = (int32_t)(src_l[t] + shift), dv = (int32_t)(src_l[ld + t] + shift);
+        const int64_t pd = c[j] + od.rank[t], ps = c[j] + os.rank[t];
+        od.perm[pd] = (int32_t)col; od.other[pd] = sv; od.keys[pd] = dv;
+        os.perm[ps] = (int32_t)col; os.other[ps] = dv; os.keys[ps] = sv;
+      } else {
+        const int32_t v = (int32_t)(n_r + ((col - real) * n_padn) / (p_l > 0 ? p_l : 1));
+        od.perm[col] = (int32_t)col; od.other[col] = v; od.keys[col] = v;
+        os.perm[col] = (int32_t)col; os.other[col] = v; os.keys[col] = v;
+      }
+    }
+  }
   const int64_t total = 2 * max_e + 2 * max_b + (max_g + 1) + max_n;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     int64_t k = i;
@@ -494,6 +527,67 @@ __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
   }
 }
 
+// rowptr and the run-sum plan of up to four orders from their SORTED int32 keys, one workgroup per order: the walk of
+// small_structure_kernel (same part ids, same rowptr / part_rowptr fill of empty rows) over keys read from global memory.
+struct WalkOrder { const int32_t* keys; int e; int n; int64_t* rowptr; int32_t* part_off; int64_t* part_rowptr; int64_t* last_part; };
+struct WalkOrders { WalkOrder o[4]; };
+__global__ __launch_bounds__(kSmallThreads) void order_walk_kernel(WalkOrders ws, int chunk_edges) {
+  __shared__ int wave_tot[kSmallThreads / 64];
+  const WalkOrder o = ws.o[blockIdx.x];
+  if (o.keys == nullptr) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int kWaves = kSmallThreads / 64;
+  const int e = o.e, n = o.n;
+  const int seg = ((e + kWaves - 1) / kWaves + 63) & ~63;
+  const int w0 = wv * seg < e ? wv * seg : e;
+  const int w1 = (wv + 1) * seg < e ? (wv + 1) * seg : e;
+  int cnt = 0;
+  for (int r0 = w0; r0 < w1; r0 += 64) {
+    const int i = r0 + lane;
+    bool start = false;
+    if (i < w1) {
+      const int key = o.keys[i];
+      const int prev = i == 0 ? -1 : o.keys[i - 1];
+      start = (i % chunk_edges == 0) || key != prev;
+    }
+    cnt += __popcll(__ballot(start));
+  }
+  if (lane == 0) wave_tot[wv] = cnt;
+  __syncthreads();
+  int running = 0, total = 0;
+  for (int w = 0; w < kWaves; ++w) {
+    const int v = wave_tot[w];
+    if (w < wv) running += v;
+    total += v;
+  }
+  for (int r0 = w0; r0 < w1; r0 += 64) {
+    const int i = r0 + lane;
+    bool start = false;
+    int key = 0, prev = 0;
+    if (i < w1) {
+      key = o.keys[i];
+      prev = i == 0 ? -1 : o.keys[i - 1];
+      start = (i % chunk_edges == 0) || key != prev;
+    }
+    const unsigned long long m = __ballot(start);
+    if (i < w1) {
+      const int id = running + __popcll(m & (~0ull >> (63 - lane))) - 1;
+      if (o.part_off != nullptr && i % chunk_edges == 0) o.part_off[i / chunk_edges] = id;
+      for (int r = prev + 1; r <= key; ++r) {       // rows whose first edge is here (empty rows in between included)
+        o.rowptr[r] = i;
+        if (o.part_rowptr != nullptr) o.part_rowptr[r] = id;
+      }
+    }
+    running += __popcll(m);
+  }
+  const int last_key = e > 0 ? o.keys[e - 1] : -1;
+  for (int r = last_key + 1 + tid; r <= n; r += kSmallThreads) {
+    o.rowptr[r] = e;
+    if (o.part_rowptr != nullptr) o.part_rowptr[r] = total;
+  }
+  if (tid == 0 && o.last_part != nullptr) o.last_part[0] = total - 1;
+}
+
 struct I64x64 { int64_t v[64]; };
 __global__ void set_i64_kernel(int64_t* __restrict__ dst, I64x64 vals, int n) {
   if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
@@ -508,7 +602,8 @@ extern "C" int pangnn_collate_subgraphs_padded(const int64_t* edge_index, int64_
                                                int64_t max_edges, int64_t max_nb, int64_t max_nodes,
                                                int64_t* out_edge_index, int64_t* out_nb_index, float* out_edge_attr,
                                                float* out_y, int64_t* out_ptr, int64_t* out_batch, float* out_x,
-                                               int64_t* out_live, pangnn_stream_t stream) {
+                                               int64_t* out_live, const pangnn_batch_orders* orders,
+                                               pangnn_stream_t stream) {
   const char* who = "pangnn_collate_subgraphs_padded";
   PG_CHECK_ARG(max_graphs >= 1 && max_graphs <= kMaxPadGraphs, PANGNN_E_BADARG, "%s: max_graphs must be in [1, %d]", who,
                kMaxPadGraphs);
@@ -517,12 +612,37 @@ extern "C" int pangnn_collate_subgraphs_padded(const int64_t* edge_index, int64_
   PG_CHECK_ARG(edge_index && nb_index && edge_attr && y && node_off && edge_off && nb_off && graph_ids && out_edge_index &&
                    out_nb_index && out_edge_attr && out_y && out_ptr && out_batch && out_x && out_live,
                PANGNN_E_BADARG, "%s: null pointer", who);
+  BatchOrders bo{};
+  if (orders != nullptr) {
+    PG_CHECK_ARG(pangnn_structure_small_supported(max_edges, max_nodes) && pangnn_structure_small_supported(max_nb, max_nodes),
+                 PANGNN_E_TOOLARGE, "%s: orders need max_edges, max_nb <= %d and max_nodes <= %d", who, kSmallMaxEdges,
+                 kSmallMaxNodes);
+    PG_CHECK_ARG(orders->chunk_edges >= 32 && orders->chunk_edges % 32 == 0, PANGNN_E_BADARG,
+                 "%s: orders->chunk_edges must be a positive multiple of 32", who);
+    const pangnn_batch_order* src[4] = {&orders->sim_dst, &orders->sim_src, &orders->nb_dst, &orders->nb_src};
+    BatchOrder* dst[4] = {&bo.sim_dst, &bo.sim_src, &bo.nb_dst, &bo.nb_src};
+    for (int k = 0; k < 4; ++k) {
+      PG_CHECK_ARG(src[k]->rank && src[k]->rowptr && src[k]->other && src[k]->perm && src[k]->keys, PANGNN_E_BADARG,
+                   "%s: orders: null pointer in order %d", who, k);
+      *dst[k] = BatchOrder{src[k]->rank, src[k]->other, src[k]->perm, src[k]->keys};
+    }
+    bo.enabled = 1;
+  }
   const int64_t total = 2 * max_edges + 2 * max_nb + (max_graphs + 1) + max_nodes;
   hipLaunchKernelGGL(collate_padded_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, edge_index, ld_e,
                      nb_index, ld_b, edge_attr, y, node_off, edge_off, nb_off, graph_ids, (int)max_graphs, num_graphs_total,
                      max_edges, max_nb, max_nodes, out_edge_index, out_nb_index, out_edge_attr, out_y, out_ptr, out_batch,
-                     out_x, out_live);
+                     out_x, out_live, bo);
   PG_CHECK_LAUNCH(who);
+  if (orders != nullptr) {
+    WalkOrders w{};
+    const pangnn_batch_order* src[4] = {&orders->sim_dst, &orders->sim_src, &orders->nb_dst, &orders->nb_src};
+    for (int k = 0; k < 4; ++k)
+      w.o[k] = WalkOrder{src[k]->keys, (int)(k < 2 ? max_edges : max_nb), (int)max_nodes, src[k]->rowptr, src[k]->part_off,
+                         src[k]->part_rowptr, src[k]->last_part};
+    hipLaunchKernelGGL(order_walk_kernel, dim3(4), dim3(kSmallThreads), 0, (hipStream_t)stream, w, (int)orders->chunk_edges);
+    PG_CHECK_LAUNCH(who);
+  }
   return 0;
 }
 

@@ -317,6 +317,11 @@ _CACHE: Dict[Tuple, EdgeStructure] = {}
 _CACHE_MAX = 16
 
 
+def structure_key(edge_index: torch.Tensor, num_nodes: int):
+    """identity of (edge_index tensor, node count): what the structure caches are keyed on"""
+    return (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), edge_index.device.index)
+
+
 def structure_of(edge_index: torch.Tensor, num_nodes: int, holder=None, name: str = "") -> EdgeStructure:
     """EdgeStructure for `edge_index`.  If `holder` (a Data/Batch object) is given the structure is
     kept on it (`holder._pangnn_structs[name]`), otherwise in a small identity-keyed cache."""

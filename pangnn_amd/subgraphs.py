@@ -271,8 +271,38 @@ class SubGraphDataset:
         return len(ids) <= spec[0] and sum(h.node[i + 1] - h.node[i] for i in ids) < spec[1] \
             and sum(h.edge[i + 1] - h.edge[i] for i in ids) <= spec[2] and sum(h.nb[i + 1] - h.nb[i] for i in ids) <= spec[3]
 
-    def padded_buffers(self, spec):
-        """the fixed buffers of a padded batch + the device list of sub-graph ids it is collated from"""
+    def structure_index(self):
+        """per flat edge of both lists: its position inside its own sub-graph in the by-target and in the by-source order
+        (int32; stable — equal keys keep list order).  A property of the data set, computed once with two stable sorts per
+        list; with it a batch's CSR orders are written without any sort (pangnn_collate_subgraphs_padded, `orders`)."""
+        idx = self.__dict__.get("_structure_index")
+        if idx is None:
+            dev = self.edge_index.device
+            n_total = int(self._host().node[-1])
+
+            def ranks(ei, off):
+                cnt = off[1:] - off[:-1]
+                gid = torch.repeat_interleave(torch.arange(self.num_graphs, device=dev), cnt)
+                first = off[:-1][gid]
+                pos = torch.arange(ei.shape[1], device=dev)
+                out = []
+                for row in (1, 0):            # by target, by source: node ids are data-set wide, so the id alone orders
+                    order = torch.argsort(ei[row], stable=True)      # sub-graph after sub-graph, row after row
+                    r = torch.empty_like(pos)
+                    r[order] = pos
+                    out.append((r - first).to(torch.int32).contiguous())
+                return out
+            assert n_total < 2 ** 31
+            sd, ss = ranks(self.edge_index, self.edge_off)
+            nd, ns = ranks(self.neighbour_edge_index, self.nb_off)
+            idx = self._structure_index = SimpleNamespace(sim_dst=sd, sim_src=ss, nb_dst=nd, nb_src=ns)
+        return idx
+
+    def padded_buffers(self, spec, orders: bool = True):
+        """the fixed buffers of a padded batch + the device list of sub-graph ids it is collated from.  `orders`: also the
+        buffers of both CSR orders (and the decoder's run-sum plans) of both edge lists, written by the collation itself —
+        no per-batch sort (`structure_index`); False, or shapes beyond the small-structure limits: built per batch by
+        graph.EdgeStructure as for any other batch."""
         g, n, e, b = spec
         dev = self.edge_index.device
         i64 = torch.empty(2 * e + 2 * b + (g + 1) + n + 8 + g + 16, dtype=torch.int64, device=dev)
@@ -291,12 +321,85 @@ class SubGraphDataset:
         w, y, x = take(f32, e), take(f32, e), take(f32, n).view(n, 1)
         hints = {"sim": {"valid_ids": True, "sorted_by_src": self._host().sorted_by_src, "band_width": 0},
                  "nb": {"valid_ids": True, "band_width": 0}}
-        return SimpleNamespace(_pangnn_hints=hints, x=x, edge_index=ei, edge_attr=w, y=y, neighbour_edge_index=nb, ptr=ptr,
-                               batch=bid, live=live, live_edges=live[:1], graph_ids=ids, spec=tuple(spec), num_graphs=g)
+        buf = SimpleNamespace(_pangnn_hints=hints, x=x, edge_index=ei, edge_attr=w, y=y, neighbour_edge_index=nb, ptr=ptr,
+                              batch=bid, live=live, live_edges=live[:1], graph_ids=ids, spec=tuple(spec), num_graphs=g,
+                              orders=None)
+        from . import _lib
+        lib = _lib.load()
+        if orders and dev.type == "cuda" and lib.pangnn_structure_small_supported(e, n) \
+                and lib.pangnn_structure_small_supported(b, n):
+            buf.orders = self._order_buffers(lib, n, e, b, dev)
+        return buf
+
+    def _order_buffers(self, lib, n, e, b, dev):
+        """device tables of the four CSR orders of a padded batch + the ctypes descriptor the collation takes"""
+        import ctypes
+
+        class Order(ctypes.Structure):
+            _fields_ = [(k, ctypes.c_void_p) for k in ("rank", "rowptr", "other", "perm", "keys", "part_off", "part_rowptr",
+                                                       "last_part")]
+
+        class Orders(ctypes.Structure):
+            _fields_ = [("chunk_edges", ctypes.c_int32), ("sim_dst", Order), ("sim_src", Order), ("nb_dst", Order),
+                        ("nb_src", Order)]
+        ct = int(lib.pangnn_decoder_chunk_tiles_for(e))
+        span = 32 * ct
+        nc = (e + span - 1) // span
+        rk = self.structure_index()
+        al = lambda k, m: -(-k // m) * m                                        # noqa: E731
+        ea, ba, na, ca = al(e, 4), al(b, 4), al(n + 1, 2), al(nc, 4)
+        i32 = torch.empty(6 * ea + 6 * ba + 2 * ca, dtype=torch.int32, device=dev)
+        i64 = torch.empty(6 * na + 4, dtype=torch.int64, device=dev)
+        seg = {}
+        o32 = o64 = 0
+        for name, m, ma in (("sim_dst", e, ea), ("sim_src", e, ea), ("nb_dst", b, ba), ("nb_src", b, ba)):
+            t = {}
+            for f in ("other", "perm", "keys"):
+                t[f] = i32[o32:o32 + m]
+                o32 += ma
+            t["rowptr"] = i64[o64:o64 + n + 1]
+            o64 += na
+            if name.startswith("sim"):
+                t["part_off"] = i32[o32:o32 + nc]
+                o32 += ca
+                t["part_rowptr"] = i64[o64:o64 + n + 1]
+                o64 += na
+                t["last_part"] = i64[6 * na + (0 if name == "sim_dst" else 2):][:1]
+            seg[name] = t
+        desc = Orders()
+        desc.chunk_edges = span
+        for name in ("sim_dst", "sim_src", "nb_dst", "nb_src"):
+            o = getattr(desc, name)
+            o.rank = getattr(rk, name).data_ptr()
+            for f in ("rowptr", "other", "perm", "keys", "part_off", "part_rowptr", "last_part"):
+                setattr(o, f, seg[name][f].data_ptr() if f in seg[name] else None)
+        return SimpleNamespace(desc=desc, tables=seg, chunk_tiles=ct, n_chunks=nc, _keep=(i32, i64, rk))
+
+    def _structures_of(self, buf):
+        """graph.EdgeStructure objects of the batch's two edge lists over the order tables the collation wrote"""
+        from .graph import CSR, EdgeStructure
+        g, n, e, b = buf.spec
+        out = {}
+        for name, ei, m in (("sim", buf.edge_index, e), ("nb", buf.neighbour_edge_index, b)):
+            td, ts = buf.orders.tables[name + "_dst"], buf.orders.tables[name + "_src"]
+            st = EdgeStructure(ei, n, hints=buf._pangnn_hints[name])
+            st._by_dst, st._by_src = CSR(td["rowptr"], td["other"], td["perm"]), CSR(ts["rowptr"], ts["other"], ts["perm"])
+            st._small_built = True
+            if name == "sim":
+                ct, nc = buf.orders.chunk_tiles, buf.orders.n_chunks
+                plans = st.__dict__.setdefault("_csr_plans", {})
+                for by, t in (("dst", td), ("src", ts)):
+                    plan = SimpleNamespace(n_parts=nc + min(n, m), part_off=t["part_off"], part_rowptr=t["part_rowptr"],
+                                           keys=t["keys"], chunk_tiles=ct, _last=t["last_part"])
+                    plan.n_parts_exact = (lambda pl: (lambda: int(pl._last) + 1))(plan)
+                    plans[(by, ct)] = plan
+            out[name] = st
+        return out
 
     def collate_padded(self, buf):
         """(re)fill the padded batch `buf` from the sub-graph ids in buf.graph_ids (device): ONE launch, no host read-back;
         capturable — a replay collates whatever ids the list holds at that moment"""
+        import ctypes
         from . import _lib
         lib = _lib.load()
         g, n, e, b = buf.spec
@@ -313,8 +416,21 @@ class SubGraphDataset:
                 self.y.data_ptr(), self.node_off.data_ptr(), self.edge_off.data_ptr(), self.nb_off.data_ptr(),
                 self.num_graphs, buf.graph_ids.data_ptr(), g, e, b, n, buf.edge_index.data_ptr(),
                 buf.neighbour_edge_index.data_ptr(), buf.edge_attr.data_ptr(), buf.y.data_ptr(), buf.ptr.data_ptr(),
-                buf.batch.data_ptr(), buf.x.data_ptr(), buf.live.data_ptr(), _lib.stream_ptr()),
+                buf.batch.data_ptr(), buf.x.data_ptr(), buf.live.data_ptr(),
+                None if buf.orders is None else ctypes.byref(buf.orders.desc), _lib.stream_ptr()),
                 "pangnn_collate_subgraphs_padded")
+        # what is cached on the batch object belongs to the previous content of the buffers (same addresses): replace it
+        # by the structures over the tables this collation wrote, or drop it (built on first use as for any batch)
+        from .graph import clear_cache, structure_key
+        clear_cache()
+        if buf.orders is None:
+            buf.__dict__.pop("_pangnn_structs", None)
+        else:
+            from .graph import register
+            sts = self._structures_of(buf)
+            buf._pangnn_structs = {name: (structure_key(st.edge_index, st.num_nodes), st) for name, st in sts.items()}
+            for st in sts.values():
+                register(st)
         return buf
 
     def set_graph_ids(self, buf, ids):

@@ -202,10 +202,7 @@ class ReplayedFreshStep:
 
     def _step(self, buf):
         """one padded fresh step: everything a new batch needs, no host read-back"""
-        from .graph import clear_cache
-        self.ds.collate_padded(buf)
-        buf.__dict__.pop("_pangnn_structs", None)        # the buffers keep their addresses: nothing cached may survive
-        clear_cache()
+        self.ds.collate_padded(buf)       # (also replaces / drops the structures cached on the buffers' addresses)
         self.optimizer.zero_grad(set_to_none=True)
         loss, out = self.model.loss_and_logits(buf, buf.y, self.pos_weight)
         loss.backward(PF.unit_grad(loss.device))

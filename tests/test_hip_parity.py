@@ -843,6 +843,7 @@ def _padded_reference_batch(ds, ids):
 def test_padded_collation_is_the_disjoint_union_plus_an_inert_tail():
     """pangnn_collate_subgraphs_padded on a SHUFFLED id list: the real part equals the index-op union entry for entry,
     the tail is self loops of the last (never real) node with weight 1 / label 0, live counts are the real counts"""
+    from pangnn_amd import functional as PF
     from pangnn_amd import simulate
     ds = simulate.simulate_subgraph_dataset(300, 4, 0.3, 10, 2, seed=5, device=dev())
     spec = ds.padded_spec(32)
@@ -869,6 +870,20 @@ def test_padded_collation_is_the_disjoint_union_plus_an_inert_tail():
         bid = buf.batch[:n]
         assert torch.equal(bid, torch.searchsorted(buf.ptr[1:count + 1].contiguous(), torch.arange(n, device=dev()), right=True))
         assert bool((buf.batch[n:] == count).all())
+        # both CSR orders and the decoder's run-sum plans, written by the collation WITHOUT a sort (per-sub-graph ranks of the
+        # data set), are the tables the one-launch sort-based build makes of the same collated lists, entry for entry
+        assert buf.orders is not None
+        from pangnn_amd.graph import EdgeStructure
+        for name, ei in (("sim", buf.edge_index), ("nb", buf.neighbour_edge_index)):
+            st = buf._pangnn_structs[name][1]
+            ref = EdgeStructure(ei.clone(), spec[1], hints=buf._pangnn_hints[name])
+            for a, b_ in ((st.by_dst, ref.by_dst), (st.by_src, ref.by_src)):
+                assert torch.equal(a.rowptr, b_.rowptr) and torch.equal(a.other, b_.other) and torch.equal(a.perm, b_.perm)
+            if name == "sim":
+                ct = PF.d16_chunk(st.num_edges)
+                for pa, pb in ((st.csr_plan("dst", ct), ref.csr_plan("dst", ct)), (st.runsum_plan(ct), ref.runsum_plan(ct))):
+                    assert torch.equal(pa.part_off, pb.part_off) and torch.equal(pa.part_rowptr, pb.part_rowptr)
+                    assert torch.equal(pa.keys, pb.keys) and pa.n_parts_exact() == pb.n_parts_exact()
     with pytest.raises(ValueError):
         ds.set_graph_ids(ds.padded_buffers((32, 10, 10, 10)), list(range(32)))          # does not fit: refused on the host
 

@@ -3,7 +3,7 @@
 set -o pipefail
 O=gpurun_out/r04d; mkdir -p $O
 run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit $rc; fi; return $rc; }
-run 600 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "padded or replayed_fresh" > $O/tests_fresh.log 2>&1; rc=$?; echo "fresh tests rc=$rc"; tail -n 25 $O/tests_fresh.log
+run 600 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "padded or replayed_fresh or hip_graph_replay or minibatch or subgraph" > $O/tests_fresh.log 2>&1; rc=$?; echo "fresh tests rc=$rc"; tail -n 25 $O/tests_fresh.log
 [ $rc -eq 0 ] || exit 1
 run 300 python bench.py --workload cfg2mb_fresh --steps 400 > $O/bench_cfg2mb_fresh.json 2> $O/bench_cfg2mb_fresh.err; echo "fresh bench rc=$?"; cut -c1-330 $O/bench_cfg2mb_fresh.json
 ROOT=$PWD
