@@ -125,15 +125,19 @@ class _Propagate(torch.autograd.Function):
 # are registered dispatcher ops `torch.ops.pangnn.*` (torch_ops.py: fake kernels, autograd formulas built from registered
 # ops) — what FakeTensor tracing / torch.compile / any TorchDispatchMode need to see them.  Same kernels and the same host
 # code as the ctypes autograd.Functions in this file, bit-identical results.  USE_DISPATCHER_OPS (PANGNN_DISPATCHER_OPS):
-#   "auto" (default)  through the ops whenever somebody can observe them — torch.compile is tracing, or a dispatch /
+#   True / "1" (default since round 4)  every per-step operator of a whole (square) graph goes through its registered op —
+#                     eager, traced or captured alike: ONE route.  The registered-op wrapper (torch.library's autograd
+#                     plumbing) costs ~25 us of host time per call: nothing on a whole-graph step (12.83 vs 12.88 ms), nothing
+#                     when a mini-batch step is replayed from a captured HIP graph (train.GraphedTrainStep /
+#                     ReplayedFreshStep, the product's mini-batch paths), +0.16 ms on an eagerly launched 0.47 ms mini-batch
+#                     step, which is why round 3 defaulted to "auto";
+#   "auto"            through the ops only when somebody can observe them — torch.compile is tracing, or a dispatch /
 #                     function mode is active (FakeTensorMode, make_fx, a TorchDispatchMode) — and straight to the
-#                     autograd.Functions otherwise: the registered-op wrapper (torch.library's autograd plumbing) costs
-#                     ~25 us of host time per call, +0.3 ms on the 0.55 ms launch-bound eager mini-batch step;
-#   True  / "1"       always through the ops (nothing on a whole-graph step: 12.83 vs 12.88 ms);
+#                     autograd.Functions otherwise;
 #   False / "0"       never (the route a partitioned shard always takes: its rectangular structures have no tensor-only
 #                     description).
-_mode = os.environ.get("PANGNN_DISPATCHER_OPS", "auto").lower()
-USE_DISPATCHER_OPS = True if _mode in ("1", "true", "on") else False if _mode in ("0", "false", "off") else "auto"
+_mode = os.environ.get("PANGNN_DISPATCHER_OPS", "1").lower()
+USE_DISPATCHER_OPS = "auto" if _mode == "auto" else False if _mode in ("0", "false", "off") else True
 _dispatch_modes = getattr(torch._C, "_len_torch_dispatch_stack", lambda: 0)
 _function_modes = getattr(torch._C, "_len_torch_function_stack", lambda: 0)
 
@@ -730,10 +734,10 @@ def decoder_loss(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
 def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, live=None):
     """`live` (device int64[1]): a padded fixed-shape batch whose first live[0] edges are real (train.ReplayedFreshStep):
     the loss is their mean and the padding contributes to no gradient"""
-    _lib.require_device(pq, extra, cvec, w2, b2, w3, b3, y, pos_weight)
-    if live is None and _via_ops(st) and DECODER_PRECISION == 1:
+    _lib.require_device(pq, extra, cvec, w2, b2, w3, b3, y, pos_weight, live)
+    if _via_ops(st) and DECODER_PRECISION == 1:
         from . import torch_ops
-        return torch_ops.decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
+        return torch_ops.decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, live)
     return _DecoderLoss.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, True, live)
 
 

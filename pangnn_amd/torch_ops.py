@@ -11,8 +11,8 @@ registers, on the same ops,
     have no fp16 row format); everything else runs in fp32.
 The second half of this module registers the per-step operators of the train step (linear, gcn_propagate, embed_conv_in,
 decoder_loss, decoder_mlp and their backward ops) from Python on the same library; `functional`'s public functions go
-through them by default (`functional.USE_DISPATCHER_OPS`, PANGNN_DISPATCHER_OPS=0 selects the ctypes
-autograd.Functions: same kernels, same results).
+through them by default — eager, traced or captured alike (`functional.USE_DISPATCHER_OPS`; PANGNN_DISPATCHER_OPS=auto: only
+when a tracer / dispatch mode observes the calls, =0: never — the ctypes autograd.Functions: same kernels, same results).
 There is no CPU implementation: the ops raise on CPU tensors.
 """
 from __future__ import annotations
@@ -175,7 +175,7 @@ _lib2.define("embed_conv_in(Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor? b
 _lib2.define("embed_conv_in_backward(Tensor g, Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor edge_index, "
              "Tensor? edge_weight, bool has_bias) -> (Tensor, Tensor, Tensor, Tensor)")
 _lib2.define("decoder_loss(Tensor pq, Tensor edge_index, Tensor? extra, Tensor? cvec, Tensor w2, Tensor b2, Tensor w3, "
-             "Tensor b3, Tensor y, Tensor? pos_weight, int denom) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
+             "Tensor b3, Tensor y, Tensor? pos_weight, int denom, Tensor? live) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
 _lib2.define("decoder_mlp(Tensor pq, Tensor edge_index, Tensor? extra, Tensor? cvec, Tensor w2, Tensor b2, Tensor w3, "
              "Tensor b3) -> Tensor")
 _lib2.define("decoder_mlp_backward(Tensor g, Tensor pq, Tensor edge_index, Tensor? extra, Tensor? cvec, Tensor w2, Tensor b2, "
@@ -487,10 +487,12 @@ torch.library.register_autograd("pangnn::bce_with_logits", _bce_bwd, setup_conte
 
 
 # ---------------------------------------------------------------------------------------------- decoder
-def _decoder_loss_impl(pq, edge_index, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+def _decoder_loss_impl(pq, edge_index, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, live):
+    """`live` (device int64[1], optional): a padded fixed-shape batch whose first live[0] edges are real"""
     st = _struct(edge_index, pq.shape[0])
     ctx = _Ctx()
-    loss, logits = _PF._DecoderLoss.forward(ctx, pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, int(denom), True)
+    loss, logits = _PF._DecoderLoss.forward(ctx, pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, int(denom), True,
+                                            live)
     g_pq, _, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
     return loss, logits, g_pq, g_cv, g_w2, g_b2, g_w3, g_b3
 
@@ -522,7 +524,7 @@ _lib2.impl("decoder_mlp_backward", _decoder_mlp_backward_impl, "CUDA")
 
 
 @torch.library.register_fake("pangnn::decoder_loss")
-def _(pq, edge_index, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+def _(pq, edge_index, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, live):
     f = lambda *s: w2.new_empty(s, dtype=torch.float32)           # noqa: E731
     return (f(), f(edge_index.shape[1]), f(*pq.shape), f(*(cvec.shape if cvec is not None else (0,))), f(*w2.shape),
             f(*b2.shape), f(*w3.shape), f(*b3.shape))
@@ -549,10 +551,10 @@ def _dloss_setup(ctx, inputs, output):
 
 def _dloss_bwd(ctx, go, *_unused):
     if go is None:
-        return (None,) * 11
+        return (None,) * 12
     g_pq, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
     k = (lambda t: t) if (go is not None and _PF.is_unit_grad(go)) else (lambda t: t * go)
-    return (k(g_pq), None, None, k(g_cv) if ctx.has_cv else None, k(g_w2), k(g_b2), k(g_w3), k(g_b3), None, None, None)
+    return (k(g_pq), None, None, k(g_cv) if ctx.has_cv else None, k(g_w2), k(g_b2), k(g_w3), k(g_b3), None, None, None, None)
 
 
 torch.library.register_autograd("pangnn::decoder_loss", _dloss_bwd, setup_context=_dloss_setup)
@@ -594,9 +596,9 @@ def embed_propagate(x_tab, w, b, st, norm):
     return ops.embed_propagate(x_tab, w, b, st._key_tensor, getattr(norm, "weight_ref", None))
 
 
-def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
+def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, live=None):
     _G.register(st)
-    out = ops.decoder_loss(pq, st._key_tensor, extra, cvec, w2, b2, w3, b3, y, pos_weight, int(denom))
+    out = ops.decoder_loss(pq, st._key_tensor, extra, cvec, w2, b2, w3, b3, y, pos_weight, int(denom), live)
     return out[0], out[1]
 
 

@@ -76,9 +76,9 @@ def test_step_operators_trace_with_fake_tensors():
         assert a.shape == (n, 64)
         assert [tuple(t.shape) for t in ops.embed_propagate_backward(a, xt, ei, None)] == [(64, 1), (64,)]
         pq, w2, b2, w3, b3, cv = f(n, 128), f(64, 64), f(64), f(64), f(1), f(64)
-        out = ops.decoder_loss(pq, ei, f(e), cv, w2, b2, w3, b3, f(e), f(1), e)
+        out = ops.decoder_loss(pq, ei, f(e), cv, w2, b2, w3, b3, f(e), f(1), e, None)
         assert [tuple(t.shape) for t in out] == [(), (e,), (n, 128), (64,), (64, 64), (64,), (64,), (1,)]
-        assert ops.decoder_loss(pq, ei, None, None, w2, b2, w3, b3, f(e), None, e)[3].numel() == 0
+        assert ops.decoder_loss(pq, ei, None, None, w2, b2, w3, b3, f(e), None, e, None)[3].numel() == 0
         lg = ops.decoder_mlp(pq.to(torch.bfloat16), ei, None, None, w2, b2, w3, b3)
         assert lg.shape == (e,) and lg.dtype == torch.float32
         assert [tuple(t.shape) for t in ops.decoder_mlp_backward(lg, pq, ei, f(e), cv, w2, b2, w3, b3)] == \
@@ -87,31 +87,37 @@ def test_step_operators_trace_with_fake_tensors():
         assert loss.shape == () and g.shape == (e,)
 
 
-def test_dispatcher_route_is_taken_whenever_the_calls_are_observed():
-    """PANGNN_DISPATCHER_OPS=auto (default): torch.ops.pangnn.* under a tracer / dispatch mode, the direct
-    autograd.Functions for unobserved eager calls (the wrapper's ~25 us per call is a third of a mini-batch step)"""
+def test_dispatcher_route_is_the_default_and_auto_follows_observers():
+    """PANGNN_DISPATCHER_OPS: the registered ops are the default route for every call (round 4); `auto` = round 3's
+    default: torch.ops.pangnn.* under a tracer / dispatch mode, the direct autograd.Functions for unobserved eager calls;
+    a partitioned shard's rectangular structure and `0` never take the ops"""
     import os
+    from types import SimpleNamespace
     from pangnn_amd import functional as PF
     from torch._subclasses.fake_tensor import FakeTensorMode
     from torch.utils._python_dispatch import TorchDispatchMode
-    if os.environ.get("PANGNN_DISPATCHER_OPS", "auto") != "auto":
+    if os.environ.get("PANGNN_DISPATCHER_OPS", "1") != "1":
         pytest.skip("route forced by the environment")
-    assert PF.USE_DISPATCHER_OPS == "auto" and not PF.observed() and not PF._via_ops()
-    with FakeTensorMode():
-        assert PF.observed() and PF._via_ops()
-
-    class Spy(TorchDispatchMode):
-        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-            return func(*args, **(kwargs or {}))
-
-    with Spy():
-        assert PF._via_ops()
-    old, PF.USE_DISPATCHER_OPS = PF.USE_DISPATCHER_OPS, True
+    assert PF.USE_DISPATCHER_OPS is True and not PF.observed() and PF._via_ops()
+    assert not PF._via_ops(SimpleNamespace(num_src=7, num_nodes=5))              # rectangular (a shard): direct route
+    old, PF.USE_DISPATCHER_OPS = PF.USE_DISPATCHER_OPS, "auto"
     try:
-        assert PF._via_ops()
+        assert not PF._via_ops()
+        with FakeTensorMode():
+            assert PF.observed() and PF._via_ops()
+
+        class Spy(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                return func(*args, **(kwargs or {}))
+
+        with Spy():
+            assert PF._via_ops()
+        PF.USE_DISPATCHER_OPS = False
+        with Spy():
+            assert not PF._via_ops()
     finally:
         PF.USE_DISPATCHER_OPS = old
-    assert not PF._via_ops()
+    assert PF._via_ops()
 
 
 def test_ops_refuse_cpu_tensors():
@@ -386,7 +392,7 @@ def test_opcheck_of_the_step_operators():
         (ops.embed_conv_in_linear, (r(n, 1), p(64, 1), p(64), p(64, 64), None, p(64, 64), p(64), ei, None)),
         (ops.embed_propagate, (r(n, 1), p(64, 1), p(64), ei, w)),
         (ops.decoder_mlp, (p(n, 128), ei, w, p(64), p(64, 64), p(64), p(64), p(1))),
-        (ops.decoder_loss, (p(n, 128), ei, None, None, p(64, 64), p(64), p(64), p(1), y, None, e)),
+        (ops.decoder_loss, (p(n, 128), ei, None, None, p(64, 64), p(64), p(64), p(1), y, None, e, None)),
         (ops.bce_with_logits, (p(e), y, r(1).abs(), e)),
     ]
     for op, args in cases:
