@@ -50,9 +50,10 @@ WORKLOADS = {
 CFG5 = {"cfg5", "cfg5slice"}
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # what limits the S kernel (profiles/*_pmc_sq_decoder16.txt; updated with the kernel)
-S_BINDS = ("vector-instruction issue (580 vector incl. 84 MFMA + 89 LDS + 55 scalar instructions per 16 edges at two waves "
-           "per SIMD; profiles/r03a_pmc_sq_decoder16.txt, profiles/r03_S_instruction_budget.txt), not the matrix pipe (36 % "
-           "busy) nor HBM")
+S_BINDS = ("vector-instruction issue (553 vector incl. 84 MFMA + 89 LDS + 58 scalar instructions per 16 edges at two waves "
+           "per SIMD: 1.39 x the sum of their issue costs; profiles/r04e_pmc_sq_decoder16.txt, "
+           "profiles/r04_decoder_instruction_budget.txt), not the matrix pipe (43 % busy) nor HBM (fabric traffic = 0.48 x the "
+           "algorithmic bytes)")
 
 
 def spmm_alg_bytes(e, n, f, s=4):
@@ -76,6 +77,7 @@ def step_alg_bytes(n, e, e_nb, d, h, parts_s, parts_t, s_rows=4):
         "conv_out_propagate": spmm_alg_bytes(e_nb, n, d, s_rows),
         "decoder_pq_linear": lin(d, 2 * d),
         "decoder_S": e * 556 + parts_s * 4 * d,                              # ids 16 + P 256 + Q 256 + y 4 + logit 4 + record 20
+        #                                         (the 32-byte record slot also holds 12 bytes of replicated dL/dlogit: not counted)
         "decoder_S_part_sum": parts_s * 4 * d + n * 4 * d + (n + 1) * 8,
         "decoder_T": e * 28 + parts_t * 4 * d,                               # perm 4 + key 4 + record 20
         "decoder_T_part_sum": parts_t * 4 * d + n * 4 * d + (n + 1) * 8,
