@@ -149,8 +149,10 @@ class GCNConv(MessagePassing):
         if self.in_channels < self.out_channels:
             # A_hat (x W^T) == (A_hat x) W^T: propagate on the narrower side (half the gather bytes for
             # 64 -> 128), then the dense layer with the bias fused
+            # ... and their sum is what the autocast Linear casts to bfloat16 first thing: cast once, stored (out_bf16), so
+            # that the Linear reads 2-byte rows and the transposed propagate gathers its bfloat16 gradient as stored
             agg = PF.propagate_any(x.to(torch.bfloat16) if rows_bf16 else x, None, st, norm, edge_weight is None,
-                                   tag=name or None)
+                                   tag=name or None, out_bf16=rows_bf16)
             # the autocast Linear's output is a bf16 tensor (src/gnn.py:111 under mixed precision): stored as such
             return PF.linear(agg, self.lin.weight, self.bias, 0, torch.bfloat16 if rows_bf16 else None)
         # dense part first: under bf16 autocast its result is WRITTEN as bfloat16 by the linear kernel (no separate cast)

@@ -102,23 +102,29 @@ class _Propagate(torch.autograd.Function):
     leaf without grad in the reference: SURVEY.md §8 a6)."""
 
     @staticmethod
-    def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
+    def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm, tag=None, out_bf16=False):
+        """`out_bf16` (bf16 autocast, a propagate-first GCNConv): the result is what an autocast Linear consumes, i.e. it is
+        cast to bfloat16 first thing — done here once and stored, so the Linear reads 2-byte rows, its dL/dx comes back as
+        bfloat16 (autograd's dtype rule; in the reference the backward of that cast hands fp32 copies of bf16 values on) and
+        the transposed propagate gathers it as stored: the same values as the reference's, half the gather bytes."""
         ctx.st, ctx.norm, ctx.tag = st, norm, tag
         ctx.has_bias = bias is not None
         ctx.x_dtype = x.dtype            # bfloat16 rows are gathered as stored (half the bytes); result fp32
-        return spmm_csr(st.by_dst, norm.by_dst, x, st.num_nodes, bias=None if bias is None else _f32c(bias),
-                        tag=None if tag is None else tag + ".fwd")
+        out = spmm_csr(st.by_dst, norm.by_dst, x, st.num_nodes, bias=None if bias is None else _f32c(bias),
+                       tag=None if tag is None else tag + ".fwd")
+        return out.to(torch.bfloat16) if out_bf16 else out
 
     @staticmethod
     def backward(ctx, g):
         st, norm = ctx.st, ctx.norm
-        g = _f32c(g)
+        if not (g.dtype == torch.bfloat16 and g.shape[1] in (32, 64, 128, 256)):     # bf16 rows: gathered as stored
+            g = _f32c(g)
         gx = spmm_csr(st.by_src, norm.by_src, g, st.num_src,
                       tag=None if ctx.tag is None else ctx.tag + ".bwd") if ctx.needs_input_grad[0] else None
-        gb = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        gb = g.sum(dim=0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         if gx is not None and gx.dtype != ctx.x_dtype:
             gx = gx.to(ctx.x_dtype)
-        return gx, gb, None, None, None
+        return gx, gb, None, None, None, None
 
 
 # The per-step operators (dense layer, GCN propagate, first layer by linearity, training / inference decoder, criterion)
@@ -155,12 +161,12 @@ def _via_ops(st: Optional[EdgeStructure] = None, tag=None) -> bool:
     return bool(use) and (st is None or st.num_src == st.num_nodes) and (KERNEL_TIMER is None or tag is None)
 
 
-def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None):
+def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None, out_bf16=False):
     if _via_ops(st, tag) and getattr(norm, "weight_ref", norm) is not norm:
         from . import torch_ops
         _lib.require_device(x, bias)
-        return torch_ops.gcn_propagate(x, bias, st, norm)
-    return _Propagate.apply(x, bias, st, norm, tag)
+        return torch_ops.gcn_propagate(x, bias, st, norm, False, out_bf16)
+    return _Propagate.apply(x, bias, st, norm, tag, bool(out_bf16))
 
 
 class _BandPropagate(torch.autograd.Function):
@@ -213,16 +219,17 @@ def _band_ok(x, st: EdgeStructure, unit_weights: bool) -> bool:
         and st.band_width() > 0
 
 
-def propagate_any(x, bias, st: EdgeStructure, norm: GcnNorm, unit_weights: bool, tag=None):
+def propagate_any(x, bias, st: EdgeStructure, norm: GcnNorm, unit_weights: bool, tag=None, out_bf16=False):
     """GCNConv's message passing: the band kernel when the structure is the positional-neighbour band with unit weights
-    (whole-graph mode of the reference), the general CSR kernels otherwise"""
+    (whole-graph mode of the reference), the general CSR kernels otherwise.  `out_bf16`: see _Propagate.forward."""
     if _via_ops(st, tag) and getattr(norm, "weight_ref", norm) is not norm:
         from . import torch_ops
         _lib.require_device(x, bias)
-        return torch_ops.gcn_propagate(x, bias, st, norm, unit_weights)         # the op makes the same band / CSR choice
+        return torch_ops.gcn_propagate(x, bias, st, norm, unit_weights, out_bf16)   # the op makes the same band / CSR choice
     if _band_ok(x, st, unit_weights) and (KERNEL_TIMER is None or tag is None or (tag + ".fwd") not in KERNEL_TIMER):
-        return band_propagate(x, bias, st, norm)
-    return propagate(x, bias, st, norm, tag)
+        y = band_propagate(x, bias, st, norm)
+        return y.to(torch.bfloat16) if out_bf16 else y
+    return propagate(x, bias, st, norm, tag, out_bf16)
 
 
 class _EdgeGatherConcat(torch.autograd.Function):

@@ -168,7 +168,7 @@ from . import graph as _G                # noqa: E402
 _lib2 = torch.library.Library("pangnn", "FRAGMENT")
 _lib2.define("linear(Tensor x, Tensor w, Tensor? bias, int in_act, bool out_bf16) -> Tensor")
 _lib2.define("linear_backward(Tensor g, Tensor x, Tensor w, int in_act, bool has_bias, bool need_dx) -> (Tensor, Tensor, Tensor)")
-_lib2.define("gcn_propagate(Tensor x, Tensor? bias, Tensor edge_index, Tensor? edge_weight, bool allow_band) -> Tensor")
+_lib2.define("gcn_propagate(Tensor x, Tensor? bias, Tensor edge_index, Tensor? edge_weight, bool allow_band, bool out_bf16) -> Tensor")
 _lib2.define("gcn_propagate_backward(Tensor g, Tensor edge_index, Tensor? edge_weight, bool allow_band, bool has_bias, bool x_bf16) -> (Tensor, Tensor)")
 _lib2.define("embed_conv_in(Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor? b_in, Tensor edge_index, Tensor? edge_weight, "
              "bool out_bf16) -> Tensor")
@@ -260,18 +260,19 @@ torch.library.register_autograd("pangnn::linear", _linear_bwd, setup_context=_li
 
 
 # ---------------------------------------------------------------------------------------------- GCN propagate
-def _gcn_propagate_impl(x, bias, edge_index, edge_weight, allow_band):
+def _gcn_propagate_impl(x, bias, edge_index, edge_weight, allow_band, out_bf16):
     st = _struct(edge_index, x.shape[0])
     norm = st.gcn_norm(edge_weight)
     if allow_band and _PF._band_ok(x, st, edge_weight is None):
-        return _PF._BandPropagate.forward(_Ctx(), x, bias, norm.deg_inv_sqrt, st.band_width())
-    return _PF._Propagate.forward(_Ctx(), x, bias, st, norm, None)
+        y = _PF._BandPropagate.forward(_Ctx(), x, bias, norm.deg_inv_sqrt, st.band_width())
+        return y.to(torch.bfloat16) if out_bf16 else y
+    return _PF._Propagate.forward(_Ctx(), x, bias, st, norm, None, bool(out_bf16))
 
 
 def _gcn_propagate_backward_impl(g, edge_index, edge_weight, allow_band, has_bias, x_bf16):
     st = _struct(edge_index, g.shape[0])
     norm = st.gcn_norm(edge_weight)
-    ctx = _Ctx((True, has_bias, False, False, False))
+    ctx = _Ctx((True, has_bias, False, False, False, False))
     ctx.has_bias, ctx.x_dtype = bool(has_bias), torch.bfloat16 if x_bf16 else torch.float32
     if allow_band and _PF._band_ok(g, st, edge_weight is None):
         ctx.k = st.band_width()
@@ -288,8 +289,8 @@ _lib2.impl("gcn_propagate_backward", _gcn_propagate_backward_impl, "CUDA")
 
 
 @torch.library.register_fake("pangnn::gcn_propagate")
-def _(x, bias, edge_index, edge_weight, allow_band):
-    return x.new_empty(x.shape, dtype=torch.float32)
+def _(x, bias, edge_index, edge_weight, allow_band, out_bf16):
+    return x.new_empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32)
 
 
 @torch.library.register_fake("pangnn::gcn_propagate_backward")
@@ -299,7 +300,7 @@ def _(g, edge_index, edge_weight, allow_band, has_bias, x_bf16):
 
 
 def _gcn_setup(ctx, inputs, output):
-    x, bias, edge_index, edge_weight, allow_band = inputs
+    x, bias, edge_index, edge_weight, allow_band, _out_bf16 = inputs
     ctx.save_for_backward(edge_index, edge_weight)
     ctx.allow_band = allow_band
     ctx.has_bias, ctx.x_bf16 = bias is not None, x.dtype == torch.bfloat16
@@ -308,7 +309,7 @@ def _gcn_setup(ctx, inputs, output):
 def _gcn_bwd(ctx, g):
     edge_index, edge_weight = ctx.saved_tensors
     gx, gb = ops.gcn_propagate_backward(g, edge_index, edge_weight, ctx.allow_band, ctx.has_bias, ctx.x_bf16)
-    return (gx if ctx.needs_input_grad[0] else None, gb if ctx.has_bias else None, None, None, None)
+    return (gx if ctx.needs_input_grad[0] else None, gb if ctx.has_bias else None, None, None, None, None)
 
 
 torch.library.register_autograd("pangnn::gcn_propagate", _gcn_bwd, setup_context=_gcn_setup)
@@ -575,9 +576,9 @@ torch.library.register_autograd("pangnn::decoder_mlp", _dmlp_bwd, setup_context=
 
 
 # ---------------------------------------------------------------------------------------------- wrappers taking structures
-def gcn_propagate(x, bias, st, norm, allow_band=False):
+def gcn_propagate(x, bias, st, norm, allow_band=False, out_bf16=False):
     _G.register(st)
-    return ops.gcn_propagate(x, bias, st._key_tensor, getattr(norm, "weight_ref", None), bool(allow_band))
+    return ops.gcn_propagate(x, bias, st._key_tensor, getattr(norm, "weight_ref", None), bool(allow_band), bool(out_bf16))
 
 
 def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):

@@ -827,6 +827,35 @@ def test_hip_graph_replay_equals_eager_steps():
         assert torch.equal(a, b)
 
 
+def test_propagate_with_bf16_output_rounds_once_and_its_backward_gathers_bf16_rows():
+    """config 5's propagate-first GCNConv under bf16 autocast: the propagate's result is what an autocast Linear consumes,
+    i.e. bfloat16 — `out_bf16` stores it that way (one rounding of the fp32 sums) and the transposed propagate gathers the
+    bfloat16 gradient rows as stored: the same sums as gathering their fp32 copies (what the reference's cast backward hands
+    on), half the bytes"""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    n, e = 3000, 90000
+    ei, w = random_graph(n, e, seed=21, hub=700)
+    st = EdgeStructure(ei.to(dev()), n)
+    norm = st.gcn_norm(w.to(dev()))
+    torch.manual_seed(4)
+    x0 = torch.randn(n, 64, device=dev()).bfloat16()
+    g0 = torch.randn(n, 64, device=dev()).bfloat16()
+    res = {}
+    for out_bf16 in (False, True):
+        x = x0.clone().requires_grad_(True)
+        y = PF.propagate_any(x, None, st, norm, False, out_bf16=out_bf16)
+        y.backward(g0 if out_bf16 else g0.float())
+        res[out_bf16] = (y.detach(), x.grad)
+    assert res[True][0].dtype == torch.bfloat16 and res[False][0].dtype == torch.float32
+    assert torch.equal(res[True][0], res[False][0].to(torch.bfloat16))                  # one rounding of the same sums
+    assert res[True][1].dtype == res[False][1].dtype == torch.bfloat16
+    # gathering bf16 rows == gathering their exact fp32 copies: the same products; the two kernels may associate differently
+    assert close(res[True][1].float(), res[False][1].float(), atol=1e-2, rtol=1e-2)
+    ref = go.propagate_add(g0.float().cpu(), ei.flip(0), go.gcn_norm(ei, w, n))        # transposed: swap the endpoints
+    assert close(res[True][1].float(), ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2)
+
+
 def _padded_reference_batch(ds, ids):
     """the disjoint union of the sub-graphs `ids` built with torch index ops on the host (what Batch.from_data_list does)"""
     h = ds._host()

@@ -59,7 +59,7 @@ def test_step_operators_trace_with_fake_tensors():
         gx, gw, gb = ops.linear_backward(y, x, w, 1, True, True)
         assert gx.shape == x.shape and gw.shape == w.shape and gb.shape == b.shape
         assert ops.linear_backward(y, x, w, 0, False, False)[0].numel() == 0
-        z = ops.gcn_propagate(x.to(torch.bfloat16), b[:64], ei, f(e), True)
+        z = ops.gcn_propagate(x.to(torch.bfloat16), b[:64], ei, f(e), True, False)
         assert z.shape == (n, 64) and z.dtype == torch.float32
         gz, gbias = ops.gcn_propagate_backward(z, ei, None, True, True, True)
         assert gz.dtype == torch.bfloat16 and gbias.shape == (64,)
@@ -128,7 +128,7 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops.pangnn.linear(torch.randn(4, 64), torch.randn(64, 64), None, 0, False)
     with pytest.raises((RuntimeError, NotImplementedError)):
-        torch.ops.pangnn.gcn_propagate(torch.randn(3, 64), None, torch.tensor([[0, 1], [1, 2]]), None, True)
+        torch.ops.pangnn.gcn_propagate(torch.randn(3, 64), None, torch.tensor([[0, 1], [1, 2]]), None, True, False)
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops.pangnn.decoder_mlp(torch.randn(3, 128), torch.tensor([[0, 1], [1, 2]]), None, None, torch.randn(64, 64),
                                      torch.randn(64), torch.randn(64), torch.randn(1))
@@ -385,8 +385,8 @@ def test_opcheck_of_the_step_operators():
     cases = [
         (ops.linear, (p(n, 64), p(128, 64), p(128), 1, False)),
         (ops.linear, (r(n, 128).to(torch.bfloat16), p(64, 128), None, 0, True)),
-        (ops.gcn_propagate, (p(n, 64), p(64), ei, w, True)),
-        (ops.gcn_propagate, (p(n, 128), None, ei, None, False)),
+        (ops.gcn_propagate, (p(n, 64), p(64), ei, w, True, False)),
+        (ops.gcn_propagate, (p(n, 128), None, ei, None, False, False)),
         (ops.embed_conv_in, (r(n, 1), p(64, 1), p(64), p(128, 64), p(128), ei, w, False)),
         (ops.embed_conv_in_linear, (r(n, 1), p(64, 1), p(64), p(128, 64), p(128), p(64, 128), None, ei, w)),
         (ops.embed_conv_in_linear, (r(n, 1), p(64, 1), p(64), p(64, 64), None, p(64, 64), p(64), ei, None)),
