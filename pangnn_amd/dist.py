@@ -168,18 +168,19 @@ class HaloPlan:
             owner = torch.searchsorted(b, need, right=True) - 1
         need_counts = torch.bincount(owner, minlength=world)
         all_counts = _all_gather_rows(need_counts.view(1, world), group)       # [world(asker), world(owner)]
-        mx = max(int(all_counts.max()), 1)
+        counts_host = all_counts.tolist()                                      # ONE read-back for every size below
+        mx = max(max(max(row) for row in counts_host), 1)
+        # the ids this rank asks of owner r, left-aligned in row r of a [world, mx] table (need is sorted by id, hence by
+        # owner): position inside the owner's row = index in `need` - first index of that owner — no per-rank loop
+        first = torch.cumsum(need_counts, 0) - need_counts
         padded = torch.full((world, mx), -1, dtype=torch.int64, device=dev)
-        off = 0
-        for r in range(world):
-            c = int(need_counts[r])
-            padded[r, :c] = need[off:off + c]
-            off += c
+        if need.numel():
+            padded[owner, torch.arange(need.numel(), device=dev) - first[owner]] = need
         everyone = _all_gather_rows(padded.view(1, world, mx), group)          # [asker, owner, mx]
-        send_idx = [everyone[r, rank, : int(all_counts[r, rank])] - lo for r in range(world)]
-        self.send_splits = [int(all_counts[r, rank]) for r in range(world)]    # rows I send to rank r
-        self.recv_splits = [int(c) for c in need_counts.tolist()]              # rows I receive from rank r
-        self.send_idx = torch.cat(send_idx) if send_idx else torch.zeros(0, dtype=torch.int64, device=dev)
+        self.send_splits = [int(counts_host[r][rank]) for r in range(world)]   # rows I send to rank r
+        self.recv_splits = [int(c) for c in counts_host[rank]]                 # rows I receive from rank r
+        asked = everyone[:, rank, :]                                           # [asker, mx]: what every rank asks of me
+        self.send_idx = (asked[asked >= 0] - lo).contiguous()                  # row-major = by asker, ids ascending
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < n_local)
         self.n_local, self.n_halo = n_local, int(need.numel())
         self.n_table = n_local + self.n_halo
