@@ -2,13 +2,15 @@
 // HIP ("CUDA" dispatch key on ROCm builds of torch) implementations that call the C ABI of libpangnn_hip.so on
 // torch's current stream.  No arithmetic lives here: each implementation checks its operands (TORCH_CHECK ->
 // Python RuntimeError), allocates the outputs with at::empty on the input's device and forwards raw pointers.
-// Autograd formulas, fake (meta) kernels and the autocast policy are registered on these ops from Python
-// (pangnn_amd/torch_ops.py: torch.library.register_autograd / register_fake), so `accelerate`'s autocast and
-// torch.compile see ordinary dispatcher ops.  Built by csrc/Makefile into pangnn_amd/libpangnn_torch.so (g++ against
+// Fake (meta) kernels, the autocast policy and — except for pangnn::linear, whose formula is a torch::autograd::Function
+// below — the autograd formulas are registered on these ops from Python (pangnn_amd/torch_ops.py:
+// torch.library.register_autograd / register_fake), so `accelerate`'s autocast and torch.compile see ordinary dispatcher ops.  Built by csrc/Makefile into pangnn_amd/libpangnn_torch.so (g++ against
 // the torch headers; contains no device code).
 #include <ATen/ATen.h>
+#include <ATen/core/dispatch/Dispatcher.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
 #include "../../include/pangnn_hip.h"
@@ -235,6 +237,135 @@ at::Tensor segment_max_bwd(const at::Tensor& g, const at::Tensor& arg, const at:
   return gm;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Node-level dense layer (round 4: implementation AND autograd formula in C++ — no Python between the dispatcher and the
+// kernels).  linear(x f32|bf16 [N, K], w f32 [M, K], bias?, in_act, out_bf16) -> [N, M] f32|bf16:  y = act(x) w^T + bias with
+// in_act = 1: act = ELU applied to the rows on their way into LDS (src/gnn.py:108 folded into the consumer).  K, M in
+// {64, 128} (pangnn_linear_supported; the Python layer sends every other shape to hipBLASLt).
+// linear_backward(g, x, w, in_act, has_bias, need_dx) -> (dx like x | empty, dw f32 [M, K], db f32 [M] | empty):
+// dx = (g w) * ELU'(x) in the epilogue when in_act (gate = x), dw = g^T act(x), db = column sums of g.
+// ---------------------------------------------------------------------------------------------------------------
+int32_t dtype_code(const at::Tensor& t) { return t.scalar_type() == at::kBFloat16 ? PANGNN_DTYPE_BF16 : PANGNN_DTYPE_F32; }
+
+// rows as the kernels read them: f32 (any other float is converted) or bfloat16 as stored, unit column stride, a row stride
+// that keeps 16-byte loads aligned — column windows of a wider matrix pass through without a copy
+at::Tensor rows_any(const at::Tensor& t) {
+  if (t.scalar_type() == at::kBFloat16) {
+    if (t.dim() == 2 && t.stride(1) == 1 && t.stride(0) % 8 == 0 && t.stride(0) >= t.size(1) &&
+        reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0)
+      return t;
+    return t.contiguous();
+  }
+  const at::Tensor f = t.scalar_type() == at::kFloat ? t : t.to(at::kFloat);
+  if (f.dim() == 2 && f.stride(1) == 1 && f.stride(0) % 4 == 0 && f.stride(0) >= f.size(1) &&
+      reinterpret_cast<uintptr_t>(f.data_ptr()) % 16 == 0)
+    return f;
+  return f.contiguous();
+}
+
+void linear_shapes(const char* op, const at::Tensor& x, const at::Tensor& w) {
+  on_gpu(x, "x");
+  TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && x.is_floating_point() && w.is_floating_point() && x.size(1) == w.size(1),
+              "pangnn::", op, ": x [N, K] and w [M, K] floating point, got ", x.sizes(), " and ", w.sizes());
+  TORCH_CHECK(w.is_cuda() && w.device() == x.device(), "pangnn::", op, ": w is on ", w.device(), " but the kernel runs on ",
+              x.device());
+  TORCH_CHECK(pangnn_linear_supported((int32_t)w.size(1), (int32_t)w.size(0), 0), "pangnn::", op,
+              ": K and M must be 64 or 128 (got ", w.size(1), ", ", w.size(0), ")");
+}
+
+at::Tensor linear_fwd(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t in_act,
+                      bool out_bf16) {
+  linear_shapes("linear", x, w);
+  operand_any_float("linear", "bias", bias, x);
+  TORCH_CHECK(!(bias.has_value() && bias->defined()) || bias->numel() == w.size(0), "pangnn::linear: bias must be [M]");
+  const DeviceGuard guard(x.device());
+  const at::Tensor xr = rows_any(x), wc = w.to(at::kFloat).contiguous();
+  c10::optional<at::Tensor> bc;
+  if (bias.has_value() && bias->defined()) bc = bias->to(at::kFloat).contiguous();
+  const int64_t n = xr.size(0), k = xr.size(1), m = wc.size(0);
+  auto y = at::empty({n, m}, x.options().dtype(out_bf16 ? at::kBFloat16 : at::kFloat));
+  check_rc(pangnn_linear_act_fwd_mixed(xr.data_ptr(), dtype_code(xr), xr.stride(0), wc.data_ptr<float>(), opt_ptr<float>(bc),
+                                       y.data_ptr(), dtype_code(y), y.stride(0), n, (int32_t)k, (int32_t)m, (int32_t)in_act,
+                                       nullptr, 0, 0, stream_of(x)),
+           "pangnn_linear_act_fwd_mixed");
+  return y;
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> linear_bwd(const at::Tensor& g, const at::Tensor& x, const at::Tensor& w,
+                                                         int64_t in_act, bool has_bias, bool need_dx) {
+  linear_shapes("linear_backward", x, w);
+  TORCH_CHECK(g.dim() == 2 && g.is_cuda() && g.device() == x.device() && g.is_floating_point() && g.size(0) == x.size(0) &&
+                  g.size(1) == w.size(0),
+              "pangnn::linear_backward: g must be a floating-point [N, M] on ", x.device());
+  TORCH_CHECK(pangnn_linear_supported((int32_t)w.size(1), (int32_t)w.size(0), 1),
+              "pangnn::linear_backward: this shape's weight gradient is left to the library (pangnn_linear_supported)");
+  const DeviceGuard guard(x.device());
+  const at::Tensor xr = rows_any(x), gr = rows_any(g), wc = w.to(at::kFloat).contiguous();
+  const int64_t n = xr.size(0), k = xr.size(1), m = wc.size(0);
+  at::Tensor gx = at::empty({0}, x.options());
+  if (need_dx) {
+    const at::Tensor wt = wc.t().contiguous();                      // [K, M]: dx = g w = linear(g, w^T), gated by ELU'(x)
+    gx = at::empty({n, k}, xr.options());                           // stored like x (it is x's gradient)
+    check_rc(pangnn_linear_act_fwd_mixed(gr.data_ptr(), dtype_code(gr), gr.stride(0), wt.data_ptr<float>(), nullptr,
+                                         gx.data_ptr(), dtype_code(gx), gx.stride(0), n, (int32_t)m, (int32_t)k, 0,
+                                         in_act ? xr.data_ptr() : nullptr, dtype_code(xr), in_act ? xr.stride(0) : 0,
+                                         stream_of(x)),
+             "pangnn_linear_act_fwd_mixed(dx)");
+  }
+  auto gw = at::empty({m, k}, wc.options());
+  auto gb = at::empty({has_bias ? m : 0}, wc.options());
+  const size_t wsb = pangnn_linear_wgrad_workspace_bytes((int32_t)k, (int32_t)m);
+  auto ws = at::empty({(int64_t)wsb}, wc.options().dtype(at::kByte));
+  check_rc(pangnn_linear_act_wgrad_mixed(gr.data_ptr(), dtype_code(gr), gr.stride(0), xr.data_ptr(), dtype_code(xr),
+                                         xr.stride(0), n, (int32_t)k, (int32_t)m, (int32_t)in_act, gw.data_ptr<float>(),
+                                         has_bias ? gb.data_ptr<float>() : nullptr, ws.data_ptr(), wsb, stream_of(x)),
+           "pangnn_linear_act_wgrad_mixed");
+  return {gx, gw, gb};
+}
+
+// autograd formula of pangnn::linear, registered under the Autograd key: forward redispatches below autograd, backward is
+// ONE call of pangnn::linear_backward (itself a dispatcher op, so a tracer sees it)
+at::Tensor call_linear(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t in_act,
+                       bool out_bf16) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("pangnn::linear", "")
+                       .typed<at::Tensor(const at::Tensor&, const at::Tensor&, const c10::optional<at::Tensor>&, int64_t, bool)>();
+  return op.call(x, w, bias, in_act, out_bf16);
+}
+std::tuple<at::Tensor, at::Tensor, at::Tensor> call_linear_backward(const at::Tensor& g, const at::Tensor& x,
+                                                                   const at::Tensor& w, int64_t in_act, bool has_bias,
+                                                                   bool need_dx) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("pangnn::linear_backward", "")
+                       .typed<std::tuple<at::Tensor, at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&,
+                                                                             const at::Tensor&, int64_t, bool, bool)>();
+  return op.call(g, x, w, in_act, has_bias, need_dx);
+}
+
+class LinearFunction : public torch::autograd::Function<LinearFunction> {
+ public:
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w,
+                            const c10::optional<at::Tensor>& bias, int64_t in_act, bool out_bf16) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    ctx->save_for_backward({x, w});
+    ctx->saved_data["in_act"] = in_act;
+    ctx->saved_data["has_bias"] = bias.has_value() && bias->defined();
+    return call_linear(x, w, bias, in_act, out_bf16);
+  }
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &x = saved[0], &w = saved[1];
+    const bool has_bias = ctx->saved_data["has_bias"].toBool(), need_dx = ctx->needs_input_grad(0);
+    auto [gx, gw, gb] = call_linear_backward(grads[0], x, w, ctx->saved_data["in_act"].toInt(), has_bias, need_dx);
+    return {need_dx ? gx : at::Tensor(), gw, has_bias ? gb : at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+at::Tensor linear_autograd(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t in_act,
+                           bool out_bf16) {
+  return LinearFunction::apply(x, w, bias, in_act, out_bf16);
+}
+
 }  // namespace
 
 TORCH_LIBRARY(pangnn, m) {
@@ -247,6 +378,8 @@ TORCH_LIBRARY(pangnn, m) {
   m.def("segment_sum_rows(Tensor rowptr, Tensor perm, Tensor m, int col_off, int f, int n_rows) -> Tensor");
   m.def("segment_max_rows(Tensor rowptr, Tensor perm, Tensor m, int n_rows) -> (Tensor, Tensor)");
   m.def("segment_max_bwd(Tensor g, Tensor arg, Tensor rowptr, int num_edges) -> Tensor");
+  m.def("linear(Tensor x, Tensor w, Tensor? bias, int in_act, bool out_bf16) -> Tensor");
+  m.def("linear_backward(Tensor g, Tensor x, Tensor w, int in_act, bool has_bias, bool need_dx) -> (Tensor, Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(pangnn, CUDA, m) {       // "CUDA" is the dispatch key of HIP tensors on ROCm builds of torch
@@ -258,4 +391,10 @@ TORCH_LIBRARY_IMPL(pangnn, CUDA, m) {       // "CUDA" is the dispatch key of HIP
   m.impl("segment_sum_rows", &segment_sum_rows);
   m.impl("segment_max_rows", &segment_max_rows);
   m.impl("segment_max_bwd", &segment_max_bwd);
+  m.impl("linear", &linear_fwd);
+  m.impl("linear_backward", &linear_bwd);
+}
+
+TORCH_LIBRARY_IMPL(pangnn, Autograd, m) {   // autograd formulas that live in C++ (the others are registered from Python)
+  m.impl("linear", &linear_autograd);
 }

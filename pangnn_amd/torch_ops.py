@@ -166,8 +166,7 @@ from . import functional as _PF          # noqa: E402
 from . import graph as _G                # noqa: E402
 
 _lib2 = torch.library.Library("pangnn", "FRAGMENT")
-_lib2.define("linear(Tensor x, Tensor w, Tensor? bias, int in_act, bool out_bf16) -> Tensor")
-_lib2.define("linear_backward(Tensor g, Tensor x, Tensor w, int in_act, bool has_bias, bool need_dx) -> (Tensor, Tensor, Tensor)")
+# (pangnn::linear / pangnn::linear_backward: schema, HIP implementation and autograd formula live in csrc/torch_ops.cpp)
 _lib2.define("gcn_propagate(Tensor x, Tensor? bias, Tensor edge_index, Tensor? edge_weight, bool allow_band, bool out_bf16) -> Tensor")
 _lib2.define("gcn_propagate_backward(Tensor g, Tensor edge_index, Tensor? edge_weight, bool allow_band, bool has_bias, bool x_bf16) -> (Tensor, Tensor)")
 _lib2.define("embed_conv_in(Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor? b_in, Tensor edge_index, Tensor? edge_weight, "
@@ -217,22 +216,9 @@ def _e(ref, *shape):
 
 
 # ---------------------------------------------------------------------------------------------- dense layer
-def _linear_impl(x, w, bias, in_act, out_bf16):
-    return _PF._Linear.forward(_Ctx(), x, w, bias, int(in_act), torch.bfloat16 if out_bf16 else None)
-
-
-def _linear_backward_impl(g, x, w, in_act, has_bias, need_dx):
-    ctx = _Ctx((need_dx, True, has_bias, False, False))
-    ctx.save_for_backward(_PF._rows_any(x), _PF._f32c(w))
-    ctx.has_bias, ctx.in_act = bool(has_bias), int(in_act)
-    gx, gw, gb = _PF._Linear.backward(ctx, g)[:3]
-    return (gx if gx is not None else x.new_empty(0), gw, gb if gb is not None else _e(w, 0))
-
-
-_lib2.impl("linear", _linear_impl, "CUDA")
-_lib2.impl("linear_backward", _linear_backward_impl, "CUDA")
-
-
+# implementation (TORCH_LIBRARY_IMPL(pangnn, CUDA)) and autograd formula (TORCH_LIBRARY_IMPL(pangnn, Autograd): a
+# torch::autograd::Function whose backward is ONE pangnn::linear_backward call) are C++ — csrc/torch_ops.cpp; only the
+# fake kernels are registered here
 @torch.library.register_fake("pangnn::linear")
 def _(x, w, bias, in_act, out_bf16):
     return x.new_empty(x.shape[0], w.shape[0], dtype=torch.bfloat16 if out_bf16 else torch.float32)
@@ -242,21 +228,6 @@ def _(x, w, bias, in_act, out_bf16):
 def _(g, x, w, in_act, has_bias, need_dx):
     return (x.new_empty(x.shape if need_dx else (0,)), w.new_empty(w.shape, dtype=torch.float32),
             w.new_empty(w.shape[0] if has_bias else 0, dtype=torch.float32))
-
-
-def _linear_setup(ctx, inputs, output):
-    x, w, bias, in_act, _ = inputs
-    ctx.save_for_backward(x, w)
-    ctx.in_act, ctx.has_bias = in_act, bias is not None
-
-
-def _linear_bwd(ctx, g):
-    x, w = ctx.saved_tensors
-    gx, gw, gb = ops.linear_backward(g, x, w, ctx.in_act, ctx.has_bias, ctx.needs_input_grad[0])
-    return (gx if ctx.needs_input_grad[0] else None, gw, gb if ctx.has_bias else None, None, None)
-
-
-torch.library.register_autograd("pangnn::linear", _linear_bwd, setup_context=_linear_setup)
 
 
 # ---------------------------------------------------------------------------------------------- GCN propagate
