@@ -2,8 +2,8 @@
 // HIP ("CUDA" dispatch key on ROCm builds of torch) implementations that call the C ABI of libpangnn_hip.so on
 // torch's current stream.  No arithmetic lives here: each implementation checks its operands (TORCH_CHECK ->
 // Python RuntimeError), allocates the outputs with at::empty on the input's device and forwards raw pointers.
-// Fake (meta) kernels, the autocast policy and — except for pangnn::linear, whose formula is a torch::autograd::Function
-// below — the autograd formulas are registered on these ops from Python (pangnn_amd/torch_ops.py:
+// Fake (meta) kernels, the autocast policy and — except for pangnn::linear and pangnn::bce_with_logits, whose formulas are
+// torch::autograd::Functions below — the autograd formulas are registered on these ops from Python (pangnn_amd/torch_ops.py:
 // torch.library.register_autograd / register_fake), so `accelerate`'s autocast and torch.compile see ordinary dispatcher ops.  Built by csrc/Makefile into pangnn_amd/libpangnn_torch.so (g++ against
 // the torch headers; contains no device code).
 #include <ATen/ATen.h>
@@ -366,6 +366,61 @@ at::Tensor linear_autograd(const at::Tensor& x, const at::Tensor& w, const c10::
   return LinearFunction::apply(x, w, bias, in_act, out_bf16);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Criterion: torch.nn.BCEWithLogitsLoss(pos_weight=class_balance), mean over `denom` edges (pangnn.py:98,203) —
+// bce_with_logits(logits [E], y [E], pos_weight? (device scalar), denom) -> (loss [], dL/dlogits [E]) in ONE pass
+// (pangnn_bce_logits_f32); the autograd formula hands dL/dlogits on, scaled by the upstream gradient of the loss.
+// ---------------------------------------------------------------------------------------------------------------
+std::tuple<at::Tensor, at::Tensor> bce_fwd(const at::Tensor& logits, const at::Tensor& y, const c10::optional<at::Tensor>& pw,
+                                           int64_t denom) {
+  on_gpu(logits, "logits");
+  TORCH_CHECK(logits.dim() == 1 && y.dim() == 1 && y.size(0) == logits.size(0) && logits.is_floating_point() &&
+                  y.is_floating_point() && y.is_cuda() && y.device() == logits.device(),
+              "pangnn::bce_with_logits: logits and y must be floating-point [E] on one GPU");
+  operand_any_float("bce_with_logits", "pos_weight", pw, logits);
+  TORCH_CHECK(denom >= 0, "pangnn::bce_with_logits: denom >= 0");
+  const DeviceGuard guard(logits.device());
+  const at::Tensor x = logits.to(at::kFloat).contiguous(), yy = y.to(at::kFloat).contiguous();
+  c10::optional<at::Tensor> pc;
+  if (pw.has_value() && pw->defined()) pc = pw->to(at::kFloat).contiguous().reshape({-1});
+  auto loss = at::empty({1}, x.options());
+  auto g = at::empty_like(x);
+  const size_t wsb = pangnn_bce_logits_workspace_bytes();
+  auto ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+  check_rc(pangnn_bce_logits_f32(x.data_ptr<float>(), yy.data_ptr<float>(), opt_ptr<float>(pc), x.size(0), denom,
+                                 loss.data_ptr<float>(), g.data_ptr<float>(), ws.data_ptr(), wsb, stream_of(logits)),
+           "pangnn_bce_logits_f32");
+  return {loss.view({}), g};
+}
+
+class BceFunction : public torch::autograd::Function<BceFunction> {
+ public:
+  static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& logits,
+                                                const at::Tensor& y, const c10::optional<at::Tensor>& pw, int64_t denom) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = c10::Dispatcher::singleton()
+                         .findSchemaOrThrow("pangnn::bce_with_logits", "")
+                         .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&,
+                                                                   const c10::optional<at::Tensor>&, int64_t)>();
+    auto [loss, g] = op.call(logits, y, pw, denom);
+    ctx->save_for_backward({g});
+    ctx->mark_non_differentiable({g});
+    return {loss, g};
+  }
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const at::Tensor g = ctx->get_saved_variables()[0];
+    at::Tensor gl;
+    if (grads[0].defined()) gl = g * grads[0];
+    return {gl, at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+std::tuple<at::Tensor, at::Tensor> bce_autograd(const at::Tensor& logits, const at::Tensor& y,
+                                                const c10::optional<at::Tensor>& pw, int64_t denom) {
+  auto out = BceFunction::apply(logits, y, pw, denom);
+  return {out[0], out[1]};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(pangnn, m) {
@@ -380,6 +435,7 @@ TORCH_LIBRARY(pangnn, m) {
   m.def("segment_max_bwd(Tensor g, Tensor arg, Tensor rowptr, int num_edges) -> Tensor");
   m.def("linear(Tensor x, Tensor w, Tensor? bias, int in_act, bool out_bf16) -> Tensor");
   m.def("linear_backward(Tensor g, Tensor x, Tensor w, int in_act, bool has_bias, bool need_dx) -> (Tensor, Tensor, Tensor)");
+  m.def("bce_with_logits(Tensor logits, Tensor y, Tensor? pos_weight, int denom) -> (Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(pangnn, CUDA, m) {       // "CUDA" is the dispatch key of HIP tensors on ROCm builds of torch
@@ -393,8 +449,10 @@ TORCH_LIBRARY_IMPL(pangnn, CUDA, m) {       // "CUDA" is the dispatch key of HIP
   m.impl("segment_max_bwd", &segment_max_bwd);
   m.impl("linear", &linear_fwd);
   m.impl("linear_backward", &linear_bwd);
+  m.impl("bce_with_logits", &bce_fwd);
 }
 
 TORCH_LIBRARY_IMPL(pangnn, Autograd, m) {   // autograd formulas that live in C++ (the others are registered from Python)
   m.impl("linear", &linear_autograd);
+  m.impl("bce_with_logits", &bce_autograd);
 }

@@ -748,59 +748,6 @@ def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, l
     return _DecoderLoss.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, True, live)
 
 
-class _Linear(torch.autograd.Function):
-    """y = act(x) w^T (+ b) over ~1e6 node rows with K, M in {64, 128}: streaming f32-MFMA kernels
-    (pangnn_linear_act_fwd_f32 / pangnn_linear_act_wgrad_f32); dL/dx is the forward kernel with w^T.
-    in_act = 1: x is the PRE-activation of an ELU (alpha = 1) that is applied on the fly — ELU(x) is never
-    written, and dL/dx comes out already multiplied by ELU'(x) (no activation-backward kernel)."""
-
-    @staticmethod
-    def forward(ctx, x, w, bias, in_act=0, out_dtype=None):
-        lib = _lib.load()
-        _lib.require_device(x, w, bias)
-        x, w = _rows_any(x), _f32c(w)
-        b = None if bias is None else _f32c(bias)
-        n, k = x.shape
-        m = w.shape[0]
-        y = torch.empty(n, m, dtype=out_dtype or torch.float32, device=x.device)
-        with _lib.device_guard(x.device):
-            _lib.check(lib.pangnn_linear_act_fwd_mixed(x.data_ptr(), _dt(x), x.stride(0), w.data_ptr(), _lib.ptr(b),
-                                                       y.data_ptr(), _dt(y), y.stride(0), n, k, m, int(in_act), None, 0,
-                                                       0, _lib.stream_ptr()), "pangnn_linear_act_fwd_mixed")
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        ctx.in_act = int(in_act)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        x, w = ctx.saved_tensors
-        g = _rows_any(g)                               # bf16 when the output was stored as bf16 (autograd's dtype rule)
-        n, k = x.shape
-        m = w.shape[0]
-        dev = x.device
-        gx = gw = gb = None
-        with _lib.device_guard(dev):
-            if ctx.needs_input_grad[0]:
-                wt = w.t().contiguous()                       # [K, M]: gx = g . w = linear(g, w^T)
-                gx = torch.empty(n, k, dtype=x.dtype, device=dev)        # stored like x (it is x's gradient)
-                gate, ldgate = (x.data_ptr(), x.stride(0)) if ctx.in_act else (None, 0)
-                _lib.check(lib.pangnn_linear_act_fwd_mixed(g.data_ptr(), _dt(g), g.stride(0), wt.data_ptr(), None,
-                                                           gx.data_ptr(), _dt(gx), gx.stride(0), n, m, k, 0, gate, _dt(x),
-                                                           ldgate, _lib.stream_ptr()), "pangnn_linear_act_fwd_mixed(dx)")
-            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                gw = torch.empty_like(w)
-                gb = torch.empty(m, dtype=torch.float32, device=dev) if ctx.has_bias else None
-                ws_bytes = lib.pangnn_linear_wgrad_workspace_bytes(k, m)
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                _lib.check(lib.pangnn_linear_act_wgrad_mixed(g.data_ptr(), _dt(g), g.stride(0), x.data_ptr(), _dt(x),
-                                                             x.stride(0), n, k, m, ctx.in_act, gw.data_ptr(), _lib.ptr(gb),
-                                                             ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
-                           "pangnn_linear_act_wgrad_mixed")
-        return gx, gw, gb, None, None
-
-
 @torch.compiler.assume_constant_result
 def _linear_supported(k: int, m: int) -> bool:
     """pangnn_linear_supported(k, m, wgrad=1); a constant of the shapes, baked in when torch.compile traces"""
@@ -810,56 +757,31 @@ def _linear_supported(k: int, m: int) -> bool:
 def linear(x, w, bias=None, in_act: int = 0, out_dtype=None):
     """torch.nn.functional.linear for node-level layers; shapes the HIP kernels do not cover
     (K or M outside {64,128}, or the 128x128 weight gradient) go to hipBLASLt via torch.
-    in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels (see _Linear).
+    in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels — forward: ELU applied to the rows on their
+    way into LDS; backward: dL/dx comes out already multiplied by ELU'(x), the weight gradient re-applies ELU (no activation
+    kernel, no activated tensor in HBM; pangnn::linear / linear_backward, csrc/torch_ops.cpp).
     `x` may be stored as bfloat16 and `out_dtype=torch.bfloat16` stores the result as bfloat16 (config 5's autocast
     Linear outputs): fp32 products and sums either way, one rounding on store; gradients of bf16 tensors are bf16."""
     _lib.require_device(x, w, bias)                  # no CPU path: the torch branch below is hipBLASLt on the GPU
     k, m = w.shape[1], w.shape[0]
-    if x.dim() == 2 and _linear_supported(int(k), int(m)):
-        if _via_ops() and out_dtype in (None, torch.float32, torch.bfloat16):
-            from . import torch_ops
-            return torch_ops.ops.linear(x, w, bias, int(in_act), out_dtype == torch.bfloat16)
-        return _Linear.apply(x, w, bias, in_act, out_dtype)
+    if x.dim() == 2 and _linear_supported(int(k), int(m)) and out_dtype in (None, torch.float32, torch.bfloat16):
+        # ONE route (round 4): the dispatcher op, whose HIP implementation and autograd formula are C++
+        # (csrc/torch_ops.cpp) — the ctypes autograd.Function twin of rounds 1-3 is gone
+        from . import torch_ops
+        return torch_ops.ops.linear(x, w, bias, int(in_act), out_dtype == torch.bfloat16)
     if in_act:
         x = torch.nn.functional.elu(x)
     y = torch.nn.functional.linear(x.float(), w, bias)
     return y if out_dtype is None else y.to(out_dtype)
 
 
-class _BCEWithLogits(torch.autograd.Function):
-    """mean BCEWithLogitsLoss(pos_weight) with its gradient produced in the same pass
-    (pangnn_bce_logits_f32); `denom` = edge count of the whole job."""
-
-    @staticmethod
-    def forward(ctx, logits, y, pos_weight, denom):
-        lib = _lib.load()
-        _lib.require_device(logits, y, pos_weight)
-        x, yy = _f32c(logits), _f32c(y)
-        pw = None if pos_weight is None else _f32c(pos_weight).reshape(-1)
-        n = x.shape[0]
-        loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        g = torch.empty_like(x)
-        with _lib.device_guard(x.device):
-            ws_bytes = lib.pangnn_bce_logits_workspace_bytes()
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-            _lib.check(lib.pangnn_bce_logits_f32(_lib.ptr(x), _lib.ptr(yy), _lib.ptr(pw), n, int(denom),
-                                                 loss.data_ptr(), _lib.ptr(g), ws.data_ptr(), ws_bytes,
-                                                 _lib.stream_ptr()), "pangnn_bce_logits_f32")
-        ctx.save_for_backward(g)
-        return loss.view(())
-
-    @staticmethod
-    def backward(ctx, go):
-        (g,) = ctx.saved_tensors
-        return g * go, None, None, None
-
-
 def bce_with_logits(logits, y, pos_weight=None, denom=None):
+    """mean BCEWithLogitsLoss(pos_weight) over `denom` edges (default: all of them; a partitioned shard passes the job's
+    edge count), loss and dL/dlogits from one pass: pangnn::bce_with_logits — implementation and autograd formula in C++
+    (csrc/torch_ops.cpp), the only route"""
     _lib.require_device(logits, y, pos_weight)
-    if _via_ops():
-        from . import torch_ops
-        return torch_ops.ops.bce_with_logits(logits, y, pos_weight, int(logits.shape[0] if denom is None else denom))[0]
-    return _BCEWithLogits.apply(logits, y, pos_weight, logits.shape[0] if denom is None else denom)
+    from . import torch_ops
+    return torch_ops.ops.bce_with_logits(logits, y, pos_weight, int(logits.shape[0] if denom is None else denom))[0]
 
 
 _UNIT_COLS = {}

@@ -153,7 +153,7 @@ class AlternateGCN(nn.Module):
     def _encode_pre(self, graph):
         """(z or its pre-activation, pending): every `h = act(layer(...))` of gnn.py:125-166 is consumed by exactly
         one dense layer (GCNConv.lin of the next conv, linear_out, or the decoder's first layer), so with ELU the
-        activation runs inside that layer's kernels (functional._Linear, in_act) and only the LAST one can be
+        activation runs inside that layer's kernels (functional.linear, in_act) and only the LAST one can be
         left pending for the caller."""
         fl = self.flags
         act, fold = self.activation_fct, self._fold_elu()

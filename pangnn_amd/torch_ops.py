@@ -181,7 +181,6 @@ _lib2.define("decoder_mlp_backward(Tensor g, Tensor pq, Tensor edge_index, Tenso
              "Tensor w3, Tensor b3) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
 
 
-_lib2.define("bce_with_logits(Tensor logits, Tensor y, Tensor? pos_weight, int denom) -> (Tensor, Tensor)")
 _lib2.define("embed_propagate(Tensor x, Tensor w, Tensor b, Tensor edge_index, Tensor? edge_weight) -> Tensor")
 _lib2.define("embed_propagate_backward(Tensor g, Tensor x, Tensor edge_index, Tensor? edge_weight) -> (Tensor, Tensor)")
 
@@ -428,34 +427,10 @@ torch.library.register_autograd("pangnn::embed_propagate", _ep_bwd, setup_contex
 
 
 # ---------------------------------------------------------------------------------------------- criterion
-def _bce_impl(logits, y, pos_weight, denom):
-    ctx = _Ctx()
-    loss = _PF._BCEWithLogits.forward(ctx, logits, y, pos_weight, int(denom))
-    return loss, ctx.saved_tensors[0]
-
-
-_lib2.impl("bce_with_logits", _bce_impl, "CUDA")
-
-
+# pangnn::bce_with_logits: schema, HIP implementation and autograd formula in C++ (csrc/torch_ops.cpp); fake kernel here
 @torch.library.register_fake("pangnn::bce_with_logits")
 def _(logits, y, pos_weight, denom):
     return logits.new_empty((), dtype=torch.float32), logits.new_empty(logits.shape, dtype=torch.float32)
-
-
-def _bce_setup(ctx, inputs, output):
-    ctx.save_for_backward(output[1])
-    ctx.mark_non_differentiable(output[1])
-    ctx.set_materialize_grads(False)
-
-
-def _bce_bwd(ctx, go, _g_unused):
-    if go is None:
-        return None, None, None, None
-    (g,) = ctx.saved_tensors
-    return (g if _PF.is_unit_grad(go) else g * go), None, None, None
-
-
-torch.library.register_autograd("pangnn::bce_with_logits", _bce_bwd, setup_context=_bce_setup)
 
 
 # ---------------------------------------------------------------------------------------------- decoder
