@@ -383,14 +383,14 @@ std::tuple<at::Tensor, at::Tensor> bce_fwd(const at::Tensor& logits, const at::T
   const at::Tensor x = logits.to(at::kFloat).contiguous(), yy = y.to(at::kFloat).contiguous();
   c10::optional<at::Tensor> pc;
   if (pw.has_value() && pw->defined()) pc = pw->to(at::kFloat).contiguous().reshape({-1});
-  auto loss = at::empty({1}, x.options());
+  auto loss = at::empty(at::IntArrayRef{}, x.options());          // 0-dim (NOT loss.view({}): `{}` also converts to a ScalarType)
   auto g = at::empty_like(x);
   const size_t wsb = pangnn_bce_logits_workspace_bytes();
   auto ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
   check_rc(pangnn_bce_logits_f32(x.data_ptr<float>(), yy.data_ptr<float>(), opt_ptr<float>(pc), x.size(0), denom,
                                  loss.data_ptr<float>(), g.data_ptr<float>(), ws.data_ptr(), wsb, stream_of(logits)),
            "pangnn_bce_logits_f32");
-  return {loss.view({}), g};
+  return {loss, g};
 }
 
 class BceFunction : public torch::autograd::Function<BceFunction> {
