@@ -392,3 +392,8 @@ def register(st, key=None):
 
 def clear_cache():
     _CACHE.clear()
+
+
+def forget(key):
+    """drop one entry of the identity-keyed cache (a buffer whose content was rewritten in place)"""
+    _CACHE.pop(key, None)

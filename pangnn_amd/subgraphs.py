@@ -421,8 +421,9 @@ class SubGraphDataset:
                 "pangnn_collate_subgraphs_padded")
         # what is cached on the batch object belongs to the previous content of the buffers (same addresses): replace it
         # by the structures over the tables this collation wrote, or drop it (built on first use as for any batch)
-        from .graph import clear_cache, structure_key
-        clear_cache()
+        from .graph import forget, structure_key
+        for ei in (buf.edge_index, buf.neighbour_edge_index):        # only THIS batch's entries of the identity-keyed cache
+            forget(structure_key(ei, n))
         if buf.orders is None:
             buf.__dict__.pop("_pangnn_structs", None)
         else:
