@@ -414,18 +414,27 @@ __global__ __launch_bounds__(kBlock) void collate_padded_kernel(
     int64_t* __restrict__ out_nb, float* __restrict__ out_w, float* __restrict__ out_y, int64_t* __restrict__ ptr,
     int64_t* __restrict__ batch, float* __restrict__ x, int64_t* __restrict__ live, BatchOrders ord) {
   __shared__ int64_t gid[kMaxPadGraphs], cn[kMaxPadGraphs + 1], ce[kMaxPadGraphs + 1], cb[kMaxPadGraphs + 1];
+  __shared__ int64_t raw_id[kMaxPadGraphs], raw_n[kMaxPadGraphs], raw_e[kMaxPadGraphs], raw_b[kMaxPadGraphs];
   __shared__ int g_sh;
+  // every slot's counts are fetched in parallel (one thread per slot: the loads of a slot depend on its id, the slots do not
+  // depend on each other), then one thread turns them into offsets
+  for (int k = threadIdx.x; k < max_g; k += kBlock) {
+    const int64_t id = ids[k];
+    const bool ok = id >= 0 && id < num_graphs_total;
+    raw_id[k] = ok ? id : -1;
+    raw_n[k] = ok ? node_off[id + 1] - node_off[id] : 0;
+    raw_e[k] = ok ? edge_off[id + 1] - edge_off[id] : 0;
+    raw_b[k] = ok ? nb_off[id + 1] - nb_off[id] : 0;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int g = 0;
     int64_t n = 0, e = 0, b = 0;
     cn[0] = ce[0] = cb[0] = 0;
     for (int k = 0; k < max_g; ++k) {
-      const int64_t id = ids[k];
-      if (id < 0 || id >= num_graphs_total) continue;        // unused slot
-      gid[g] = id;
-      n += node_off[id + 1] - node_off[id];
-      e += edge_off[id + 1] - edge_off[id];
-      b += nb_off[id + 1] - nb_off[id];
+      if (raw_id[k] < 0) continue;                            // unused slot
+      gid[g] = raw_id[k];
+      n += raw_n[k]; e += raw_e[k]; b += raw_b[k];
       ++g;
       cn[g] = n; ce[g] = e; cb[g] = b;
     }
