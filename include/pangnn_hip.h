@@ -398,6 +398,14 @@ int    pangnn_linear_act_fwd_mixed(const void* x, int32_t x_dtype, int64_t ldx, 
 int    pangnn_linear_act_wgrad_mixed(const void* g, int32_t g_dtype, int64_t ldg, const void* x, int32_t x_dtype,
                                      int64_t ldx, int64_t n, int32_t K, int32_t M, int32_t in_act, float* gw,
                                      float* gb, void* workspace, size_t workspace_bytes, pangnn_stream_t stream);
+/* dL/dx of the dense layer y = act(x) . w^T straight from the layer's own weight w [M][K] row-major (the kernel stages w
+ * through the strides of its transpose — no transposed copy of w per step, one launch less in a launch-bound mini-batch step):
+ *   gx [n][K] = g [n][M] . w   (* ELU'(gate[n, 0:K]) when gate != NULL: dL/d(pre-activation), as act_fwd's gate)
+ * Storage types / alignment as pangnn_linear_act_fwd_mixed with x = g, y = gx.  (autograd of nn.Linear / GCNConv.lin:
+ * src/gnn.py:104,110-116; pangnn.py:207.) */
+int    pangnn_linear_dgrad_mixed(const void* g, int32_t g_dtype, int64_t ldg, const float* w, void* gx, int32_t gx_dtype,
+                                 int64_t ldgx, int64_t n, int32_t K, int32_t M, const void* gate, int32_t gate_dtype,
+                                 int64_t ldgate, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Confusion counts of thresholded link predictions, accumulated on the device:
@@ -416,6 +424,21 @@ int    pangnn_confusion_update_f32(const float* scores, const float* labels, int
  * input is h0 = x w^T + 1 b^T, so dL/dw = (A_hat x)^T g and dL/db = (A_hat 1)^T g with g = dL/d(A_hat h0);
  * r = A_hat x and s = A_hat 1 are node vectors computed once per graph.  Reproducible two-stage sum.
  * ---------------------------------------------------------------------------------------- */
+/* (r, s) = (A_hat x, A_hat 1) over one CSR order in ONE launch: r[i] = sum_{k in row i} val[k] x[other[k]],
+ * s[i] = sum_{k in row i} val[k] (val = NULL: unit weights).  What the scalar-feature first layer needs of a graph
+ * (src/gnn.py:97,125,158 by linearity: functional._EmbedConvIn); a fresh mini-batch pays it every step. */
+int    pangnn_node_actions_f32(const int64_t* rowptr, const int32_t* other, const float* val, const float* x,
+                               int64_t n_rows, float* r, float* s, pangnn_stream_t stream);
+/* Operands of the decoder's re-associated first layer from mlp[0] = Linear(2D (+1), D) (src/gnn.py:110,173-175) in one
+ * launch: w_pq [2D][D] = [W[:, :D] ; W[:, D:2D]], b_pq [2D] = [0 ; b], cvec [D] = W[:, 2D] (skip != 0).  w: [D] rows of
+ * ldw >= 2D (+1) floats.  Plain data movement. */
+int    pangnn_pq_operands_f32(const float* w, int64_t ldw, const float* b, int32_t d, int skip, float* w_pq,
+                              float* b_pq, float* cvec, pangnn_stream_t stream);
+/* out[c] = sum_n g[n, c] of a SHORT matrix (the node rows of a mini-batch; g f32 or bfloat16, ld in elements) in one
+ * launch, fixed order of additions — the bias gradient of GCNConv (PyG: out + bias; src/gnn.py:165).  Long matrices: the
+ * two-stage sums above. */
+int    pangnn_colsum_small(const void* g, int32_t g_dtype, int64_t ldg, int64_t n, int32_t F, float* out,
+                           pangnn_stream_t stream);
 size_t pangnn_weighted_colsum_workspace_bytes(int32_t F);
 int    pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const float* r, const float* s, int64_t n,
                                   int32_t F, float* out, void* workspace, size_t workspace_bytes,

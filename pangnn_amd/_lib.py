@@ -53,6 +53,10 @@ SIGNATURES = {
     "pangnn_linear_act_fwd_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "pangnn_linear_act_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
     # bf16-storage modes: (x, x_dtype, ldx, w, bias, y, y_dtype, ldy, n, K, M, in_act, gate, gate_dtype, ldgate, stream)
+    "pangnn_linear_dgrad_mixed": (C.c_int, [_p, _i32, _i64, _p, _p, _i32, _i64, _i64, _i32, _i32, _p, _i32, _i64, _p]),
+    "pangnn_node_actions_f32": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p, _p]),
+    "pangnn_pq_operands_f32": (C.c_int, [_p, _i64, _p, _i32, C.c_int, _p, _p, _p, _p]),
+    "pangnn_colsum_small": (C.c_int, [_p, _i32, _i64, _i64, _i32, _p, _p]),
     "pangnn_linear_act_fwd_mixed": (C.c_int, [_p, _i32, _i64, _p, _p, _p, _i32, _i64, _i64, _i32, _i32, _i32, _p, _i32,
                                               _i64, _p]),
     # (g, g_dtype, ldg, x, x_dtype, ldx, n, K, M, in_act, gw, gb, workspace, bytes, stream)

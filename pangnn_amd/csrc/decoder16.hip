@@ -206,6 +206,8 @@ __device__ __forceinline__ uint4 ld_row16u(const void* table, uint32_t byte_off)
 // ---- weights -> LDS images (once per workgroup).  which = 1: W2 (P1), 2: W2'^T (P2), 3: both.
 __device__ __forceinline__ void stage_weights16(const float* w2, const float* b2, const float* w3, const float* cvec,
                                                 char* lds, int nthreads, int which, int w2p_base, int vec_base) {
+  // the loads of several rounds in flight (a mini-batch launch is a handful of workgroups that all start here)
+#pragma unroll 8
   for (int i = threadIdx.x; i < 64 * 64; i += nthreads) {
     const int j = i >> 6, k = i & 63;
     const float w = w2[i];

@@ -371,6 +371,7 @@ __global__ __launch_bounds__(kBlock) void embed_conv_in_rows_kernel(const float*
   if ((int)threadIdx.x < F) {
     float a = 0.f, c = 0.f;
     const float* wr = w_in + (int64_t)threadIdx.x * D;
+#pragma unroll 16
     for (int d = 0; d < D; ++d) { a = fmaf(wr[d], w_emb[d], a); c = fmaf(wr[d], b_emb[d], c); }
     ac[0][threadIdx.x] = a;
     ac[1][threadIdx.x] = c;
@@ -404,12 +405,15 @@ __global__ __launch_bounds__(kBlock) void embed_conv_in_param_grads_kernel(const
                                                                            float* __restrict__ g_b_emb,
                                                                            float* __restrict__ g_w_in,
                                                                            float* __restrict__ g_b_in) {
+  // (loads of several iterations in flight in both loops: this one-workgroup kernel is a chain of cache round trips otherwise)
+#pragma unroll 8
   for (int i = threadIdx.x; i < H * D; i += kBlock) {
     const int h = i / D, d = i % D;
     g_w_in[i] = fmaf(sums[h], w_emb[d], sums[H + h] * b_emb[d]);
   }
   for (int d = threadIdx.x; d < D; d += kBlock) {
     float u = 0.f, v = 0.f;
+#pragma unroll 16
     for (int h = 0; h < H; ++h) { u = fmaf(w_in[(int64_t)h * D + d], sums[h], u); v = fmaf(w_in[(int64_t)h * D + d], sums[H + h], v); }
     g_w_emb[d] = u;
     g_b_emb[d] = v;
@@ -460,6 +464,110 @@ __global__ __launch_bounds__(kBlock) void softmax_qscore_kernel(const int64_t* _
     c = c < eps ? eps : (c > 1.0 - eps ? 1.0 - eps : c);
     const double v = -10.0 * log10(c);
     q[i] = (p != p ? -10.0 * log10(1.0 - eps) : v) + pseudo;            // NaN p: the reference's nan_to_num branch
+  }
+}
+
+// (r, s) = (A_hat x, A_hat 1) of one CSR order: r[i] = sum_k val[k] x[other[k]], s[i] = sum_k val[k] over row i — the two
+// node vectors through which a scalar-feature embedding acts after one propagate (functional._node_actions).  One wave per
+// row, lanes stride the row, xor-shuffle finish: one launch where the generic propagate on a 16-column table took three
+// (table build, propagate, transpose-copy) — what a fresh mini-batch pays every step.
+__global__ __launch_bounds__(kBlock) void node_actions_kernel(const int64_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ other,
+                                                              const float* __restrict__ val, const float* __restrict__ x,
+                                                              int64_t n, float* __restrict__ r, float* __restrict__ sv) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t b = rowptr[row], e = rowptr[row + 1];
+  float ar = 0.f, as = 0.f;
+  for (int64_t k = b + lane; k < e; k += kWave) {
+    const float v = val ? val[k] : 1.f;
+    as += v;
+    ar = fmaf(v, x[other[k]], ar);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    ar += __shfl_xor(ar, off);
+    as += __shfl_xor(as, off);
+  }
+  if (lane == 0) {
+    r[row] = ar;
+    sv[row] = as;
+  }
+}
+
+// Operands of the decoder's re-associated first layer from mlp[0] = Linear(2D (+1), D) (src/gnn.py:110,173-175) in ONE launch:
+// w_pq [2D][D] = [W[:, :D] ; W[:, D:2D]], b_pq [2D] = [0 ; b], cvec [D] = W[:, 2D] (skip connections).  Plain data movement.
+__global__ __launch_bounds__(kBlock) void pq_operands_kernel(const float* __restrict__ w, int64_t ldw,
+                                                             const float* __restrict__ b, int d, float* __restrict__ w_pq,
+                                                             float* __restrict__ b_pq, float* __restrict__ cvec) {
+  const int total = 2 * d * d;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+    const int row = i / d, col = i - row * d;                 // row of w_pq: half * d + j
+    const int half = row >= d, j = row - half * d;
+    w_pq[i] = w[(int64_t)j * ldw + half * d + col];
+  }
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < 2 * d; i += kBlock) b_pq[i] = i < d ? 0.f : b[i - d];
+    if (cvec)
+      for (int i = threadIdx.x; i < d; i += kBlock) cvec[i] = w[(int64_t)i * ldw + 2 * d];
+  }
+}
+
+// column sums of a SHORT matrix (a mini-batch's node rows) in ONE one-workgroup launch.  A thread owns 4 adjacent columns
+// (16-byte loads, f32; 8-byte, bf16); the F / 4 threads of a row group take rows q, q + R, q + 2R, ... (R = 1024 / (F / 4) row
+// groups) with eight loads in flight — on 900 rows a dependent load-add per L2 round trip took 89 us — and the R partial
+// rows are added in group order: fixed order of additions, reproducible.  VEC = 1: any F <= 1024 / alignment, scalar columns.
+template <typename TG, int VEC>
+__global__ __launch_bounds__(kSumThreads) void colsum_small_kernel(const TG* __restrict__ g, int64_t ldg, int64_t n, int f,
+                                                                   float* __restrict__ out) {
+  __shared__ float red[kSumThreads * VEC];
+  const int lpr = (f + VEC - 1) / VEC;                      // threads per row
+  const int groups = kSumThreads / lpr;                     // row groups of the block (>= 1: F <= 1024 VEC)
+  const int c = threadIdx.x % lpr, q = threadIdx.x / lpr;
+  float s[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s[v] = 0.f;
+  auto ld = [&](int64_t row, float (&v)[VEC]) {
+    const TG* p = g + row * ldg + VEC * c;
+    if constexpr (VEC == 4 && sizeof(TG) == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if constexpr (VEC == 4) {
+      const uint2 t = *reinterpret_cast<const uint2*>(p);   // four bfloat16: exact in f32
+      v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+      v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    } else if constexpr (sizeof(TG) == 4) {
+      v[0] = *p;
+    } else {
+      v[0] = __uint_as_float((uint32_t)*p << 16);
+    }
+  };
+  if (q < groups) {
+    int64_t row = q;
+    for (; row + 7 * (int64_t)groups < n; row += 8 * (int64_t)groups) {
+      float v[8][VEC];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ld(row + u * (int64_t)groups, v[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s[k] += v[u][k];
+    }
+    for (; row < n; row += groups) {
+      float v[VEC];
+      ld(row, v);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) s[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) red[threadIdx.x * VEC + k] = s[k];
+  __syncthreads();
+  for (int col = threadIdx.x; col < f; col += kSumThreads) {
+    float t = 0.f;
+    for (int r = 0; r < groups; ++r) t += red[(r * lpr + col / VEC) * VEC + col % VEC];
+    out[col] = t;
   }
 }
 
@@ -630,6 +738,54 @@ extern "C" int pangnn_bce_logits_f32(const float* logits, const float* y, const 
   hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, s, static_cast<const float*>(workspace), blocks,
                      loss);
   PG_CHECK_LAUNCH("pangnn_bce_logits_f32(finish)");
+  return 0;
+}
+
+extern "C" int pangnn_node_actions_f32(const int64_t* rowptr, const int32_t* other, const float* val, const float* x,
+                                       int64_t n_rows, float* r, float* s, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_rows >= 0, PANGNN_E_BADARG, "pangnn_node_actions_f32: negative size");
+  if (n_rows == 0) return 0;
+  // `other` is NULL for an edge-less list (every row empty); E is not an argument, so that is the caller's contract
+  PG_CHECK_ARG(rowptr && x && r && s, PANGNN_E_BADARG, "pangnn_node_actions_f32: null pointer");
+  const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  hipLaunchKernelGGL(node_actions_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, rowptr, other, val, x,
+                     n_rows, r, s);
+  PG_CHECK_LAUNCH("pangnn_node_actions_f32");
+  return 0;
+}
+
+extern "C" int pangnn_pq_operands_f32(const float* w, int64_t ldw, const float* b, int32_t d, int skip, float* w_pq,
+                                      float* b_pq, float* cvec, pangnn_stream_t stream) {
+  PG_CHECK_ARG(d > 0 && d <= 4096 && ldw >= 2 * (int64_t)d + (skip ? 1 : 0), PANGNN_E_BADARG,
+               "pangnn_pq_operands_f32: w must be [D][2D (+1)] (D = %d, ldw = %lld)", (int)d, (long long)ldw);
+  PG_CHECK_ARG(w && b && w_pq && b_pq && (!skip || cvec), PANGNN_E_BADARG, "pangnn_pq_operands_f32: null pointer");
+  int blocks = (2 * d * d + kBlock - 1) / kBlock;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(pq_operands_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, w, ldw, b, (int)d, w_pq, b_pq,
+                     skip ? cvec : static_cast<float*>(nullptr));
+  PG_CHECK_LAUNCH("pangnn_pq_operands_f32");
+  return 0;
+}
+
+extern "C" int pangnn_colsum_small(const void* g, int32_t g_dtype, int64_t ldg, int64_t n, int32_t F, float* out,
+                                   pangnn_stream_t stream) {
+  PG_CHECK_ARG(n >= 0 && F > 0 && F <= kSumThreads && ldg >= F && out && (n == 0 || g), PANGNN_E_BADARG,
+               "pangnn_colsum_small: bad argument (F = %d: 1 .. %d)", (int)F, kSumThreads);
+  PG_CHECK_ARG(g_dtype == PANGNN_DTYPE_F32 || g_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
+               "pangnn_colsum_small: storage types are PANGNN_DTYPE_F32 / PANGNN_DTYPE_BF16");
+  const bool bf = g_dtype == PANGNN_DTYPE_BF16;
+  const bool vec = F % 4 == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(g) & (bf ? 7u : 15u)) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(1), block(kSumThreads);
+  if (bf && vec)
+    hipLaunchKernelGGL((colsum_small_kernel<uint16_t, 4>), grid, block, 0, st, static_cast<const uint16_t*>(g), ldg, n, (int)F, out);
+  else if (bf)
+    hipLaunchKernelGGL((colsum_small_kernel<uint16_t, 1>), grid, block, 0, st, static_cast<const uint16_t*>(g), ldg, n, (int)F, out);
+  else if (vec)
+    hipLaunchKernelGGL((colsum_small_kernel<float, 4>), grid, block, 0, st, static_cast<const float*>(g), ldg, n, (int)F, out);
+  else
+    hipLaunchKernelGGL((colsum_small_kernel<float, 1>), grid, block, 0, st, static_cast<const float*>(g), ldg, n, (int)F, out);
+  PG_CHECK_LAUNCH("pangnn_colsum_small");
   return 0;
 }
 

@@ -254,6 +254,9 @@ __device__ __forceinline__ void stage_w(const float* __restrict__ w, int sm, int
   if constexpr (WImg<K, M>::X3) {
     constexpr int WS = WImg<K, M>::WS, IMG = M * WS;
     unsigned short* W3 = reinterpret_cast<unsigned short*>(Wl);
+    // eight weight loads in flight per thread: on a mini-batch (a few workgroups, every one of them staging w before its
+    // first tile) the loop of dependent load -> split -> store rounds was most of the kernel (13-16 us for 900 rows)
+#pragma unroll 8
     for (int i = threadIdx.x; i < M * K; i += n_threads) {
       const int m = sk == 1 ? i / K : i % M, k = sk == 1 ? i % K : i / M;       // consecutive threads: consecutive addresses
       const float v = w[m * sm + k * sk];
@@ -267,6 +270,7 @@ __device__ __forceinline__ void stage_w(const float* __restrict__ w, int sm, int
     }
   } else {
     constexpr int KS = K + 4;
+#pragma unroll 8
     for (int i = threadIdx.x; i < M * K; i += n_threads) {
       const int m = sk == 1 ? i / K : i % M, k = sk == 1 ? i % K : i / M;
       Wl[m * KS + k] = w[m * sm + k * sk];
@@ -343,7 +347,7 @@ __device__ __forceinline__ void tile_mult(const float* Xt, const float* Wl, int 
 // TX / TY / TG: storage types of x, y and gate (float or bf16s).
 template <int K, int M, int ACT, bool GATE, typename TX = float, typename TY = float, typename TG = float>
 __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(const TX* __restrict__ x, int64_t ldx,
-                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ w, int w_sm, int w_sk,
                                                          const float* __restrict__ bias,
                                                          TY* __restrict__ y, int64_t ldy, int64_t n,
                                                          int64_t n_tiles, const TG* __restrict__ gate,
@@ -355,7 +359,7 @@ __global__ __launch_bounds__((FwdGeo<K, M>::WAVES * 64)) void linear_fwd_kernel(
   float* Wl = lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // SGPR
   float* Xt = lds + WF + wave * (32 * KS);
-  stage_w<K, M>(w, K, 1, Wl, WAVES * 64);
+  stage_w<K, M>(w, w_sm, w_sk, Wl, WAVES * 64);   // (K, 1): w is [M][K]; (1, M): w is the [K][M] matrix whose transpose is meant
   __syncthreads();
   const int r = lane & 31, hh = lane >> 5;
   const int64_t stride = (int64_t)gridDim.x * WAVES;
@@ -610,8 +614,9 @@ static int num_cus() {
 }
 
 template <int K, int M, typename TX, typename TY, typename TG>
-static int launch_fwd_t(const void* x, int64_t ldx, const float* w, const float* bias, void* y, int64_t ldy, int64_t n,
-                        int in_act, const void* gate, int64_t ldgate, hipStream_t s) {
+static int launch_fwd_t(const void* x, int64_t ldx, const float* w, int w_trans, const float* bias, void* y, int64_t ldy,
+                        int64_t n, int in_act, const void* gate, int64_t ldgate, hipStream_t s) {
+  const int w_sm = w_trans ? 1 : K, w_sk = w_trans ? M : 1;
   constexpr int WAVES = FwdGeo<K, M>::WAVES;
   const int64_t n_tiles = (n + 31) / 32;
   int64_t grid = (n_tiles + WAVES - 1) / WAVES;
@@ -622,12 +627,12 @@ static int launch_fwd_t(const void* x, int64_t ldx, const float* w, const float*
   TY* yp = static_cast<TY*>(y);
   const TG* gp = static_cast<const TG*>(gate);
   if (gate)
-    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, true, TX, TY, TG>), g, b, 0, s, xp, ldx, w, bias, yp, ldy, n, n_tiles, gp, ldgate);
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, true, TX, TY, TG>), g, b, 0, s, xp, ldx, w, w_sm, w_sk, bias, yp, ldy, n, n_tiles, gp, ldgate);
   else if (in_act)
-    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 1, false, TX, TY, float>), g, b, 0, s, xp, ldx, w, bias, yp, ldy, n, n_tiles,
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 1, false, TX, TY, float>), g, b, 0, s, xp, ldx, w, w_sm, w_sk, bias, yp, ldy, n, n_tiles,
                        static_cast<const float*>(nullptr), ldgate);
   else
-    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, false, TX, TY, float>), g, b, 0, s, xp, ldx, w, bias, yp, ldy, n, n_tiles,
+    hipLaunchKernelGGL((linear_fwd_kernel<K, M, 0, false, TX, TY, float>), g, b, 0, s, xp, ldx, w, w_sm, w_sk, bias, yp, ldy, n, n_tiles,
                        static_cast<const float*>(nullptr), ldgate);
   PG_CHECK_LAUNCH("pangnn_linear_fwd");
   return 0;
@@ -636,9 +641,10 @@ static int launch_fwd_t(const void* x, int64_t ldx, const float* w, const float*
 // storage-type dispatch.  A gated product (dL/dx of "dense after ELU") writes the gradient of the gate tensor, so its
 // result is stored like the gate: (TG, TY) is (f32, f32) or (bf16, bf16).
 template <int K, int M>
-static int launch_fwd(const void* x, int x_bf16, int64_t ldx, const float* w, const float* bias, void* y, int y_bf16,
-                      int64_t ldy, int64_t n, int in_act, const void* gate, int gate_bf16, int64_t ldgate, hipStream_t s) {
-#define PG_FWD(TX, TY, TG) return launch_fwd_t<K, M, TX, TY, TG>(x, ldx, w, bias, y, ldy, n, in_act, gate, ldgate, s)
+static int launch_fwd(const void* x, int x_bf16, int64_t ldx, const float* w, int w_trans, const float* bias, void* y,
+                      int y_bf16, int64_t ldy, int64_t n, int in_act, const void* gate, int gate_bf16, int64_t ldgate,
+                      hipStream_t s) {
+#define PG_FWD(TX, TY, TG) return launch_fwd_t<K, M, TX, TY, TG>(x, ldx, w, w_trans, bias, y, ldy, n, in_act, gate, ldgate, s)
   if (gate) {
     if (gate_bf16) { if (x_bf16) PG_FWD(bf16s, bf16s, bf16s); PG_FWD(float, bf16s, bf16s); }
     if (x_bf16) PG_FWD(bf16s, float, float);
@@ -707,6 +713,9 @@ __device__ __forceinline__ void gen_params(const float* __restrict__ w_emb, cons
   for (int k = threadIdx.x; k < K; k += n_threads) {
     float a = 0.f, c = 0.f;
     const float* wr = w_in + (int64_t)k * D;
+    // sixteen loads in flight (the sums stay in order): one load -> fma round per cache round trip was ~10 us of every
+    // kernel that starts here when the launch is a mini-batch's handful of workgroups
+#pragma unroll 16
     for (int d = 0; d < D; ++d) { a = fmaf(wr[d], w_emb[d], a); c = fmaf(wr[d], b_emb[d], c); }
     acb[k] = a;
     acb[K + k] = c;
@@ -1108,10 +1117,9 @@ extern "C" int pangnn_linear_supported(int32_t K, int32_t M, int wgrad) {
 static bool dtype_ok(int32_t d) { return d == PANGNN_DTYPE_F32 || d == PANGNN_DTYPE_BF16; }
 static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
-extern "C" int pangnn_linear_act_fwd_mixed(const void* x, int32_t x_dtype, int64_t ldx, const float* w, const float* bias,
-                                           void* y, int32_t y_dtype, int64_t ldy, int64_t n, int32_t K, int32_t M,
-                                           int32_t in_act, const void* gate, int32_t gate_dtype, int64_t ldgate,
-                                           pangnn_stream_t stream) {
+static int linear_fwd_common(const void* x, int32_t x_dtype, int64_t ldx, const float* w, int w_trans, const float* bias,
+                             void* y, int32_t y_dtype, int64_t ldy, int64_t n, int32_t K, int32_t M, int32_t in_act,
+                             const void* gate, int32_t gate_dtype, int64_t ldgate, pangnn_stream_t stream) {
   PG_CHECK_ARG(n >= 0, PANGNN_E_BADARG, "pangnn_linear_fwd: negative size");
   PG_CHECK_ARG(pangnn_linear_supported(K, M, 0), PANGNN_E_BADARG,
                "pangnn_linear_fwd: K and M must be 64 or 128 (got %d, %d)", (int)K, (int)M);
@@ -1127,10 +1135,25 @@ extern "C" int pangnn_linear_act_fwd_mixed(const void* x, int32_t x_dtype, int64
                PANGNN_E_ALIGN, "pangnn_linear_fwd: x rows must start on 16 bytes (f32) / 8 bytes (bf16), w on 16, ldx % 4 == 0");
   hipStream_t s = (hipStream_t)stream;
   const int xb = x_dtype == PANGNN_DTYPE_BF16, yb = y_dtype == PANGNN_DTYPE_BF16, gb = gate_dtype == PANGNN_DTYPE_BF16;
-  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
-  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
-  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
-  return launch_fwd<128, 128>(x, xb, ldx, w, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  return launch_fwd<128, 128>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+}
+
+extern "C" int pangnn_linear_act_fwd_mixed(const void* x, int32_t x_dtype, int64_t ldx, const float* w, const float* bias,
+                                           void* y, int32_t y_dtype, int64_t ldy, int64_t n, int32_t K, int32_t M,
+                                           int32_t in_act, const void* gate, int32_t gate_dtype, int64_t ldgate,
+                                           pangnn_stream_t stream) {
+  return linear_fwd_common(x, x_dtype, ldx, w, 0, bias, y, y_dtype, ldy, n, K, M, in_act, gate, gate_dtype, ldgate, stream);
+}
+
+// dL/dx of the dense layer y = act(x) w^T straight from the layer's own weight w [M][K] (no transposed copy: the kernel
+// stages w through the strides of its transpose): gx [n][K] = g [n][M] w  (* ELU'(gate) when a gate is given)
+extern "C" int pangnn_linear_dgrad_mixed(const void* g, int32_t g_dtype, int64_t ldg, const float* w, void* gx,
+                                         int32_t gx_dtype, int64_t ldgx, int64_t n, int32_t K, int32_t M, const void* gate,
+                                         int32_t gate_dtype, int64_t ldgate, pangnn_stream_t stream) {
+  return linear_fwd_common(g, g_dtype, ldg, w, 1, nullptr, gx, gx_dtype, ldgx, n, M, K, 0, gate, gate_dtype, ldgate, stream);
 }
 
 extern "C" int pangnn_linear_act_fwd_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y,

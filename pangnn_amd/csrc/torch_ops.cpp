@@ -304,13 +304,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> linear_bwd(const at::Tensor& g, c
   const int64_t n = xr.size(0), k = xr.size(1), m = wc.size(0);
   at::Tensor gx = at::empty({0}, x.options());
   if (need_dx) {
-    const at::Tensor wt = wc.t().contiguous();                      // [K, M]: dx = g w = linear(g, w^T), gated by ELU'(x)
+    // dx = g w, gated by ELU'(x): the kernel stages w [M, K] through the strides of its transpose (no copy of w^T)
     gx = at::empty({n, k}, xr.options());                           // stored like x (it is x's gradient)
-    check_rc(pangnn_linear_act_fwd_mixed(gr.data_ptr(), dtype_code(gr), gr.stride(0), wt.data_ptr<float>(), nullptr,
-                                         gx.data_ptr(), dtype_code(gx), gx.stride(0), n, (int32_t)m, (int32_t)k, 0,
-                                         in_act ? xr.data_ptr() : nullptr, dtype_code(xr), in_act ? xr.stride(0) : 0,
-                                         stream_of(x)),
-             "pangnn_linear_act_fwd_mixed(dx)");
+    check_rc(pangnn_linear_dgrad_mixed(gr.data_ptr(), dtype_code(gr), gr.stride(0), wc.data_ptr<float>(), gx.data_ptr(),
+                                       dtype_code(gx), gx.stride(0), n, (int32_t)k, (int32_t)m,
+                                       in_act ? xr.data_ptr() : nullptr, dtype_code(xr), in_act ? xr.stride(0) : 0,
+                                       stream_of(x)),
+             "pangnn_linear_dgrad_mixed");
   }
   auto gw = at::empty({m, k}, wc.options());
   auto gb = at::empty({has_bias ? m : 0}, wc.options());

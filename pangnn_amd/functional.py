@@ -96,6 +96,23 @@ def segment_sum_rows(csr: CSR, m: torch.Tensor, col_off: int, f: int, n_rows: in
     return out
 
 
+COLSUM_SMALL_ROWS = 4096
+
+
+def colsum(g: torch.Tensor) -> torch.Tensor:
+    """column sums of dL/dout (GCNConv's bias gradient) in fp32: one launch for the short matrices of a mini-batch
+    (torch's column reduction is a zero-fill + a reduce kernel there), torch's two-stage sum for long ones"""
+    if g.is_cuda and g.dim() == 2 and g.shape[0] <= COLSUM_SMALL_ROWS and g.stride(1) == 1 and 0 < g.shape[1] <= 1024 \
+            and g.dtype in (torch.float32, torch.bfloat16):
+        lib = _lib.load()
+        out = torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
+        with _lib.device_guard(g.device):
+            _lib.check(lib.pangnn_colsum_small(g.data_ptr(), _dt(g), g.stride(0), g.shape[0], g.shape[1], out.data_ptr(),
+                                               _lib.stream_ptr()), "pangnn_colsum_small")
+        return out
+    return g.sum(dim=0, dtype=torch.float32)
+
+
 class _Propagate(torch.autograd.Function):
     """out = A_hat @ x + bias with A_hat given by (structure, norm).  Backward is the transposed
     propagate over the source-grouped CSR (k5^T); edge weights are not differentiated (they are a
@@ -121,7 +138,7 @@ class _Propagate(torch.autograd.Function):
             g = _f32c(g)
         gx = spmm_csr(st.by_src, norm.by_src, g, st.num_src,
                       tag=None if ctx.tag is None else ctx.tag + ".bwd") if ctx.needs_input_grad[0] else None
-        gb = g.sum(dim=0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        gb = colsum(g) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         if gx is not None and gx.dtype != ctx.x_dtype:
             gx = gx.to(ctx.x_dtype)
         return gx, gb, None, None, None, None
@@ -784,8 +801,6 @@ def bce_with_logits(logits, y, pos_weight=None, denom=None):
     return torch_ops.ops.bce_with_logits(logits, y, pos_weight, int(logits.shape[0] if denom is None else denom))[0]
 
 
-_UNIT_COLS = {}
-
 
 def _node_actions(x_tab, st, norm):
     """(r, s) = (A_hat x, A_hat 1): the two node vectors through which a scalar-feature embedding acts after one
@@ -795,12 +810,17 @@ def _node_actions(x_tab, st, norm):
     cache = norm.__dict__.setdefault("_node_actions", {})
     key = (x_tab.data_ptr(), x_tab._version, tuple(x_tab.shape))
     if key not in cache:
-        # columns (x, 1, 0, ..., 0) = e1 + x e0^T in one launch; (r, s) = the first two result columns in one copy
-        e01 = _UNIT_COLS.get(xv.device)
-        if e01 is None:
-            e01 = _UNIT_COLS[xv.device] = torch.eye(2, 16, dtype=torch.float32, device=xv.device)
-        x16 = torch.addcmul(e01[1], xv.unsqueeze(1), e01[0])
-        rs = spmm_csr(st.by_dst, norm.by_dst, x16, st.num_nodes)[:, :2].t().contiguous()
+        # ONE launch (pangnn_node_actions_f32: a wave per row of the by-target CSR) — a fresh mini-batch pays this every step
+        # (rounds 2-4: the generic propagate on a 16-column table (x, 1, 0, ...): table build + propagate + a transposing copy)
+        lib = _lib.load()
+        xv = xv.contiguous()
+        rs = torch.empty(2, st.num_nodes, dtype=torch.float32, device=xv.device)
+        csr, val = st.by_dst, norm.by_dst
+        _lib.require_device(xv, csr.rowptr, val)
+        with _lib.device_guard(xv.device):
+            _lib.check(lib.pangnn_node_actions_f32(csr.rowptr.data_ptr(), _lib.ptr(csr.other), _lib.ptr(val), xv.data_ptr(),
+                                                   st.num_nodes, rs[0].data_ptr(), rs[1].data_ptr(), _lib.stream_ptr()),
+                       "pangnn_node_actions_f32")
         cache.clear()
         cache[key] = (rs[0], rs[1], x_tab)                                   # x_tab kept alive: key is its address
     r, s, _ = cache[key]
@@ -998,6 +1018,19 @@ class _PQOperands(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, b, d, skip):
         ctx.d, ctx.skip = int(d), bool(skip)
+        d = int(d)
+        if w.is_cuda and not observed() and w.dtype == torch.float32 and b.dtype == torch.float32 and w.dim() == 2 \
+                and w.stride(1) == 1 and b.is_contiguous() and w.shape[1] >= 2 * d + int(bool(skip)):
+            # one launch (a fresh or replayed mini-batch step is made of launches: cat + pad + copy were three)
+            lib = _lib.load()
+            out = torch.empty(2 * d * d + 2 * d + (d if skip else 0), dtype=torch.float32, device=w.device)
+            w_pq, b_pq = out[:2 * d * d].view(2 * d, d), out[2 * d * d:2 * d * d + 2 * d]
+            cvec = out[2 * d * d + 2 * d:] if skip else None
+            with _lib.device_guard(w.device):
+                _lib.check(lib.pangnn_pq_operands_f32(w.data_ptr(), w.stride(0), b.data_ptr(), d, int(bool(skip)),
+                                                      w_pq.data_ptr(), b_pq.data_ptr(), _lib.ptr(cvec), _lib.stream_ptr()),
+                           "pangnn_pq_operands_f32")
+            return w_pq, b_pq, cvec
         w_pq = torch.cat([w[:, :d], w[:, d:2 * d]], dim=0)
         b_pq = torch.nn.functional.pad(b, (d, 0))
         cvec = w[:, 2 * d].contiguous() if skip else None

@@ -1306,6 +1306,117 @@ def test_weighted_colsum_kernel(F, n):
                                                   out.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr()), "colsum")
 
 
+@pytest.mark.parametrize("n,e,hub", [(1, 0, False), (7, 40, False), (900, 3500, False), (5000, 120000, True)])
+@pytest.mark.parametrize("weighted", [True, False], ids=["weights", "unit"])
+def test_node_actions_kernel_is_the_propagate_of_x_and_of_ones(n, e, hub, weighted):
+    """pangnn_node_actions_f32: (r, s) = (A_hat x, A_hat 1) over the by-target CSR in one launch, against numpy in fp64 and
+    against the generic propagate kernel on the two-column table it replaces"""
+    from pangnn_amd import _lib
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import structure_of
+    lib = _lib.load()
+    rng = np.random.default_rng(n + e)
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    if hub and e:
+        dst[: e // 3] = 3                                                   # one row far longer than a wave
+    ei = torch.tensor(np.stack([src, dst]), dtype=torch.int64, device=dev())
+    val = torch.tensor(rng.random(e) + 0.25, dtype=torch.float32, device=dev()) if weighted else None
+    x = torch.tensor(rng.standard_normal(n), dtype=torch.float32, device=dev())
+    st = structure_of(ei, n)
+    csr = st.by_dst
+    v_csr = None if val is None else val[csr.perm.long()].contiguous()
+    r, s_ = torch.full((n,), float("nan"), device=dev()), torch.full((n,), float("nan"), device=dev())
+    with torch.cuda.device(dev()):
+        _lib.check(lib.pangnn_node_actions_f32(csr.rowptr.data_ptr(), _lib.ptr(csr.other), _lib.ptr(v_csr), x.data_ptr(), n,
+                                               r.data_ptr(), s_.data_ptr(), _lib.stream_ptr()), "node_actions")
+    v64 = np.ones(e) if val is None else val.double().cpu().numpy()
+    r_ref, s_ref = np.zeros(n), np.zeros(n)
+    np.add.at(r_ref, dst, v64 * x.double().cpu().numpy()[src])
+    np.add.at(s_ref, dst, v64)
+    assert close(r, torch.tensor(r_ref), atol=1e-5 * (1 + float(np.abs(r_ref).max(initial=0))), rtol=1e-5)
+    assert close(s_, torch.tensor(s_ref), atol=1e-5 * (1 + float(np.abs(s_ref).max(initial=0))), rtol=1e-5)
+    if e:
+        tab = torch.zeros(n, 16, device=dev())
+        tab[:, 0], tab[:, 1] = x, 1.0
+        both = PF.spmm_csr(csr, v_csr, tab, n)
+        assert close(r, both[:, 0], atol=1e-5 * (1 + float(both.abs().max())), rtol=1e-5)
+        assert close(s_, both[:, 1], atol=1e-5 * (1 + float(both.abs().max())), rtol=1e-5)
+
+
+@pytest.mark.parametrize("d,skip", [(64, False), (64, True), (16, True), (128, False)])
+def test_pq_operands_kernel_is_the_sliced_form(d, skip):
+    """pangnn_pq_operands_f32 (one launch) == cat / pad / column copy of mlp[0]'s parameters, bit for bit; gradients of
+    functional.pq_operands == autograd of the sliced form"""
+    from pangnn_amd import functional as PF
+    gen = torch.Generator().manual_seed(d)
+    w = torch.randn(d, 2 * d + int(skip), generator=gen).to(dev()).requires_grad_(True)
+    b = torch.randn(d, generator=gen).to(dev()).requires_grad_(True)
+    w_pq, b_pq, cvec = PF.pq_operands(w, b, d, skip)
+    ref = (torch.cat([w[:, :d], w[:, d:2 * d]], dim=0), torch.cat([torch.zeros_like(b), b]), w[:, 2 * d] if skip else None)
+    assert torch.equal(w_pq, ref[0]) and torch.equal(b_pq, ref[1]) and (cvec is None) == (not skip)
+    if skip:
+        assert torch.equal(cvec, ref[2])
+    up = [torch.randn_like(t) for t in (w_pq, b_pq)] + ([torch.randn_like(cvec)] if skip else [])
+    outs = [w_pq, b_pq] + ([cvec] if skip else [])
+    gw, gb = torch.autograd.grad(outs, [w, b], up)
+    gw_ref, gb_ref = torch.autograd.grad([t for t in ref if t is not None], [w, b], up)
+    assert torch.equal(gw, gw_ref) and torch.equal(gb, gb_ref)
+
+
+@pytest.mark.parametrize("F", [1, 64, 100, 128])
+@pytest.mark.parametrize("n", [0, 1, 17, 900, 16384])
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_colsum_small_kernel(F, n, bf16):
+    from pangnn_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(F + n)
+    g = torch.randn(n, F + 8, generator=gen).to(dev()).to(torch.bfloat16 if bf16 else torch.float32)[:, 4:F + 4]   # strided rows
+    outs = []
+    for _ in range(2):
+        out = torch.full((F,), float("nan"), device=dev())
+        with torch.cuda.device(dev()):
+            _lib.check(lib.pangnn_colsum_small(g.data_ptr(), int(bf16), g.stride(0), n, F, out.data_ptr(), _lib.stream_ptr()),
+                       "colsum_small")
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])                                    # fixed order of additions
+    ref = g.double().sum(0)
+    atol = 1e-5 * (1 + (float(ref.abs().max()) if n else 0.0)) + 1e-6 * n ** 0.5
+    assert close(outs[0], ref, atol=atol, rtol=1e-5)
+    from pangnn_amd import functional as PF
+    assert close(PF.colsum(g), ref, atol=atol, rtol=1e-5)
+
+
+@pytest.mark.parametrize("k,m", [(64, 64), (64, 128), (128, 64), (128, 128)])
+@pytest.mark.parametrize("n", [1, 33, 1000])
+@pytest.mark.parametrize("gated,bf16", [(False, False), (True, False), (True, True)], ids=["plain", "gate", "gate-bf16"])
+def test_linear_dgrad_from_the_layers_own_weight(k, m, n, gated, bf16):
+    """pangnn_linear_dgrad_mixed (w [M][K] staged through the strides of its transpose) == the forward kernel on a
+    transposed copy of w, bit for bit — the same operand images, the same products"""
+    from pangnn_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(k + m + n)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.randn(n, m, generator=gen).to(dev()).to(dt)
+    w = torch.randn(m, k, generator=gen).to(dev())
+    gate = torch.randn(n, k, generator=gen).to(dev()).to(dt) if gated else None
+    a = torch.full((n, k), float("nan"), dtype=dt, device=dev())
+    b = torch.full((n, k), float("nan"), dtype=dt, device=dev())
+    wt = w.t().contiguous()
+    with torch.cuda.device(dev()):
+        _lib.check(lib.pangnn_linear_dgrad_mixed(g.data_ptr(), int(bf16), g.stride(0), w.data_ptr(), a.data_ptr(), int(bf16),
+                                                 a.stride(0), n, k, m, _lib.ptr(gate), int(bf16), k if gated else 0,
+                                                 _lib.stream_ptr()), "linear_dgrad")
+        _lib.check(lib.pangnn_linear_act_fwd_mixed(g.data_ptr(), int(bf16), g.stride(0), wt.data_ptr(), None, b.data_ptr(),
+                                                   int(bf16), b.stride(0), n, m, k, 0, _lib.ptr(gate), int(bf16),
+                                                   k if gated else 0, _lib.stream_ptr()), "linear_fwd")
+    assert torch.equal(a, b)
+    ref = g.double() @ w.double()
+    if gated:
+        gd = gate.double()
+        ref = ref * torch.where(gd > 0, torch.ones_like(gd), gd.exp())
+    assert close(a.float(), ref, atol=(0.3 if bf16 else 2e-4), rtol=(2e-2 if bf16 else 1e-4))
+
+
 @pytest.mark.parametrize("F", [64, 128])
 @pytest.mark.parametrize("n", [0, 1, 5, 1000, 300007])
 @pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
