@@ -888,7 +888,12 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     tile = tile_nxt;
   }
 
-  // ---- finish: per-lane partials -> per-wave rows -> workgroup slab (fixed order)
+  // ---- finish: per-lane partials -> workgroup slab.  The eight waves are added as a fixed binary tree,
+  // ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)), through LDS: in round d the waves with bit d set (lower bits clear)
+  // write their values, their partners d below add them — every value at its own address (value v of lane l at
+  // [v][l]: conflict-free, no read-modify-write chains), three rounds.  (Rounds 2-4 let the waves take turns adding into one
+  // LDS image: eight serialised rounds of 64 dependent read-add-write steps, ~20 us — nothing at 75 M edges per launch,
+  // most of the kernel on a 5 000-edge mini-batch.)
   // gw3[j] = sum over the 16 edge slots c
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb)
@@ -905,46 +910,73 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     gb3p += __shfl_xor(gb3p, off);
     lossp += __shfl_xor(lossp, off);
   }
-  const int hh = lane >> 5, r = lane & 31;
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(lds + LDS_WAVE0);   // reuse the tile area: SLAB16 floats
-  for (int w = 0; w < S_WAVES; ++w) {
-    if (wave == w) {
-      const bool first = (w == 0);
+  constexpr int NV = 64 + 16 + 4 + 2;                        // values per lane: dL/dW2 tile | gw3 | gcvec | gb3, loss
+  float val[NV];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int j = 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int idx = j * 64 + r + 32 * nb;
-            red[idx] = (first ? 0.f : red[idx]) + w3l[j] * acc3[mb][nb][i];
-          }
-      if (c == 0) {
+      for (int i = 0; i < 16; ++i) val[32 * mb + 16 * nb + i] = acc3[mb][nb][i];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
+  for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int j = 16 * jb + 4 * g + i;
-            red[4096 + j] = 0.f;                                  // dL/db2: dgrad pass
-            red[4096 + 64 + j] = (first ? 0.f : red[4096 + 64 + j]) + gw3a[jb][i];
-          }
-      }
-      if (g == 0) {
+    for (int i = 0; i < 4; ++i) val[64 + 4 * jb + i] = gw3a[jb][i];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-          red[4096 + 128 + 16 * kb + c] = (first ? 0.f : red[4096 + 128 + 16 * kb + c]) + gcv[kb];
-      }
-      if (lane == 0) {
-        red[4096 + 192] = (first ? 0.f : red[4096 + 192]) + gb3p;
-        red[4096 + 193] = (first ? 0.f : red[4096 + 193]) + lossp;
-      }
+  for (int kb = 0; kb < 4; ++kb) val[80 + kb] = gcv[kb];
+  val[84] = gb3p;
+  val[85] = lossp;
+  __syncthreads();                                           // every wave is done with the weight / tile images
+  float* buf = reinterpret_cast<float*>(lds);                // [4 writers][NV][64 lanes] = 88 KB of the 116 KB
+  static_assert(4 * NV * 64 * 4 <= S_LDS, "tree buffers");
+#pragma unroll
+  for (int d = 1; d < S_WAVES; d <<= 1) {
+    const bool writer = (wave & (2 * d - 1)) == d, reader = (wave & (2 * d - 1)) == 0;
+    float* mine = buf + (size_t)((wave >> 1) & 3) * (NV * 64) + lane;   // writer w and its reader w - d share slot (w >> 1) & 3 ...
+    if (d == 2) mine = buf + (size_t)(wave >> 2) * (NV * 64) + lane;    // ... (round 1: pairs (0,1) (2,3) (4,5) (6,7); round 2: (0,2) (4,6))
+    if (d == 4) mine = buf + lane;
+    if (writer) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) mine[v * 64] = val[v];
+    }
+    __syncthreads();
+    if (reader) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) val[v] += mine[v * 64];
     }
     __syncthreads();
   }
-  float* slab = slabs + (int64_t)blockIdx.x * SLAB16;
-  for (int i = threadIdx.x; i < 4096 + 194; i += S_WAVES * 64) slab[i] = red[i];
+  if (wave == 0) {
+    float* slab = slabs + (int64_t)blockIdx.x * SLAB16;
+    const int hh = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int j = 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          slab[j * 64 + r + 32 * nb] = a.w3[j] * val[32 * mb + 16 * nb + i];     // (the LDS copy of w3 is under the tree buffers)
+        }
+    if (c == 0) {
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = 16 * jb + 4 * g + i;
+          slab[4096 + j] = 0.f;                                   // dL/db2: dgrad pass
+          slab[4096 + 64 + j] = val[64 + 4 * jb + i];
+        }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) slab[4096 + 128 + 16 * kb + c] = val[80 + kb];
+    }
+    if (lane == 0) {
+      slab[4096 + 192] = val[84];
+      slab[4096 + 193] = val[85];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1118,23 +1150,27 @@ __global__ __launch_bounds__(T_WAVES * 64) void decoder_dgrad16_kernel(
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) gb2a[jb][i] += __shfl_xor(gb2a[jb][i], off);
       }
+    // every wave writes its 64 sums to its own row, then 64 threads add the 16 rows in wave order (one round; rounds 2-4
+    // let the waves take turns: 16 serialised rounds of dependent LDS read-add-writes, most of a mini-batch launch)
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds + T_WAVE0);
     const float* w3v = reinterpret_cast<const float*>(lds + T_VEC) + 64;
-    for (int w = 0; w < T_WAVES; ++w) {
-      if (wave == w && c == 0) {
+    if (c == 0) {
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
+      for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int j = 16 * jb + 4 * g + i;
-            const float unscale = __builtin_bit_cast(float, (uint32_t)(127 - (7 - 2 * jb - (i >> 1))) << 23);   // 2^-p
-            red[j] = (w == 0 ? 0.f : red[j]) + w3v[j] * (gb2a[jb][i] * unscale);
-          }
-      }
-      __syncthreads();
+        for (int i = 0; i < 4; ++i) {
+          const float unscale = __builtin_bit_cast(float, (uint32_t)(127 - (7 - 2 * jb - (i >> 1))) << 23);   // 2^-p
+          red[wave * 64 + 16 * jb + 4 * g + i] = gb2a[jb][i] * unscale;
+        }
     }
-    if (threadIdx.x < 64) gb2_slabs[(int64_t)blockIdx.x * 64 + threadIdx.x] = red[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = red[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < T_WAVES; ++w) t += red[w * 64 + threadIdx.x];
+      gb2_slabs[(int64_t)blockIdx.x * 64 + threadIdx.x] = w3v[threadIdx.x] * t;
+    }
   }
 }
 

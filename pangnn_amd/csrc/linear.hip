@@ -530,6 +530,53 @@ struct WgradGeo {
   static constexpr int SLAB = M * K + M;     // gw | gb
 };
 
+// Workgroup finish of the weight-gradient kernels: the four waves' accumulators are added as a fixed binary tree,
+// (w0 + w1) + (w2 + w3), through LDS — value v of lane l at [v][l]: every store and load at its own address, two rounds —
+// and wave 0 writes the slab (gw [M][K] | gb [M]).  (Until round 4 the waves took turns adding into one LDS image: four
+// serialised rounds of dependent read-add-write steps — nothing at N = 1e6 rows, a third of the kernel on a mini-batch.)
+template <int K, int M, int LDS_F>
+__device__ __forceinline__ void wgrad_finish(const f32x16 (&acc)[M / 32][K / 32], const float (&gbp)[M / 32], float* lds,
+                                             float* __restrict__ slab, int wave, int lane) {
+  constexpr int NA = (M / 32) * (K / 32) * 16, NV = NA + M / 32;
+  static_assert(2 * NV * 64 <= LDS_F, "tree buffers of the wgrad finish");
+  const int r = lane & 31, hh = lane >> 5;
+  float val[NV];
+#pragma unroll
+  for (int a = 0; a < M / 32; ++a) {
+#pragma unroll
+    for (int b = 0; b < K / 32; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) val[(a * (K / 32) + b) * 16 + i] = acc[a][b][i];
+    val[NA + a] = gbp[a];
+  }
+  __syncthreads();                                   // every wave is done with its tile images
+#pragma unroll
+  for (int d = 1; d < 4; d <<= 1) {
+    const bool writer = (wave & (2 * d - 1)) == d, reader = (wave & (2 * d - 1)) == 0;
+    float* mine = lds + (size_t)(d == 1 ? (wave >> 1) : 0) * (NV * 64) + lane;      // pairs (0,1) (2,3), then (0,2)
+    if (writer) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) mine[v * 64] = val[v];
+    }
+    __syncthreads();
+    if (reader) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) val[v] += mine[v * 64];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int a = 0; a < M / 32; ++a) {
+#pragma unroll
+      for (int b = 0; b < K / 32; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) slab[(32 * a + jrow(i, hh)) * K + r + 32 * b] = val[(a * (K / 32) + b) * 16 + i];   // gw[m][k]
+      if (hh == 0) slab[M * K + r + 32 * a] = val[NA + a];
+    }
+  }
+}
+
 template <int K, int M, int ACT, typename TG = float, typename TX = float>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const TG* __restrict__ g, int64_t ldg,
                                                            const TX* __restrict__ x, int64_t ldx,
@@ -571,27 +618,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const TG* __restrict_
   }
 #pragma unroll
   for (int a = 0; a < M / 32; ++a) gbp[a] += __shfl_xor(gbp[a], 32);
-  __syncthreads();
-  float* red = lds;
-  for (int wv = 0; wv < 4; ++wv) {
-    if (wave == wv) {
-      const bool first = (wv == 0);
-#pragma unroll
-      for (int a = 0; a < M / 32; ++a) {
-#pragma unroll
-        for (int b = 0; b < K / 32; ++b)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int idx = (32 * a + jrow(i, hh)) * K + r + 32 * b;      // gw[m][k]
-            red[idx] = (first ? 0.f : red[idx]) + acc[a][b][i];
-          }
-        if (hh == 0) red[M * K + r + 32 * a] = (first ? 0.f : red[M * K + r + 32 * a]) + gbp[a];
-      }
-    }
-    __syncthreads();
-  }
-  float* slab = slabs + (int64_t)blockIdx.x * SLAB;
-  for (int i = threadIdx.x; i < SLAB; i += 256) slab[i] = red[i];
+  wgrad_finish<K, M, LDS_F>(acc, gbp, lds, slabs + (int64_t)blockIdx.x * SLAB, wave, lane);
 }
 
 __global__ __launch_bounds__(kSumThreads) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
@@ -950,27 +977,7 @@ __global__ __launch_bounds__(256) void gen_linear_wgrad_kernel(const float* __re
   }
 #pragma unroll
   for (int a = 0; a < M / 32; ++a) gbp[a] += __shfl_xor(gbp[a], 32);
-  __syncthreads();
-  float* red = lds;
-  for (int wv = 0; wv < 4; ++wv) {
-    if (wave == wv) {
-      const bool first = (wv == 0);
-#pragma unroll
-      for (int a = 0; a < M / 32; ++a) {
-#pragma unroll
-        for (int b = 0; b < K / 32; ++b)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int idx = (32 * a + jrow(i, hh)) * K + r + 32 * b;
-            red[idx] = (first ? 0.f : red[idx]) + acc[a][b][i];
-          }
-        if (hh == 0) red[M * K + r + 32 * a] = (first ? 0.f : red[M * K + r + 32 * a]) + gbp[a];
-      }
-    }
-    __syncthreads();
-  }
-  float* slab = slabs + (int64_t)blockIdx.x * SLAB;
-  for (int i = threadIdx.x; i < SLAB; i += 256) slab[i] = red[i];
+  wgrad_finish<K, M, LDS_F>(acc, gbp, lds, slabs + (int64_t)blockIdx.x * SLAB, wave, lane);
 }
 
 // sums[3][H] = [r s 1]^T ((g W_out) * ELU'(h)): KG = width of g (the dense layer's output width), H = width of h.
