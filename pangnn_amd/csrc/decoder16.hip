@@ -182,6 +182,18 @@ __device__ __forceinline__ bf16x8 ld_b128(const char* lds_base, int off) {
 #ifdef PANGNN_D16_DEBUG
 __device__ float* d16_dbg_v = nullptr;     // [E][64] dL/dh1pre as the S kernel sees it (diagnostic builds only)
 #endif
+#ifdef PANGNN_D16_STAMP                   // diagnostic builds only (tools/probe_decoder_stamps.py): where a small launch spends its time
+__device__ unsigned long long* d16_stamps = nullptr;     // wave 0 of workgroup 0: wall_clock64() (100 MHz) at the marked points
+#define D16_STAMP(i)                                                                          \
+  do {                                                                                        \
+    if (d16_stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {                       \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+      d16_stamps[i] = wall_clock64();                                                         \
+    }                                                                                         \
+  } while (0)
+#else
+#define D16_STAMP(i) ((void)0)
+#endif
 
 struct D16Params {
   const void* p; const void* q; uint32_t ldp_b; uint32_t ldq_b;     // row strides in bytes; rows are f32 or bf16 (PQ16)
@@ -645,8 +657,11 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int c = lane & 15, g = lane >> 4;
   char* wv = lds + LDS_WAVE0 + wave * WV_BYTES;
+  D16_STAMP(0);
   stage_weights16(a.w2, a.b2, a.w3, a.cvec, lds, S_WAVES * 64, 3, LDS_W2P, LDS_VEC);
+  D16_STAMP(1);
   __syncthreads();
+  D16_STAMP(2);
   const float* w3l = reinterpret_cast<const float*>(lds + LDS_VEC) + 64;
   const float* cvl = w3l + 64;
 
@@ -699,6 +714,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   int poff_cur = (RUNSUM && tile < n_tiles) ? rs.part_off[tile >> clog] : 0;
   float carry = 0.f;
   int64_t pidx = 0;
+  D16_STAMP(3);
 
   while (tile < n_tiles) {
     // chunk bookkeeping as selects (no branch in the loop body): a chunk's first tile starts from its part offset with
@@ -728,7 +744,9 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       // ---- P1: C[j][e] = b2[j] + sum_k W2[j][k] h1[e][k]
       f32x4 acc[4];
       uint32_t m1 = 0;                     // relu mask bits of h1 (packed inside the first product, off its split terms)
+      D16_STAMP(4 + 4 * hx);
       const float xv = p1_logit<false, true>(lds, h, wfrag0, wfrag1, g, b3v, acc, one2, &m1);
+      D16_STAMP(5 + 4 * hx);
       // the rows of the next half tile fly during the epilogue and the other two products
       issue_half_rows(a, in_nxt, g, rows);
 
@@ -842,6 +860,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       p3_block(1);
       D16_SETPRIO(0);
 
+      D16_STAMP(6 + 4 * hx);
       // ---- P2 + run sums by source
       if (RUNSUM || has_extra) {
         f32x4 v[4], gm[4];
@@ -882,6 +901,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
         }
       }
       wave_sync();          // the next half tile overwrites the images / recl / gl
+      D16_STAMP(7 + 4 * hx);
       in_cur = in_nxt;
     }
     poff_cur = last_tile ? poff_nxt : poff_cur;
@@ -910,6 +930,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     gb3p += __shfl_xor(gb3p, off);
     lossp += __shfl_xor(lossp, off);
   }
+  D16_STAMP(12);
   constexpr int NV = 64 + 16 + 4 + 2;                        // values per lane: dL/dW2 tile | gw3 | gcvec | gb3, loss
   float val[NV];
 #pragma unroll
@@ -926,6 +947,12 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   for (int kb = 0; kb < 4; ++kb) val[80 + kb] = gcv[kb];
   val[84] = gb3p;
   val[85] = lossp;
+  const int hh = lane >> 5, r = lane & 31;
+  float w3r[2][16];                                          // w3 of this lane's 32 rows of dL/dW2 (its LDS copy goes under the tree buffers)
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w3r[mb][i] = w3l[32 * mb + (i & 3) + 8 * (i >> 2) + 4 * hh];
   __syncthreads();                                           // every wave is done with the weight / tile images
   float* buf = reinterpret_cast<float*>(lds);                // [4 writers][NV][64 lanes] = 88 KB of the 116 KB
   static_assert(4 * NV * 64 * 4 <= S_LDS, "tree buffers");
@@ -946,9 +973,12 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
     }
     __syncthreads();
   }
+  D16_STAMP(13);
+  // wave 0 lays the sums out as the slab in LDS (the tree buffers are free again), every thread copies its share out:
+  // coalesced stores from 512 threads — written by wave 0 alone (68 stores per lane behind 32 dependent loads of w3) the
+  // slab took 7 us of a 25 us mini-batch launch
+  float* img = buf;
   if (wave == 0) {
-    float* slab = slabs + (int64_t)blockIdx.x * SLAB16;
-    const int hh = lane >> 5, r = lane & 31;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -956,7 +986,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int j = 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          slab[j * 64 + r + 32 * nb] = a.w3[j] * val[32 * mb + 16 * nb + i];     // (the LDS copy of w3 is under the tree buffers)
+          img[j * 64 + r + 32 * nb] = w3r[mb][i] * val[32 * mb + 16 * nb + i];
         }
     if (c == 0) {
 #pragma unroll
@@ -964,19 +994,23 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int j = 16 * jb + 4 * g + i;
-          slab[4096 + j] = 0.f;                                   // dL/db2: dgrad pass
-          slab[4096 + 64 + j] = val[64 + 4 * jb + i];
+          img[4096 + j] = 0.f;                                    // dL/db2: dgrad pass
+          img[4096 + 64 + j] = val[64 + 4 * jb + i];
         }
     }
     if (g == 0) {
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) slab[4096 + 128 + 16 * kb + c] = val[80 + kb];
+      for (int kb = 0; kb < 4; ++kb) img[4096 + 128 + 16 * kb + c] = val[80 + kb];
     }
     if (lane == 0) {
-      slab[4096 + 192] = val[84];
-      slab[4096 + 193] = val[85];
+      img[4096 + 192] = val[84];
+      img[4096 + 193] = val[85];
     }
   }
+  __syncthreads();
+  float* slab = slabs + (int64_t)blockIdx.x * SLAB16;
+  for (int i = threadIdx.x; i < 4096 + 194; i += S_WAVES * 64) slab[i] = img[i];
+  D16_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1287,6 +1321,11 @@ int launch_decoder_infer16(const float* p, int64_t ldp, const float* q, int64_t 
 
 using namespace pangnn;
 
+#ifdef PANGNN_D16_STAMP
+extern "C" int pangnn_debug_set_stamps(unsigned long long* ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(d16_stamps), &ptr, sizeof(ptr));
+}
+#endif
 #ifdef PANGNN_D16_DEBUG
 extern "C" int pangnn_debug_set_v(float* ptr) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(d16_dbg_v), &ptr, sizeof(ptr));

@@ -565,16 +565,20 @@ __device__ __forceinline__ void wgrad_finish(const f32x16 (&acc)[M / 32][K / 32]
     }
     __syncthreads();
   }
+  // wave 0 lays the sums out as the slab in LDS (the tree buffers are free again), every thread copies its share out
+  // (coalesced stores from the whole workgroup instead of 130 stores per lane of one wave)
   if (wave == 0) {
 #pragma unroll
     for (int a = 0; a < M / 32; ++a) {
 #pragma unroll
       for (int b = 0; b < K / 32; ++b)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) slab[(32 * a + jrow(i, hh)) * K + r + 32 * b] = val[(a * (K / 32) + b) * 16 + i];   // gw[m][k]
-      if (hh == 0) slab[M * K + r + 32 * a] = val[NA + a];
+        for (int i = 0; i < 16; ++i) lds[(32 * a + jrow(i, hh)) * K + r + 32 * b] = val[(a * (K / 32) + b) * 16 + i];    // gw[m][k]
+      if (hh == 0) lds[M * K + r + 32 * a] = val[NA + a];
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < M * K + M; i += 256) slab[i] = lds[i];
 }
 
 template <int K, int M, int ACT, typename TG = float, typename TX = float>

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round-4 call v: conflict-free weight staging (decoder W2'^T image, transposed dense operand): tests, small-list probe, benches
+set -o pipefail
+O=gpurun_out/r04v; mkdir -p $O
+run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit $rc; fi; return $rc; }
+run 900 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "decoder or S_and_T or padded or replayed_fresh or hip_graph_replay or minibatch or subgraph or fused_loss or alternate_gcn or linear or first_layer or fused_embedding or first_dense or folded" > $O/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -n 3 $O/tests.log
+[ $rc -eq 0 ] || exit 1
+run 300 python bench.py --workload cfg2mb_fresh --steps 400 > $O/bench_cfg2mb_fresh.json 2> $O/bench_cfg2mb_fresh.err; echo "fresh bench rc=$?"; cut -c1-300 $O/bench_cfg2mb_fresh.json
+run 300 python bench.py --workload cfg2mb --steps 400 > $O/bench_cfg2mb.json 2> $O/bench_cfg2mb.err; echo "mb bench rc=$?"; cut -c1-300 $O/bench_cfg2mb.json
+ROOT=$PWD
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_small /tmp/prof_fresh
+timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/prof_small -o p --output-format csv -- python3 $ROOT/tools/probe_decoder_small.py > $ROOT/$O/probe.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_fresh -o p --output-format csv -- python3 $ROOT/bench.py --workload cfg2mb_fresh --steps 200 > $ROOT/$O/fresh_under_rocprof.json 2> $ROOT/$O/fresh_rocprof.log
+cd $ROOT
+python tools/probe_decoder_small_report.py /tmp/prof_small | tee $O/decoder_small.txt
+python tools/step_kernel_sequence.py /tmp/prof_fresh > $O/fresh_step_sequence.txt 2>&1; grep -v "^  *[-0-9.]* us gap  *[45]\.[0-9] us" $O/fresh_step_sequence.txt | cut -c1-150
