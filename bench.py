@@ -50,9 +50,10 @@ WORKLOADS = {
 CFG5 = {"cfg5", "cfg5slice"}
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # what limits the S kernel (profiles/*_pmc_sq_decoder16.txt; updated with the kernel)
-S_BINDS = ("vector-instruction issue (553 vector incl. 84 MFMA + 89 LDS + 58 scalar instructions per 16 edges at two waves "
-           "per SIMD: 1.39 x the sum of their issue costs; profiles/r04e_pmc_sq_decoder16.txt, "
-           "profiles/r04_decoder_instruction_budget.txt), not the matrix pipe (43 % busy) nor HBM (fabric traffic = 0.48 x the "
+S_BINDS = ("vector-instruction issue PLUS matrix-pipe time (557 vector incl. 84 MFMA + 89 LDS + 58 scalar instructions per 16 "
+           "edges at two waves per SIMD; measured cycles = 4 x non-matrix VALU + matrix-pipe cycles within 4 %: the two add, "
+           "neither hides the other — profiles/r04y_pmc_sq_decoder16.txt, r04q_s_kernel_schedule_and_p3_experiments.txt, "
+           "r04_decoder_instruction_budget.txt), not the matrix pipe alone (43 % busy) nor HBM (fabric traffic = 0.48 x the "
            "algorithmic bytes)")
 
 
