@@ -2,10 +2,12 @@
 // HIP ("CUDA" dispatch key on ROCm builds of torch) implementations that call the C ABI of libpangnn_hip.so on
 // torch's current stream.  No arithmetic lives here: each implementation checks its operands (TORCH_CHECK ->
 // Python RuntimeError), allocates the outputs with at::empty on the input's device and forwards raw pointers.
-// Fake (meta) kernels, the autocast policy and — except for pangnn::linear and pangnn::bce_with_logits, whose formulas are
-// torch::autograd::Functions below — the autograd formulas are registered on these ops from Python (pangnn_amd/torch_ops.py:
-// torch.library.register_autograd / register_fake), so `accelerate`'s autocast and torch.compile see ordinary dispatcher ops.  Built by csrc/Makefile into pangnn_amd/libpangnn_torch.so (g++ against
-// the torch headers; contains no device code).
+// The autograd formulas of the ops that are pure functions of their tensor operands (linear, bce_with_logits, propagate,
+// segment_max_rows) are torch::autograd::Functions below, registered under the Autograd key.  Fake (meta) kernels, the autocast
+// policy and the formulas of the ops that look a cached graph structure up by its edge_index tensor are registered on the same
+// ops from Python (pangnn_amd/torch_ops.py: torch.library.register_fake / register_autograd), so `accelerate`'s autocast and
+// torch.compile see ordinary dispatcher ops.  Built by csrc/Makefile into pangnn_amd/libpangnn_torch.so (g++ against the torch
+// headers; contains no device code).
 #include <ATen/ATen.h>
 #include <ATen/core/dispatch/Dispatcher.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -421,6 +423,87 @@ std::tuple<at::Tensor, at::Tensor> bce_autograd(const at::Tensor& logits, const 
   return {out[0], out[1]};
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Autograd formulas of the two graph ops that are pure functions of their tensor operands (round 4: C++, like linear /
+// bce_with_logits — what is left to Python are the formulas of ops that look a cached structure up by edge_index).
+//   propagate:        dL/dx = spmm over the by-source CSR triple that rides along (the normalised weights are not
+//                     differentiated: SURVEY.md §8 a6), dL/dbias = column sums of g
+//   segment_max_rows: dL/dm = scatter of g to the arg-max entries (pangnn::segment_max_bwd)
+// Both backward formulas call registered ops, so a tracer sees them.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Sig>
+auto typed_op(const char* name) {
+  return c10::Dispatcher::singleton().findSchemaOrThrow(name, "").typed<Sig>();
+}
+
+class PropagateFunction : public torch::autograd::Function<PropagateFunction> {
+ public:
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& rowptr, const at::Tensor& other,
+                            const at::Tensor& val, const at::Tensor& rowptr_t, const at::Tensor& other_t,
+                            const at::Tensor& val_t, const at::Tensor& x, const c10::optional<at::Tensor>& bias) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    ctx->save_for_backward({rowptr_t, other_t, val_t});
+    ctx->saved_data["n_src"] = x.size(0);
+    ctx->saved_data["x_dtype"] = (int64_t)x.scalar_type();
+    ctx->saved_data["has_bias"] = bias.has_value() && bias->defined();
+    static auto op = typed_op<at::Tensor(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                         const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                         const c10::optional<at::Tensor>&)>("pangnn::propagate");
+    return op.call(rowptr, other, val, rowptr_t, other_t, val_t, x, bias);
+  }
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor& g = grads[0];
+    at::Tensor gx, gb;
+    if (ctx->needs_input_grad(6)) {
+      static auto op = typed_op<at::Tensor(const at::Tensor&, const at::Tensor&, const c10::optional<at::Tensor>&,
+                                           const at::Tensor&, const c10::optional<at::Tensor>&, int64_t)>("pangnn::spmm");
+      gx = op.call(saved[0], saved[1], saved[2], g, c10::nullopt, ctx->saved_data["n_src"].toInt());
+      const auto dt = (at::ScalarType)ctx->saved_data["x_dtype"].toInt();
+      if (gx.scalar_type() != dt) gx = gx.to(dt);
+    }
+    if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(7)) gb = g.sum(0);
+    return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gx, gb};
+  }
+};
+
+at::Tensor propagate_autograd(const at::Tensor& rowptr, const at::Tensor& other, const at::Tensor& val,
+                              const at::Tensor& rowptr_t, const at::Tensor& other_t, const at::Tensor& val_t,
+                              const at::Tensor& x, const c10::optional<at::Tensor>& bias) {
+  return PropagateFunction::apply(rowptr, other, val, rowptr_t, other_t, val_t, x, bias);
+}
+
+class SegmentMaxFunction : public torch::autograd::Function<SegmentMaxFunction> {
+ public:
+  static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& rowptr,
+                                                const at::Tensor& perm, const at::Tensor& m, int64_t n_rows) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = typed_op<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                                                 int64_t)>("pangnn::segment_max_rows");
+    auto [out, arg] = op.call(rowptr, perm, m, n_rows);
+    ctx->save_for_backward({arg, rowptr});
+    ctx->saved_data["e"] = m.size(0);
+    ctx->mark_non_differentiable({arg});
+    return {out, arg};
+  }
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    at::Tensor gm;
+    if (grads[0].defined()) {
+      static auto op = typed_op<at::Tensor(const at::Tensor&, const at::Tensor&, const at::Tensor&, int64_t)>(
+          "pangnn::segment_max_bwd");
+      gm = op.call(grads[0], saved[0], saved[1], ctx->saved_data["e"].toInt());
+    }
+    return {at::Tensor(), at::Tensor(), gm, at::Tensor()};
+  }
+};
+
+std::tuple<at::Tensor, at::Tensor> segment_max_autograd(const at::Tensor& rowptr, const at::Tensor& perm, const at::Tensor& m,
+                                                        int64_t n_rows) {
+  auto out = SegmentMaxFunction::apply(rowptr, perm, m, n_rows);
+  return {out[0], out[1]};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(pangnn, m) {
@@ -455,4 +538,6 @@ TORCH_LIBRARY_IMPL(pangnn, CUDA, m) {       // "CUDA" is the dispatch key of HIP
 TORCH_LIBRARY_IMPL(pangnn, Autograd, m) {   // autograd formulas that live in C++ (the others are registered from Python)
   m.impl("linear", &linear_autograd);
   m.impl("bce_with_logits", &bce_autograd);
+  m.impl("propagate", &propagate_autograd);
+  m.impl("segment_max_rows", &segment_max_autograd);
 }

@@ -4,8 +4,9 @@ The schemas and their HIP implementations are registered in C++ (csrc/torch_ops.
 TORCH_LIBRARY_IMPL(pangnn, CUDA, ...) over the C ABI of libpangnn_hip.so); this module loads that library and
 registers, on the same ops,
   * fake (meta) kernels — shapes / dtypes only, so FakeTensor tracing and torch.compile work without a GPU launch,
-  * autograd formulas  — propagate: the transposed propagate over the by-source CSR (edge weights are not
-    differentiated); edge_gather_concat: two segment sums; segment_max_rows: scatter to the arg-max,
+  * autograd formulas  — edge_gather_concat: two segment sums over the cached CSR orders (propagate — the transposed
+    propagate over the by-source CSR, edge weights not differentiated, SURVEY.md §8 a6 — and segment_max_rows — scatter to
+    the arg-max — have theirs in C++, csrc/torch_ops.cpp),
   * the autocast policy — what PyG does under `accelerate`'s mixed precision: the propagate gathers bfloat16 rows as
     stored (half the bytes) with fp32 weights / accumulation / result; float16 rows are promoted to fp32 (the kernels
     have no fp16 row format); everything else runs in fp32.
@@ -77,24 +78,7 @@ def _(g, arg, rowptr, num_edges):
 
 
 # ---------------------------------------------------------------------------------------------- autograd
-def _propagate_setup(ctx, inputs, output):
-    rowptr, other, val, rowptr_t, other_t, val_t, x, bias = inputs
-    ctx.save_for_backward(rowptr_t, other_t, val_t)
-    ctx.n_src, ctx.x_dtype, ctx.has_bias = x.shape[0], x.dtype, bias is not None
-
-
-def _propagate_backward(ctx, g):
-    rowptr_t, other_t, val_t = ctx.saved_tensors
-    gx = ops.spmm(rowptr_t, other_t, val_t, g, None, ctx.n_src) if ctx.needs_input_grad[6] else None
-    if gx is not None and gx.dtype != ctx.x_dtype:
-        gx = gx.to(ctx.x_dtype)
-    gb = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[7]) else None
-    return None, None, None, None, None, None, gx, gb
-
-
-torch.library.register_autograd("pangnn::propagate", _propagate_backward, setup_context=_propagate_setup)
-
-
+# pangnn::propagate and pangnn::segment_max_rows: autograd formulas in C++ (csrc/torch_ops.cpp, Autograd key)
 def _gather_setup(ctx, inputs, output):
     z, edge_index, extra = inputs
     ctx.edge_index, ctx.n, ctx.d = edge_index, z.shape[0], z.shape[1]
@@ -109,21 +93,6 @@ def _gather_backward(ctx, g):
 
 
 torch.library.register_autograd("pangnn::edge_gather_concat", _gather_backward, setup_context=_gather_setup)
-
-
-def _segmax_setup(ctx, inputs, output):
-    rowptr, perm, m, n_rows = inputs
-    ctx.save_for_backward(output[1], rowptr)
-    ctx.e = m.shape[0]
-    ctx.mark_non_differentiable(output[1])
-
-
-def _segmax_backward(ctx, g, _g_arg):
-    arg, rowptr = ctx.saved_tensors
-    return None, None, ops.segment_max_bwd(g, arg, rowptr, ctx.e), None
-
-
-torch.library.register_autograd("pangnn::segment_max_rows", _segmax_backward, setup_context=_segmax_setup)
 
 
 # ---------------------------------------------------------------------------------------------- autocast policy
