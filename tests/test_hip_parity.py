@@ -1170,6 +1170,84 @@ def test_full_size_config4_against_a_torch_fp64_evaluation():
         assert err <= FP64_DIRECT, tag
 
 
+class _ChunkedPropagateF64(torch.autograd.Function):
+    """oracle.gcn_oracle.propagate_add (index_select -> mul -> index_add_) over 4 M-edge chunks, so that the [E, F] float64
+    temporaries of a 7.5e7-edge graph never exist at once; edge weights are not differentiated"""
+
+    @staticmethod
+    def forward(ctx, x, edge_index, norm):
+        ctx.save_for_backward(edge_index, norm)
+        out = torch.zeros(x.shape, dtype=x.dtype, device=x.device)
+        for a, b in _chunks(edge_index.shape[1]):
+            out.index_add_(0, edge_index[1, a:b], norm[a:b, None] * x.index_select(0, edge_index[0, a:b]))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        edge_index, norm = ctx.saved_tensors
+        gx = torch.zeros_like(g)
+        for a, b in _chunks(edge_index.shape[1]):
+            gx.index_add_(0, edge_index[0, a:b], norm[a:b, None] * g.index_select(0, edge_index[1, a:b]))
+        return gx, None, None
+
+
+def test_full_size_config4_train_step_against_the_oracle_model_in_float64(monkeypatch):
+    """BASELINE config 4 at FULL size, the WHOLE train step (AlternateGCN default topology: embedding -> conv_in -> ELU ->
+    conv_out -> ELU -> mlp decoder -> BCEWithLogits(pos_weight) -> backward) against oracle/gcn_oracle.py's model evaluated
+    in float64 on the GPU: the oracle's own modules and gcn_norm, its propagate_add run in edge chunks (the same
+    index_select / mul / index_add_), its mlp applied to 4 M edges at a time.  Every logit within 1e-4 (north_star), the loss
+    within 1e-6, every parameter gradient within 1e-4 of its scale.  (Measured 5e-6 .. 2.2e-5: with pos_weight = neg / pos
+    the freshly initialised model's gradient is the small difference of two large class sums — dL/db3 = sum_e dL/dlogit_e
+    is 0.5 (neg - pos_weight pos) / E = 0 at sigmoid = 0.5 — so fp32 accumulation over 7.5e7 edges shows in the RESULT's
+    scale; on random decoder inputs the same kernels measure 1e-7 .. 7e-6,
+    test_full_size_config4_against_a_torch_fp64_evaluation.)"""
+    import types
+    import pangnn_amd
+    from pangnn_amd import simulate
+    g = simulate.simulate_graph(50000, 20, 0.2, 100, 20, seed=0, device=dev())
+    n, e = g.num_nodes, g.edge_index.shape[1]
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 128), flags=go.default_flags(), num_nodes=n)
+    with torch.no_grad():
+        for k, p in oracle.named_parameters():
+            if k.endswith("bias"):
+                p.uniform_(-0.5, 0.5)         # PyG initialises conv biases to 0; make them count
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], num_nodes=n)
+    model.load_state_dict(oracle.state_dict())
+    loss, logits = model.loss_and_logits(g, g.y, g.class_balance)
+    loss.backward()
+    # ---- the oracle in float64 on the GPU
+    oracle = oracle.double().to(dev())
+    monkeypatch.setattr(go, "propagate_add", lambda x, ei, norm: _ChunkedPropagateF64.apply(x, ei, norm))
+    g64 = types.SimpleNamespace(x=g.x.double(), edge_index=g.edge_index, edge_attr=g.edge_attr.double(),
+                                neighbour_edge_index=g.neighbour_edge_index)
+    z = oracle.encode(g64)
+    zl = z.detach().requires_grad_(True)
+    src, dst = g.edge_index
+    pw = float(g.class_balance)
+    loss64, worst = 0.0, 0.0
+    for a, b in _chunks(e):
+        lg = oracle.mlp(torch.cat([zl[src[a:b]], zl[dst[a:b]]], dim=1)).squeeze(-1)
+        worst = max(worst, float((logits[a:b].double() - lg.detach()).abs().max()))
+        yy = g.y[a:b].double()
+        part = torch.nn.functional.binary_cross_entropy_with_logits(
+            lg, yy, pos_weight=torch.tensor(pw, dtype=torch.float64, device=dev()), reduction="sum") / e
+        part.backward()
+        loss64 += float(part)
+    z.backward(zl.grad)
+    print(f"[full-size fp64 model] max |logit error| = {worst:.2e}; loss {float(loss):.8f} vs {loss64:.8f}")
+    assert worst <= 1e-4 and abs(float(loss) - loss64) <= 1e-6 * max(1.0, abs(loss64))
+    ref = dict(oracle.named_parameters())
+    for k, p in model.named_parameters():
+        if ref[k].grad is None:                # conv_hidden / linear_out: not on the default topology's path
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        r = ref[k].grad
+        err = float((p.grad.double() - r).abs().max()) / (float(r.abs().max()) + 1e-300)
+        print(f"[full-size fp64 model] {k}: max error / scale = {err:.2e}")
+        assert err <= 1e-4, k
+
+
 @pytest.mark.parametrize("skip", [False, True], ids=["default", "skip"])
 def test_full_size_S_and_T_kernels_agree_on_by_source_sums(skip):
     """BASELINE config 4 at full size, the two decoder kernels against EACH OTHER: dL/dP summed by source comes (i) out of
