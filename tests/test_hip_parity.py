@@ -1191,12 +1191,16 @@ class _ChunkedPropagateF64(torch.autograd.Function):
         return gx, None, None
 
 
-def test_full_size_config4_train_step_against_the_oracle_model_in_float64(monkeypatch):
+@pytest.mark.parametrize("fuse_embedding", [True, False], ids=["first-layer-by-linearity", "layer-by-layer"])
+def test_full_size_config4_train_step_against_the_oracle_model_in_float64(monkeypatch, fuse_embedding):
     """BASELINE config 4 at FULL size, the WHOLE train step (AlternateGCN default topology: embedding -> conv_in -> ELU ->
     conv_out -> ELU -> mlp decoder -> BCEWithLogits(pos_weight) -> backward) against oracle/gcn_oracle.py's model evaluated
     in float64 on the GPU: the oracle's own modules and gcn_norm, its propagate_add run in edge chunks (the same
     index_select / mul / index_add_), its mlp applied to 4 M edges at a time.  Every logit within 1e-4 (north_star), the loss
-    within 1e-6, every parameter gradient within 1e-4 of its scale.  (Measured 5e-6 .. 2.2e-5: with pos_weight = neg / pos
+    within 1e-6, every parameter gradient within 1e-4 of its scale — for the default evaluation (conv_in(embedding(x)) by
+    linearity, generated inside conv_out's dense kernels) and for the layer-by-layer one (`fuse_embedding=False`: the star
+    propagate over 7.5e7 edges and its transpose run inside the step, as they do for any non-scalar feature).
+    (Measured 5e-6 .. 2.2e-5: with pos_weight = neg / pos
     the freshly initialised model's gradient is the small difference of two large class sums — dL/db3 = sum_e dL/dlogit_e
     is 0.5 (neg - pos_weight pos) / E = 0 at sigmoid = 0.5 — so fp32 accumulation over 7.5e7 edges shows in the RESULT's
     scale; on random decoder inputs the same kernels measure 1e-7 .. 7e-6,
@@ -1212,7 +1216,7 @@ def test_full_size_config4_train_step_against_the_oracle_model_in_float64(monkey
         for k, p in oracle.named_parameters():
             if k.endswith("bias"):
                 p.uniform_(-0.5, 0.5)         # PyG initialises conv biases to 0; make them count
-    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], num_nodes=n)
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], num_nodes=n, fuse_embedding=fuse_embedding)
     model.load_state_dict(oracle.state_dict())
     loss, logits = model.loss_and_logits(g, g.y, g.class_balance)
     loss.backward()
@@ -1235,7 +1239,7 @@ def test_full_size_config4_train_step_against_the_oracle_model_in_float64(monkey
         part.backward()
         loss64 += float(part)
     z.backward(zl.grad)
-    print(f"[full-size fp64 model] max |logit error| = {worst:.2e}; loss {float(loss):.8f} vs {loss64:.8f}")
+    print(f"[full-size fp64 model, fuse_embedding={fuse_embedding}] max |logit error| = {worst:.2e}; loss {float(loss):.8f} vs {loss64:.8f}")
     assert worst <= 1e-4 and abs(float(loss) - loss64) <= 1e-6 * max(1.0, abs(loss64))
     ref = dict(oracle.named_parameters())
     for k, p in model.named_parameters():
