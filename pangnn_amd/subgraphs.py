@@ -190,6 +190,48 @@ class SubGraphDataset:
     def __len__(self):
         return self.num_graphs
 
+    @classmethod
+    def from_data_list(cls, graphs, device=None) -> "SubGraphDataset":
+        """The flat data set of a LIST of per-group sub-graphs as the reference builds them (`UnionGraphDataset`'s
+        `generate_sub_graphs`, src/dataset.py:280-310: PyG `Data` objects with `x [n, 1]`, `edge_index [2, e]` and
+        `neighbour_edge_index [2, b]` in LOCAL ids, `edge_attr [e]`, `y [e]`; any object with those attributes) — so that
+        the reference's own sub-graphs train through `batch()`, `train.GraphedTrainStep` and `train.ReplayedFreshStep`
+        (one captured HIP graph for every shuffled mini-batch) without going through this package's graph construction.
+        Edge order inside a sub-graph is kept (PyG's `Batch.from_data_list` keeps it too: logits come back in that order);
+        one host -> device copy per tensor kind, once per data set."""
+        graphs = list(graphs)
+        if not graphs:
+            raise ValueError("from_data_list needs at least one sub-graph")
+        if device is None:
+            device = graphs[0].edge_index.device
+        for i, gr in enumerate(graphs):
+            n = int(gr.x.shape[0])
+            ei, nb = gr.edge_index, gr.neighbour_edge_index
+            if ei.dim() != 2 or ei.shape[0] != 2 or nb.dim() != 2 or nb.shape[0] != 2:
+                raise ValueError(f"sub-graph {i}: edge_index / neighbour_edge_index must be [2, E]")
+            if gr.edge_attr.shape[0] < ei.shape[1] or gr.y.shape[0] != ei.shape[1]:
+                raise ValueError(f"sub-graph {i}: edge_attr / y do not match edge_index")
+            for name, t in (("edge_index", ei), ("neighbour_edge_index", nb)):
+                if t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
+                    raise ValueError(f"sub-graph {i}: {name} holds ids outside [0, {n})")
+
+        def offsets(counts):
+            off = torch.zeros(len(counts) + 1, dtype=torch.int64)
+            off[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int64), 0)
+            return off
+
+        node_off = offsets([int(gr.x.shape[0]) for gr in graphs])
+        edge_off = offsets([int(gr.edge_index.shape[1]) for gr in graphs])
+        nb_off = offsets([int(gr.neighbour_edge_index.shape[1]) for gr in graphs])
+        ei = torch.cat([gr.edge_index.to("cpu", torch.int64) + int(node_off[i]) for i, gr in enumerate(graphs)], dim=1)
+        nb = torch.cat([gr.neighbour_edge_index.to("cpu", torch.int64) + int(node_off[i]) for i, gr in enumerate(graphs)], dim=1)
+        w = torch.cat([gr.edge_attr[: gr.edge_index.shape[1]].to("cpu", torch.float32) for gr in graphs])
+        y = torch.cat([gr.y.to("cpu", torch.float32) for gr in graphs])
+        dev = torch.device(device)
+        return cls(num_graphs=len(graphs), node_off=node_off.to(dev), edge_off=edge_off.to(dev), nb_off=nb_off.to(dev),
+                   node_global=None, edge_index=ei.contiguous().to(dev), edge_attr=w.to(dev), y=y.to(dev),
+                   neighbour_edge_index=nb.contiguous().to(dev), group_of_graph=None)
+
     def _host(self):
         """host copies of the three offset tables and the order property of the flat edge list, read back ONCE: collating a
         batch then needs no device -> host synchronisation"""

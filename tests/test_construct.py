@@ -290,3 +290,29 @@ def test_padded_batch_shapes_are_host_arithmetic_on_the_offset_tables():
     assert ds.fits((g, n, e, b), big) and not ds.fits(tight, big) and not ds.fits((g, n, e, b), list(range(33)))
     sub = ds.padded_spec(8, graphs=range(20))
     assert sub[0] == 8 and sub[2] == sum(sorted(sizes(h.edge)[:20])[-8:])
+
+
+@pytest.mark.parametrize("name", ["cfg1_2genomes", "cfg3_5genomes", "cfg2_sim_1000x5"])
+def test_flat_dataset_from_reference_built_subgraphs_collates_like_pyg(name):
+    """SubGraphDataset.from_data_list over the sub-graphs AS THE REFERENCE BUILT THEM (golden fixtures: its own local node
+    numbering and edge order): every mini-batch of the flat data set is PyG's Batch.from_data_list of the same sub-graphs
+    (oracle.collate: cumulative node offsets on the index tensors, concatenation of everything else), entry for entry."""
+    from conftest import sub_graphs_from_golden
+    from oracle import gcn_oracle as go
+    from pangnn_amd.subgraphs import SubGraphDataset
+    subs = sub_graphs_from_golden(name, count=70)
+    ds = SubGraphDataset.from_data_list(subs, device="cpu")
+    assert ds.num_graphs == len(subs)
+    for i0, i1 in ((0, 32), (32, 64), (64, len(subs)), (5, 6)):
+        if i0 >= len(subs):
+            continue
+        b = ds.batch(i0, i1)
+        ref = go.collate(subs[i0:i1])
+        assert torch.equal(b.edge_index, ref.edge_index) and torch.equal(b.neighbour_edge_index, ref.neighbour_edge_index)
+        assert torch.equal(b.edge_attr, ref.edge_attr) and torch.equal(b.y, ref.y) and torch.equal(b.x, ref.x)
+        assert torch.equal(b.batch, ref.batch) and b.num_graphs == min(i1, len(subs)) - i0
+    with pytest.raises(ValueError):
+        bad = sub_graphs_from_golden(name, count=2)
+        bad[1].edge_index = bad[1].edge_index + 10_000
+        SubGraphDataset.from_data_list(bad, device="cpu")
+

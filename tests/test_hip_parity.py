@@ -977,6 +977,38 @@ def test_replayed_fresh_step_serves_every_batch(flags):
             assert close(p.grad, q.grad, atol=1e-5 * scale + 1e-9, rtol=1e-4), k
 
 
+@pytest.mark.parametrize("name", ["cfg3_5genomes", "cfg2_sim_1000x5"])
+def test_reference_built_subgraphs_train_through_one_captured_graph(name):
+    """The reference's own sub-graphs (golden fixtures of `generate_sub_graphs`: its node numbering, its edge order — not
+    source-sorted) -> SubGraphDataset.from_data_list -> train.ReplayedFreshStep: a shuffled DataLoader(batch_size=32) epoch
+    replayed from ONE captured HIP graph tracks the oracle's train steps (oracle.collate + oracle.train_step, the PyG
+    restatement) on the same batches: loss per step within 1e-4, logits of every batch within 5e-4 after the epoch's drift."""
+    import pangnn_amd
+    from pangnn_amd.subgraphs import SubGraphDataset
+    from pangnn_amd.train import ReplayedFreshStep, make_optimizer
+    subs = sub_graphs_from_golden(name, count=160)
+    ds = SubGraphDataset.from_data_list(subs, device=dev())
+    assert not ds._host().sorted_by_src                      # the reference's set-iteration edge order
+    pw = ds.class_balance()
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 128))
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+    model.load_state_dict(oracle.state_dict())
+    opt_o = torch.optim.Adam(oracle.parameters(), lr=1e-3)
+    opt_m = make_optimizer(model, capturable=True)
+    step = ReplayedFreshStep(model, opt_m, ds, pw, 32, capture=True, warmup=1)
+    perm = torch.randperm(len(subs), generator=torch.Generator().manual_seed(1)).tolist()
+    for k in range(0, len(perm), 32):
+        ids = perm[k:k + 32]
+        batch = go.collate([subs[i] for i in ids])
+        lo, out_o = go.train_step(oracle, opt_o, batch, batch.y, pw.cpu())
+        lm, out_m = step(ids)
+        assert out_m.shape == out_o.shape
+        assert close(lm, lo, atol=1e-4, rtol=1e-4), k
+        assert close(out_m, out_o, atol=5e-4, rtol=5e-4), k
+    assert len(step._slots) >= 1
+
+
 @pytest.mark.parametrize("flags", [dict(), dict(skip_connections=True)], ids=["default", "skip"])
 def test_fused_loss_pass_equals_forward_criterion_backward(flags):
     """model.loss_and_logits (one decoder pass: logits + BCE + all gradients) vs model() + criterion +
