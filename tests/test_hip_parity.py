@@ -1162,6 +1162,7 @@ def test_full_size_config4_against_a_torch_fp64_evaluation(skip, pq16):
     gp64, gq64 = torch.zeros(n, 64, dtype=torch.float64, device=dev()), torch.zeros(n, 64, dtype=torch.float64, device=dev())
     gw264, gb264 = torch.zeros(64, 64, dtype=torch.float64, device=dev()), torch.zeros(64, dtype=torch.float64, device=dev())
     gw364, gb364 = torch.zeros(64, dtype=torch.float64, device=dev()), torch.zeros((), dtype=torch.float64, device=dev())
+    gw2abs = torch.zeros(64, 64, dtype=torch.float64, device=dev())
     worst_logit = 0.0
     fragile_nodes = torch.zeros(n, dtype=torch.bool, device=dev())
     n_fragile_edges = 0
@@ -1193,6 +1194,7 @@ def test_full_size_config4_against_a_torch_fp64_evaluation(skip, pq16):
         dh2 = ge[:, None] * w364 * (h2p > 0)
         gb264 += dh2.sum(0)
         gw264 += dh2.t() @ h1
+        gw2abs += dh2.abs().t() @ h1                  # sum of |terms|: what the fp32 partial sums are made of
         dh1 = (dh2 @ W64) * (h1p > 0)
         gp64.index_add_(0, s_, dh1)
         gq64.index_add_(0, d_, dh1)
@@ -1211,6 +1213,10 @@ def test_full_size_config4_against_a_torch_fp64_evaluation(skip, pq16):
         err, err_frag = float(d[~fragile_nodes].max()), float(d[fragile_nodes].max()) if n_frag else 0.0
         print(f"[full-size fp64] {tag}: max error / scale = {err:.2e} ({err_frag:.2e} on the rows a fragile edge touches)")
         assert err <= FP64_DIRECT and err_frag <= 5e-2, tag
+    # dL/dW2 is a cancelling sum (the two classes pull in opposite directions): its error against the sum of |terms|
+    cond = float(gw2abs.max()) / float(gw264.abs().max())
+    print(f"[full-size fp64] dL/dW2: sum |terms| / |sum| = {cond:.1f}; max error / max sum |terms| = "
+          f"{float((g_w2.double() - gw264).abs().max()) / float(gw2abs.max()):.2e}")
     for got, ref, tag in ((g_w2, gw264, "dL/dW2"), (g_b2, gb264, "dL/db2"), (g_w3, gw364, "dL/dw3"),
                           (g_b3.reshape(()), gb364, "dL/db3")) + (((g_cv, gcv64, "dL/dcvec"),) if skip else ()):
         err = float((got.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-300)
