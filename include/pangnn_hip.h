@@ -24,7 +24,10 @@
 extern "C" {
 #endif
 
-#define PANGNN_ABI_VERSION 1
+/* 2 (round 5): pangnn_decoder_train_f32 / _mixed / pangnn_decoder_dgrad_f32 took live_edges in round 4 and the 32-byte record
+ * layout changed without a bump; pangnn_scale_unless_one_f32 added.  A library of another version is refused
+ * by pangnn_amd/_lib.py and by libpangnn_torch.so when it resolves this ABI. */
+#define PANGNN_ABI_VERSION 2
 
 #define PANGNN_E_BADARG    (-1)  /* null pointer / negative size / unsupported feature width */
 #define PANGNN_E_TOOLARGE  (-2)  /* size exceeds an int32 index range used by the kernels    */
@@ -526,6 +529,18 @@ int    pangnn_bce_logits_f32(const float* logits, const float* y, const float* p
 int    pangnn_softmax_qscore_f64(const int64_t* rowptr, const double* score, int64_t num_segments,
                                  int64_t num_items, double t, double epsilon, double pseudo_count, double* q,
                                  pangnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * `accelerator.backward(loss)` (pangnn.py:207) behind the one-pass training decoder: that pass has every gradient of the
+ * step's loss in memory before autograd's backward starts, so backward only has to multiply them by the upstream
+ * gradient of the loss — which `loss.backward()` / accelerate's `loss / gradient_accumulation_steps` make EXACTLY 1,
+ * a fact the host cannot read without a synchronisation.  This entry scales up to PANGNN_SCALE_MAX_TENSORS fp32 buffers in
+ * place by the DEVICE scalar scale[0] and does nothing at all (no loads beyond the scalar, no stores) when it is 1.0f.
+ * ptrs / counts are HOST arrays of n_tensors device pointers / element counts (copied into the launch arguments).
+ * ---------------------------------------------------------------------------------------- */
+#define PANGNN_SCALE_MAX_TENSORS 8
+int    pangnn_scale_unless_one_f32(float* const* ptrs, const int64_t* counts, int32_t n_tensors, const float* scale,
+                                   pangnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,9 @@ _lib.load()
 from . import torch_ops                                       # noqa: E402  (registers torch.ops.pangnn.*; raises if not built)
 from .convolution import EdgeConv, GCNConv, MessagePassing   # noqa: E402
 from .data import Batch, Data, DataLoader                    # noqa: E402
+from .deferred import BCEWithLogitsLoss, DeferredLogits        # noqa: E402
 from .gnn import AlternateGCN                                 # noqa: E402
 from .graph import EdgeStructure, structure_of                # noqa: E402
 
 __all__ = ["AlternateGCN", "GCNConv", "MessagePassing", "EdgeConv", "Data", "Batch", "DataLoader",
-           "EdgeStructure", "structure_of"]
+           "EdgeStructure", "structure_of", "BCEWithLogitsLoss", "DeferredLogits"]

@@ -105,7 +105,11 @@ SIGNATURES = {
     # T kernel: dL/dh1 run sums in a permuted (CSR) edge order from the records
     "pangnn_decoder_dgrad_workspace_bytes": (_sz, []),
     "pangnn_decoder_dgrad_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    # (host array of device pointers, host array of element counts, n_tensors, device scalar, stream)
+    "pangnn_scale_unless_one_f32": (C.c_int, [_p, _p, _i32, _p, _p]),
 }
+
+ABI_VERSION = 2          # PANGNN_ABI_VERSION of include/pangnn_hip.h this binding was written against
 
 _lib = None
 
@@ -129,8 +133,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError here == ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.pangnn_abi_version() != 1:
-        raise PangnnHipError(f"pangnn_amd: ABI version {lib.pangnn_abi_version()} != 1")
+    if lib.pangnn_abi_version() != ABI_VERSION:
+        raise PangnnHipError(f"pangnn_amd: {LIB_PATH} has ABI version {lib.pangnn_abi_version()}, this binding needs "
+                             f"{ABI_VERSION} — rebuild it from this tree (`make -C pangnn_amd/csrc`); a library selected "
+                             f"through PANGNN_HIP_LIB must come from the same tree")
     _lib = lib
     return lib
 

@@ -571,6 +571,36 @@ __global__ __launch_bounds__(kSumThreads) void colsum_small_kernel(const TG* __r
   }
 }
 
+// Gradients of the one-pass training decoder times the upstream gradient of the loss (pangnn_scale_unless_one_f32): every
+// workgroup reads the device scalar first and leaves when it is exactly 1 — what `loss.backward()` hands over — so the usual
+// step pays one launch and no memory traffic; any other value (a GradScaler's scale, a loss divided for gradient
+// accumulation) is applied in place, 16 bytes per lane where the buffer allows.
+struct ScaleList {
+  float* p[PANGNN_SCALE_MAX_TENSORS];
+  int64_t n[PANGNN_SCALE_MAX_TENSORS];
+};
+
+__global__ __launch_bounds__(kBlock) void scale_unless_one_kernel(ScaleList l, const float* __restrict__ scale) {
+  const float s = *scale;
+  if (s == 1.0f) return;
+  float* p = l.p[blockIdx.y];
+  const int64_t n = l.n[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = t; i < n4; i += stride) {
+      float4 v = p4[i];
+      v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+      p4[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + t; i < n; i += stride) p[i] *= s;
+  } else {
+    for (int64_t i = t; i < n; i += stride) p[i] *= s;
+  }
+}
+
 }  // namespace pangnn
 
 using namespace pangnn;
@@ -970,5 +1000,31 @@ extern "C" int pangnn_softmax_qscore_f64(const int64_t* rowptr, const double* sc
   hipLaunchKernelGGL(softmax_qscore_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, rowptr, score,
                      num_segments, t, epsilon, pseudo_count, q);
   PG_CHECK_LAUNCH("pangnn_softmax_qscore_f64");
+  return 0;
+}
+
+extern "C" int pangnn_scale_unless_one_f32(float* const* ptrs, const int64_t* counts, int32_t n_tensors, const float* scale,
+                                           pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_tensors >= 0 && n_tensors <= PANGNN_SCALE_MAX_TENSORS, PANGNN_E_BADARG,
+               "pangnn_scale_unless_one_f32: n_tensors = %d (0 .. %d)", (int)n_tensors, PANGNN_SCALE_MAX_TENSORS);
+  if (n_tensors == 0) return 0;
+  PG_CHECK_ARG(ptrs && counts && scale, PANGNN_E_BADARG, "pangnn_scale_unless_one_f32: null pointer");
+  ScaleList l;
+  int64_t longest = 0;
+  for (int i = 0; i < PANGNN_SCALE_MAX_TENSORS; ++i) {
+    l.p[i] = i < n_tensors ? ptrs[i] : nullptr;
+    l.n[i] = i < n_tensors ? counts[i] : 0;
+    PG_CHECK_ARG(l.n[i] >= 0 && (l.n[i] == 0 || l.p[i]), PANGNN_E_BADARG,
+                 "pangnn_scale_unless_one_f32: tensor %d: null pointer or negative count", i);
+    PG_CHECK_ARG((reinterpret_cast<uintptr_t>(l.p[i]) & 3u) == 0, PANGNN_E_ALIGN,
+                 "pangnn_scale_unless_one_f32: tensor %d is not 4-byte aligned", i);
+    if (l.n[i] > longest) longest = l.n[i];
+  }
+  if (longest == 0) return 0;
+  int64_t blocks = (longest / 4 + kBlock - 1) / kBlock;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(scale_unless_one_kernel, dim3((unsigned)blocks, (unsigned)n_tensors), dim3(kBlock), 0,
+                     (hipStream_t)stream, l, scale);
+  PG_CHECK_LAUNCH("pangnn_scale_unless_one_f32");
   return 0;
 }

@@ -462,7 +462,8 @@ class PropagateFunction : public torch::autograd::Function<PropagateFunction> {
       const auto dt = (at::ScalarType)ctx->saved_data["x_dtype"].toInt();
       if (gx.scalar_type() != dt) gx = gx.to(dt);
     }
-    if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(7)) gb = g.sum(0);
+    // fp32 column sums whatever g is stored as (a bfloat16 g under autocast: the ctypes route's colsum kernel sums in fp32 too)
+    if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(7)) gb = at::sum(g, {0}, false, at::kFloat);
     return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gx, gb};
   }
 };
@@ -507,6 +508,11 @@ std::tuple<at::Tensor, at::Tensor> segment_max_autograd(const at::Tensor& rowptr
 }  // namespace
 
 TORCH_LIBRARY(pangnn, m) {
+  // the C ABI this file was compiled against (include/pangnn_hip.h) must be the one the loaded libpangnn_hip.so implements:
+  // signatures changed between versions, and a stale library selected by path would read pointers as sizes
+  TORCH_CHECK(pangnn_abi_version() == PANGNN_ABI_VERSION, "libpangnn_torch.so was built against C ABI version ",
+              PANGNN_ABI_VERSION, " but the loaded libpangnn_hip.so reports ", pangnn_abi_version(),
+              " — rebuild both from one tree (make -C pangnn_amd/csrc)");
   m.def("csr_from_coo(Tensor edge_index, int num_nodes, int group_by) -> (Tensor, Tensor, Tensor)");
   m.def("gcn_norm(Tensor rowptr, Tensor other, Tensor perm, Tensor? edge_weight) -> (Tensor, Tensor, Tensor)");
   m.def("spmm(Tensor rowptr, Tensor other, Tensor? val, Tensor x, Tensor? bias, int n_rows) -> Tensor");

@@ -8,10 +8,10 @@ of its graphs — `x`, `edge_attr`, `y` concatenated on dim 0, every attribute w
 """
 from __future__ import annotations
 
-import random
-from typing import Iterable, List, Optional, Sequence
+from typing import List, Sequence
 
 import torch
+import torch.utils.data
 
 
 class Data:
@@ -73,26 +73,19 @@ class Batch(Data):
         return out
 
 
-class DataLoader:
-    """Minimal stand-in for torch_geometric.loader.DataLoader as called at pangnn.py:121,152-153."""
+class DataLoader(torch.utils.data.DataLoader):
+    """torch_geometric.loader.DataLoader as called at pangnn.py:121,152-153: a `torch.utils.data.DataLoader` over a list of
+    `Data` whose collate function is `Batch.from_data_list` (what PyG's loader is), so `accelerator.prepare(loader)`
+    (pangnn.py:122,155) wraps it like any torch loader and moves every `Batch` to the device through its `.to()`.
+    `device=` does that move here for loops that do not go through accelerate."""
 
-    def __init__(self, dataset: Sequence[Data], batch_size: int = 1, shuffle: bool = False,
-                 pin_memory: bool = False, device=None, generator: Optional[random.Random] = None):
-        self.dataset, self.batch_size, self.shuffle = list(dataset), int(batch_size), shuffle
-        self.pin_memory, self.device = pin_memory, device
-        self._rng = generator or random.Random()
+    def __init__(self, dataset: Sequence[Data], batch_size: int = 1, shuffle: bool = False, device=None, **kwargs):
+        kwargs.pop("collate_fn", None)
+        self._device = device
+        super().__init__(list(dataset), batch_size=int(batch_size), shuffle=bool(shuffle), collate_fn=self._collate, **kwargs)
 
-    def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
-
-    def __iter__(self) -> Iterable[Batch]:
-        order = list(range(len(self.dataset)))
-        if self.shuffle:
-            self._rng.shuffle(order)
-        for i in range(0, len(order), self.batch_size):
-            b = Batch.from_data_list([self.dataset[j] for j in order[i:i + self.batch_size]])
-            if self.pin_memory and torch.cuda.is_available():
-                b.pin_memory()
-            if self.device is not None:
-                b = b.to(self.device, non_blocking=self.pin_memory)
-            yield b
+    def _collate(self, graphs):
+        b = Batch.from_data_list(graphs)
+        if self._device is not None and self.num_workers == 0:
+            b = b.to(self._device, non_blocking=bool(self.pin_memory))
+        return b

@@ -658,6 +658,35 @@ def is_unit_grad(g: torch.Tensor) -> bool:
     return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0
 
 
+def scale_by_loss_grad_(ctx, tensors, go):
+    """The gradients the one-pass training decoder left in memory, times the upstream gradient `go` of its loss.
+    `loss.backward()` and accelerate's `(loss / gradient_accumulation_steps).backward()` (pangnn.py:207) hand over EXACTLY 1,
+    which the host cannot know without a synchronisation: pangnn_scale_unless_one_f32 reads the device scalar and returns
+    when it is 1.0, so the usual step costs one launch and no pass over the [N, 128] gradient; any other value (a
+    GradScaler's scale under fp16, gradient accumulation) is applied in place.  In place means the stored gradients are
+    consumed: a second backward through the same node (retain_graph=True) raises instead of scaling twice."""
+    if type(go) is not torch.Tensor or not go.is_cuda:          # a FakeTensor while a compiler traces the formula
+        return [None if t is None else t * go for t in tensors]
+    if getattr(ctx, "_pangnn_scaled", False):
+        raise RuntimeError("pangnn_amd: the fused decoder loss computes its gradients in its forward pass and hands them over "
+                           "once; backward through it a second time is not supported (call the model again)")
+    ctx._pangnn_scaled = True
+    live = [t for t in tensors if t is not None and t.numel() > 0]
+    for t in live:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            return [None if u is None else u * go for u in tensors]
+    lib = _lib.load()
+    n = len(live)
+    if n:
+        import ctypes as C
+        g32 = go if go.dtype == torch.float32 else go.float()
+        with _lib.device_guard(g32.device):
+            _lib.check(lib.pangnn_scale_unless_one_f32((C.c_void_p * n)(*[t.data_ptr() for t in live]),
+                                                       (C.c_int64 * n)(*[t.numel() for t in live]), n,
+                                                       g32.data_ptr(), _lib.stream_ptr()), "pangnn_scale_unless_one_f32")
+    return list(tensors)
+
+
 class _DecoderLoss(torch.autograd.Function):
     """Training form of the fused decoder: mean BCEWithLogits(pos_weight) loss, logits and ALL gradients in
     one pass over the edges (pangnn_decoder_mlp_loss_f32).  Everything is computed in forward(); backward()
@@ -747,8 +776,9 @@ class _DecoderLoss(torch.autograd.Function):
         if is_unit_grad(go):         # `loss.backward(unit_grad(device))` (train.train_step): nothing to scale
             return (gp, gq if ctx.has_q else None, None, None, g_cv if ctx.has_cv else None,
                     g_w2, g_b2, g_w3, g_b3, None, None, None, None, None)
-        return (gp * go, (gq * go) if ctx.has_q else None, None, None, (g_cv * go) if ctx.has_cv else None,
-                g_w2 * go, g_b2 * go, g_w3 * go, g_b3 * go, None, None, None, None, None)
+        gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = scale_by_loss_grad_(
+            ctx, [gp, gq if ctx.has_q else None, g_cv if ctx.has_cv else None, g_w2, g_b2, g_w3, g_b3], go)
+        return (gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None, None, None, None, None)
 
 
 def decoder_loss(p, q, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):

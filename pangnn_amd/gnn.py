@@ -50,7 +50,8 @@ _FLAG_DEFAULTS = dict(union_edge_weights=False, base_model=False, skip_connectio
 class AlternateGCN(nn.Module):
     def __init__(self, device=None, dataset=None, categorical_nodes: bool = False, dims=(64, 128),
                  args=None, num_nodes: Optional[int] = None, fused_decoder: bool = True,
-                 fuse_embedding: bool = True, fold_activation: bool = True, fuse_first_dense: Optional[bool] = None, **flags):
+                 fuse_embedding: bool = True, fold_activation: bool = True, fuse_first_dense: Optional[bool] = None,
+                 deferred_logits: Optional[bool] = None, **flags):
         super().__init__()
         self.device = device
         cfg = dict(_FLAG_DEFAULTS)
@@ -69,6 +70,9 @@ class AlternateGCN(nn.Module):
         # None: on unless PANGNN_FUSE_FIRST_DENSE=0 (same-box A/B of bench.py)
         self.fuse_first_dense = (os.environ.get("PANGNN_FUSE_FIRST_DENSE", "1") != "0") if fuse_first_dense is None \
             else bool(fuse_first_dense)
+        # None: on unless PANGNN_DEFERRED_LOGITS=0 — training-mode forward() returns a DeferredLogits handle (deferred.py)
+        self.deferred_logits = (os.environ.get("PANGNN_DEFERRED_LOGITS", "1") != "0") if deferred_logits is None \
+            else bool(deferred_logits)
         node_embedding_dim, hidden_dim = dims
 
         if categorical_nodes:
@@ -206,17 +210,27 @@ class AlternateGCN(nn.Module):
         pq_dtype = torch.bfloat16 if (PF.autocast_bf16(z) and d == 64 and PF.DECODER_PRECISION == 1) else None
         return PF.linear(z, w_pq, b_pq, in_act, pq_dtype), st, extra, cvec
 
-    def loss_and_logits(self, graph, labels, pos_weight=None):
-        """`criterion(model(graph), labels)` (pangnn.py:200-203) as ONE decoder pass when the fused kernel
-        applies (mlp decoder, node_dim 64): returns (loss, detached logits).  Falls back to forward +
-        criterion otherwise."""
-        from .train import criterion
+    def _fused_decoder_operands(self, graph):
+        """(pq, structure, extra, cvec) of the one-pass training decoder, or None where that kernel does not apply (another
+        decoder, node_dim != 64, no gradient wanted): the encoder (gnn.py:125-166) with its last ELU folded into the
+        node-level half of `mlp[0]` (gnn.py:110,173-175)"""
         z, pending = self._encode_pre(graph)
         fused = "mlp" in self.flags.decoder and self.fused_decoder is True and z.shape[1] == 64 and torch.is_grad_enabled()
         if not (fused and pending and self._fold_elu()):
             z, pending = (self.activation_fct(z) if pending else z), False
-        if fused:
-            pq, st, extra, cvec = self._decoder_inputs(z, graph, 1 if pending else 0)
+        if not fused:
+            return None, z
+        return self._decoder_inputs(z, graph, 1 if pending else 0), z
+
+    def loss_and_logits(self, graph, labels, pos_weight=None):
+        """`criterion(model(graph), labels)` (pangnn.py:200-203) as ONE decoder pass when the fused kernel
+        applies (mlp decoder, node_dim 64): returns (loss, detached logits).  Falls back to forward +
+        criterion otherwise.  `model(graph)` followed by torch's / this package's BCEWithLogitsLoss reaches the same pass
+        through the handle `forward` returns in training mode (deferred.DeferredLogits)."""
+        from .train import criterion
+        ops, z = self._fused_decoder_operands(graph)
+        if ops is not None:
+            pq, st, extra, cvec = ops
             # a padded fixed-shape batch (SubGraphDataset.padded_buffers) carries the number of its real edges on the device
             return PF.decoder_loss_pq(pq, st, extra, cvec, self.mlp[2].weight, self.mlp[2].bias,
                                       self.mlp[4].weight.view(-1), self.mlp[4].bias, labels, pos_weight,
@@ -225,6 +239,15 @@ class AlternateGCN(nn.Module):
             raise NotImplementedError("a padded fixed-shape batch needs the fused training decoder (mlp decoder, node_dim 64)")
         out = self._decode(z, graph)
         return criterion(out, labels, pos_weight), out.detach()
+
+    def _defers(self) -> bool:
+        """training-mode `forward` hands out a DeferredLogits handle instead of launching the inference decoder: only where the
+        one-pass training decoder could resolve it, and never while a tracer / dispatch mode watches (a traced program
+        wants plain tensors: `loss_and_logits` is the traceable training entry)"""
+        fl = self.flags
+        return (self.deferred_logits and self.training and torch.is_grad_enabled() and fl.decoder == "mlp"
+                and self.fused_decoder is True and self.mlp[2].in_features == 64 and PF.DECODER_PRECISION == 1
+                and not torch.compiler.is_compiling() and not PF.observed())
 
     def _decode(self, nodes, graph):
         fl = self.flags
@@ -264,8 +287,32 @@ class AlternateGCN(nn.Module):
         return h.squeeze(-1)
 
     def forward(self, graph) -> torch.Tensor:
-        fl = self.flags
+        """logits [E] (gnn.py:121-200).  In training mode with the mlp decoder the result is a `DeferredLogits` handle: the
+        encoder and the node-level half of `mlp[0]` run here (inside accelerate's autocast wrapper of `forward`), the per-edge
+        decoder when the handle is used — as ONE pass with the loss and every gradient if that use is
+        `BCEWithLogitsLoss(pos_weight)(output, labels)` (pangnn.py:98,203), through the inference kernel on any other use."""
+        if self._defers():
+            ops, z = self._fused_decoder_operands(graph)
+            if ops is not None:
+                return self._deferred(graph, *ops)
+            return self._decode(z, graph)
         return self._decode(self.encode(graph), graph)
+
+    def _deferred(self, graph, pq, st, extra, cvec):
+        from .deferred import DeferredLogits
+        w2, b2, w3, b3 = self.mlp[2].weight, self.mlp[2].bias, self.mlp[4].weight.view(-1), self.mlp[4].bias
+        live = getattr(graph, "live_edges", None)
+
+        def materialize():
+            if live is not None:
+                raise NotImplementedError("a padded fixed-shape batch needs the fused training decoder: call "
+                                          "BCEWithLogitsLoss(pos_weight)(output, labels) on the model's output first")
+            return PF.decoder_mlp_pq(pq, st, extra, cvec, w2, b2, w3, b3)
+
+        def fused_loss(labels, pos_weight):
+            return PF.decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, labels, pos_weight, labels.shape[0], live=live)
+
+        return DeferredLogits(st.num_edges, pq.device, materialize, fused_loss)
 
     def _pairs(self, z, edge_index, graph=None):
         st = structure_of(edge_index, z.shape[0], holder=graph, name="sim")

@@ -469,8 +469,12 @@ def _dloss_bwd(ctx, go, *_unused):
     if go is None:
         return (None,) * 12
     g_pq, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
-    k = (lambda t: t) if (go is not None and _PF.is_unit_grad(go)) else (lambda t: t * go)
-    return (k(g_pq), None, None, k(g_cv) if ctx.has_cv else None, k(g_w2), k(g_b2), k(g_w3), k(g_b3), None, None, None, None)
+    if not _PF.is_unit_grad(go):
+        # loss.backward() / accelerate's (loss / 1).backward(): a device scalar that is 1 — one launch that finds that out
+        # on the device and leaves (functional.scale_by_loss_grad_)
+        g_pq, g_cv, g_w2, g_b2, g_w3, g_b3 = _PF.scale_by_loss_grad_(
+            ctx, [g_pq, g_cv if ctx.has_cv else None, g_w2, g_b2, g_w3, g_b3], go)
+    return (g_pq, None, None, g_cv if ctx.has_cv else None, g_w2, g_b2, g_w3, g_b3, None, None, None, None)
 
 
 torch.library.register_autograd("pangnn::decoder_loss", _dloss_bwd, setup_context=_dloss_setup)

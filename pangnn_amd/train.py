@@ -11,6 +11,12 @@ from . import functional as PF
 def criterion(logits, labels, pos_weight):
     """torch.nn.BCEWithLogitsLoss(pos_weight=class_balance) (pangnn.py:98) — loss and dL/dlogits from one
     HIP pass (device tensors only: there is no CPU path)"""
+    from .deferred import DeferredLogits
+    if isinstance(logits, DeferredLogits):     # training-mode model(graph): resolved by the one-pass decoder when it still can be
+        loss = logits.fused_bce(labels, pos_weight)
+        if loss is not None:
+            return loss
+        logits = logits.materialize()
     return PF.bce_with_logits(logits, labels, pos_weight)
 
 

@@ -1019,8 +1019,10 @@ def test_fused_loss_pass_equals_forward_criterion_backward(flags):
     # reference: oracle
     lo = torch.nn.functional.binary_cross_entropy_with_logits(oracle(g), g.y, pos_weight=pw)
     lo.backward()
-    # unfused HIP path
+    # unfused HIP path (deferred_logits off: forward() really launches the inference decoder, criterion the loss kernel)
+    model.deferred_logits = False
     out = model(gd)
+    assert type(out) is torch.Tensor
     lu = criterion(out, gd.y, pw.to(dev()))
     lu.backward()
     gu = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
@@ -1080,7 +1082,7 @@ def test_full_size_config4_invariants():
     l, r = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
     assert abs(l - r) <= 1e-6 * max(abs(l), abs(r), 1.0)
     torch.manual_seed(0)
-    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128])
+    model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], deferred_logits=False)
     out = model(g)
     lu = criterion(out, g.y, g.class_balance)
     lu.backward()
@@ -2082,7 +2084,8 @@ def test_full_size_config5_slice_invariants():
     assert abs(l - r) <= 1e-6 * max(abs(l), abs(r), 1.0)
     del x, y, ax, aty
     torch.manual_seed(0)
-    model = pangnn_amd.AlternateGCN(dev(), None, True, dims=[64, 128], num_nodes=n, skip_connections=True)
+    model = pangnn_amd.AlternateGCN(dev(), None, True, dims=[64, 128], num_nodes=n, skip_connections=True,
+                                    deferred_logits=False)
     g.x = torch.arange(n, device=dev())
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = model(g)

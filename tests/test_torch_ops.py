@@ -264,7 +264,9 @@ def _model_and_graph(case, dev):
     if kw.get("union_edge_weights"):
         g.edge_attr = g.union_edge_attr       # dataset.py:380: Data(x, ei, union_edge_weights, y)
     torch.manual_seed(0)
-    model = pangnn_amd.AlternateGCN(dev, None, False, dims=dims, fuse_embedding=fuse, fuse_first_dense=first_dense, **kw)
+    # deferred_logits off: `via_forward` means forward() launching the inference decoder op and criterion the loss op
+    model = pangnn_amd.AlternateGCN(dev, None, False, dims=dims, fuse_embedding=fuse, fuse_first_dense=first_dense,
+                                    deferred_logits=False, **kw)
     pw = (g.y == 0).sum() / g.y.sum()
     return model, g, pw, autocast, via_forward
 
