@@ -270,6 +270,108 @@ def cfg5slice_sibling(dev, steps, seed=0):
             "final_loss": float(loss.item())}
 
 
+def reference_loop_sibling(dev, graph, labels, class_balance, d, h, e_sim, steps, deferred=True):
+    """The reference's own loop, call for call, under a real accelerate.Accelerator on the headline graph
+    (/root/reference/pangnn.py:25 Accelerator, :87-98 model / torch Adam / torch BCEWithLogitsLoss(pos_weight = host scalar),
+    :122 prepare, :190-216 model.train(); zero_grad(); output = model(batch); loss = criterion(output, labels);
+    accelerator.backward(loss); optimizer.step()) — what a maintainer runs after INTEGRATION.md §1's import swap.
+    `deferred=True` (the default of the package): model(batch) returns a DeferredLogits handle that torch's criterion resolves
+    through the one-pass training decoder; False: round 4's literal route (inference decoder in forward, loss kernel, S with
+    the given dL/dlogits + T in backward).  Also timed: the same steps followed by the loop's per-batch reporting lines
+    (:218-222 loss.item() — a host sync —, sigmoid(output.detach()), threshold, confusion-matrix update)."""
+    import pangnn_amd
+    from accelerate import Accelerator
+    from accelerate.state import AcceleratorState
+    from pangnn_amd import functional as PF
+    from pangnn_amd.metrics import BinaryConfusionMatrix
+    AcceleratorState._reset_state(True)
+    accelerator = Accelerator(mixed_precision="no")                                               # pangnn.py:25
+    torch.manual_seed(0)
+    model = pangnn_amd.AlternateGCN(device=accelerator.device, dataset=None, categorical_nodes=False, dims=[d, h],
+                                    deferred_logits=deferred)                                     # pangnn.py:87
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.001)                                    # pangnn.py:88
+    criterion = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(float(class_balance)))         # pangnn.py:98
+    model, optimizer = accelerator.prepare(model, optimizer)                                      # pangnn.py:122
+    conf = BinaryConfusionMatrix(0.5, device=dev)
+    batch = graph
+
+    def step(report):
+        model.train()                                                                             # pangnn.py:190
+        optimizer.zero_grad()                                                                     # pangnn.py:194
+        output = model(batch)                                                                     # pangnn.py:200
+        loss = criterion(output, labels)                                                          # pangnn.py:203
+        accelerator.backward(loss)                                                                # pangnn.py:207
+        optimizer.step()                                                                          # pangnn.py:216
+        if report:
+            loss.item()                                                                           # pangnn.py:218
+            probabilities = torch.sigmoid(output.detach())                                        # pangnn.py:220
+            conf.update((probabilities >= 0.5).int(), labels)                                     # pangnn.py:221-222
+        return loss, output
+
+    for _ in range(3):
+        step(True)
+    torch.cuda.synchronize()
+    old, PF.KERNEL_TIMER = PF.KERNEL_TIMER, {"dec.fwd": [], "dec.bwd": [], "dec.dgrad": []}
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, output = step(False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tm = PF.KERNEL_TIMER
+    finally:
+        PF.KERNEL_TIMER = old
+    route = getattr(output, "route", "plain tensor")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    dt_rep = time.perf_counter() - t0
+    per_step = lambda tag: (sum(a.elapsed_time(b) for a, b in tm[tag]) / steps) if tm.get(tag) else 0.0    # noqa: E731
+    AcceleratorState._reset_state(True)
+    ms = dt / steps * 1e3
+    return {"what": "pangnn.py:190-216 literally under accelerate.Accelerator(mixed_precision='no'): model.train(); "
+                    "optimizer.zero_grad(); output = model(batch); loss = torch.nn.BCEWithLogitsLoss(pos_weight)(output, labels); "
+                    "accelerator.backward(loss); optimizer.step() with torch.optim.Adam, same graph as the headline" +
+                    ("" if deferred else "; deferred_logits=False: forward launches the inference decoder, backward S + T"),
+            "steps": steps, "ms_per_step": ms, "value": e_sim * steps / dt, "unit": "edges/s",
+            "output_type": type(output).__name__, "route": route,
+            "decoder_fwd_ms_per_step": per_step("dec.fwd"), "decoder_S_ms_per_step": per_step("dec.bwd"),
+            "decoder_T_ms_per_step": per_step("dec.dgrad"),
+            "decoder_share_of_step": (per_step("dec.fwd") + per_step("dec.bwd") + per_step("dec.dgrad")) / ms,
+            "with_reporting_ms_per_step": dt_rep / steps * 1e3,
+            "with_reporting_what": "the same steps each followed by pangnn.py:218-222: loss.item() (host sync), "
+                                   "torch.sigmoid(output.detach()), (p >= 0.5).int(), confusion-matrix update on the device",
+            "final_loss": float(loss.item())}
+
+
+def eval_sibling(dev, model, graph, labels, pos_weight, e_sim, passes=3):
+    """the validation pass of pangnn.py:241-289 / predict.py:34 on the headline graph: no_grad forward (inference decoder
+    kernel), loss, confusion counts, ROC-AUC and PR-AUC accumulated on the device (pangnn_amd.train.evaluate)"""
+    from pangnn_amd.train import evaluate
+    evaluate(model, [graph], pos_weight)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        res = evaluate(model, [graph], pos_weight)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    with torch.no_grad():
+        model.eval()
+        model(graph)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(passes):
+            model(graph)
+        torch.cuda.synchronize()
+        dt_fwd = time.perf_counter() - t1
+        model.train()
+    return {"what": "validation pass over the whole graph (pangnn.py:241-289): no_grad forward + loss + confusion counts + ROC-AUC + "
+                    "PR-AUC, all on the device, one read-out at the end", "passes": passes, "ms_per_pass": dt / passes * 1e3,
+            "value": e_sim * passes / dt, "unit": "edges/s", "forward_only_ms": dt_fwd / passes * 1e3,
+            "roc_auc": res["roc_auc"], "pr_auc": res["pr_auc"], "loss": res["loss"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +387,7 @@ def main():
                          "(cfg5slice, mini-batch regimes): what the counter passes of tools/pmc_traffic.sh want")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sibling timings (general-feature step, strict fp32, cfg5slice, mini-batch regimes)")
+    ap.add_argument("--reference-loop", action="store_true", help="time the reference_loop / eval siblings with --genes too")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -509,6 +612,20 @@ def main():
         finally:                                                  # whatever happened, the process is back in the mode
             PF.DECODER_PRECISION = old_mode                       # the emitted line describes
             PF.KERNEL_TIMER = None
+        # (ii-b) the reference's own loop under accelerate on the same graph (deferred logits = the package default, and
+        # round 4's literal route beside it), and the validation pass
+        if not args.genes or args.reference_loop:
+            n_ref = max(args.steps, 10)
+            for key, fn in (("reference_loop", lambda: reference_loop_sibling(dev, graph, labels, pos_weight, d, h, e_sim, n_ref)),
+                            ("reference_loop_literal", lambda: reference_loop_sibling(dev, graph, labels, pos_weight, d, h, e_sim,
+                                                                                      n_ref, deferred=False)),
+                            ("eval", lambda: eval_sibling(dev, model, graph, labels, pos_weight, e_sim))):
+                try:
+                    extra[key] = fn()
+                except Exception as ex:
+                    extra[key] = {"error": repr(ex)}
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
         # (iii) the other regimes of the path, timed in this process after the headline (each builds its own data):
         # config 5's per-GPU slice, and the reference's mini-batch regime replayed / with a fresh Batch per step
         if args.workload == "cfg4" and not args.genes and not args.no_siblings:
@@ -651,7 +768,8 @@ def main():
                            "once per graph (r = A_hat x, s = A_hat 1: conv_in(embedding(x)) = r a^T + s c^T + b_in by linearity, "
                            "functional._EmbedConvIn); timed here on the layer-by-layer model, outside the headline",
                 "bwd_avg_launch_ms": extra.get("bwd_avg_launch_ms", (_avg("sim.bwd") or 0) * 1e3 or None)}
-        for k_ in ("general_features", "strict_fp32", "cfg5slice", "cfg2mb", "cfg2mb_fresh", "extras_error"):
+        for k_ in ("reference_loop", "reference_loop_literal", "eval", "general_features", "strict_fp32", "cfg5slice", "cfg2mb",
+                   "cfg2mb_fresh", "extras_error"):
             if k_ in extra:
                 line[k_] = extra[k_]
         if not args.no_cpu_baseline and world == 1:
