@@ -97,12 +97,28 @@ TRAFFIC_KERNELS = {"decoder_train": "decoder_train16_kernel", "decoder_dgrad": "
                    "spmm_fwd": "spmm_row_kernel<64, 4, false, false>"}
 
 
+# the sources the three counted kernels are compiled from: profiles/traffic.json carries their hash at collection time
+TRAFFIC_SOURCES = ("decoder16.hip", "spmm.hip", "common.h")
+
+
+def kernel_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, "pangnn_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_entry(prof, key, workload, world, e_sim):
     """the profiles/traffic.json entry of kernel `key` IF it was collected on this workload, GPU count, edge count and
-    kernel name — otherwise None (the line then carries "traffic": null instead of a stale figure)"""
+    kernel name AND from the kernel sources this tree holds (tools/update_traffic.py stamps their hash) — otherwise None
+    (the line then carries "traffic": null instead of a stale figure)"""
+    sha = kernel_source_sha16()
     for ent in prof.get("entries", []):
         if ent.get("key") == key and ent.get("workload") == workload and ent.get("n_gpus") == world \
-                and ent.get("sim_edges") == e_sim and TRAFFIC_KERNELS[key] in ent.get("kernel", ""):
+                and ent.get("sim_edges") == e_sim and TRAFFIC_KERNELS[key] in ent.get("kernel", "") \
+                and ent.get("kernel_source_sha16") == sha:
             return ent
     return None
 
@@ -713,17 +729,22 @@ def main():
             b_dec = e_local * 556.0 + n_parts_s * 256.0
             ent = traffic_entry(prof, "decoder_train", args.workload, world, e_sim)
             line["roofline"] = {
-                "bound": "issue", "kernel": "decoder_train16_kernel<fused loss, run sums> (largest kernel of the step)",
-                "bound_note": "what binds is vector-instruction issue (what_binds); achieved / peak / frac stay the prescribed "
-                              "byte figures against the 8 TB/s HBM roof, the nearer of the kernel's two hardware roofs",
+                "bound": "hbm", "limiter": "issue",
+                "kernel": "decoder_train16_kernel<fused loss, run sums> (largest kernel of the step)",
+                "bound_note": "bound names the roof that achieved / peak / frac are priced against (8 TB/s HBM, the nearer of the "
+                              "kernel's two hardware roofs); limiter names what the counters say binds the kernel: vector-"
+                              "instruction issue plus matrix-pipe time (what_binds), neither roof",
                 "achieved": b_dec / t_dec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": b_dec / t_dec / HBM_PEAK,
                 "frac_note": "algorithmic bytes per step's worth of S launches / launch time / 8 TB/s: HBM is the nearer of the "
                              "kernel's two roofs (useful matrix flops are at mfma.useful_frac of the bf16 peak)",
                 "alg_bytes_per_launch": b_dec, "achievable_peak": 6300.0,
                 "traffic": ent["bytes_fetch_doubled"] if ent else None,
                 "traffic_note": ("rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE of " + src_note + ", same workload / "
-                                 "edge count / kernel name, not this run; L2-fabric bytes, Infinity-Cache hits included") if ent
-                else "no counter collection in profiles/traffic.json matches this workload, edge count and kernel name",
+                                 "edge count / kernel name / kernel sources (sha " + str(ent.get("kernel_source_sha16")) +
+                                 ", collected at " + str(ent.get("collected_at_head")) + "), not this run; L2-fabric bytes, "
+                                 "Infinity-Cache hits included") if ent
+                else "no counter collection in profiles/traffic.json matches this workload, edge count, kernel name and the "
+                     "hash of this tree's kernel sources",
                 "mfma": {"peak_tflops": 2500.0, "useful_tflops": flop_useful / t_dec / 1e12,
                          "useful_frac": flop_useful / t_dec / 1e12 / 2500.0,
                          "issued_tflops": flop_issued / t_dec / 1e12, "issued_mfma_frac": flop_issued / t_dec / 1e12 / 2500.0,
@@ -736,7 +757,8 @@ def main():
             b_dg = e_local * 28.0 + n_parts_d * 256.0        # perm 4 + key 4 + record 20 per edge, part rows written
             ent = traffic_entry(prof, "decoder_dgrad", args.workload, world, e_sim)
             line["roofline_dgrad"] = {
-                "bound": "issue", "kernel": "decoder_dgrad16_kernel (dL/dh1 run sums by target from the per-edge records)",
+                "bound": "hbm", "limiter": "issue",
+                "kernel": "decoder_dgrad16_kernel (dL/dh1 run sums by target from the per-edge records)",
                 "launches_per_step": n_dgr, "avg_launch_ms": t_dgr * 1e3, "alg_bytes_per_launch": b_dg,
                 "achieved": b_dg / t_dgr / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": b_dg / t_dgr / HBM_PEAK,
                 "mfma_tflops": 24 * 16384.0 / 16.0 * e_local / t_dgr / 1e12,

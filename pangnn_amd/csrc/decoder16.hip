@@ -1375,6 +1375,8 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
   PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16", who);
   PG_CHECK_ARG(D == D16, PANGNN_E_BADARG, "%s: built for node_dim 64, got %d", who, (int)D);
   PG_CHECK_ARG(num_edges >= 0 && ld >= num_edges && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
+  // the records this pass writes are read back by pangnn_decoder_dgrad_f32 through int32 edge ids
+  PG_CHECK_ARG(num_edges < 2147483647LL, PANGNN_E_TOOLARGE, "%s: num_edges must fit int32 (partition the graph first)", who);
   PG_CHECK_ARG(ldp >= D16 && ldq >= D16 && ldp % (pq16 ? 8 : 4) == 0 && ldq % (pq16 ? 8 : 4) == 0, PANGNN_E_BADARG,
                "%s: ldp / ldq must be multiples of 4 (f32) / 8 (bf16) and >= 64", who);
   PG_CHECK_ARG((double)num_nodes * (double)(ldp > ldq ? ldp : ldq) * (pq16 ? 2.0 : 4.0) < 4294967296.0, PANGNN_E_TOOLARGE,
@@ -1458,6 +1460,8 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
                                         pangnn_stream_t stream) {
   const char* who = "pangnn_decoder_dgrad_f32";
   PG_CHECK_ARG(num_edges >= 0, PANGNN_E_BADARG, "%s: bad size", who);
+  // edge ids are int32 in perm and 32-bit in the kernel's record addressing ((e << 1) << 4 with a 32-bit e << 1)
+  PG_CHECK_ARG(num_edges < 2147483647LL, PANGNN_E_TOOLARGE, "%s: num_edges must fit int32 (partition the graph first)", who);
   hipStream_t s = (hipStream_t)stream;
   if (num_edges == 0) {
     if (g_b2) {

@@ -755,9 +755,9 @@ extern "C" int pangnn_bce_logits_f32(const float* logits, const float* y, const 
                                      int64_t denom, float* loss, float* g_logits, void* workspace,
                                      size_t workspace_bytes, pangnn_stream_t stream) {
   PG_CHECK_ARG(n >= 0 && denom > 0, PANGNN_E_BADARG, "pangnn_bce_logits_f32: bad size");
-  PG_CHECK_ARG(loss && workspace && workspace_bytes >= kBceBlocks * sizeof(float) &&
-                   (n == 0 || (logits && y && g_logits)),
-               PANGNN_E_BADARG, "pangnn_bce_logits_f32: null pointer / workspace");
+  PG_CHECK_ARG(loss && (n == 0 || (logits && y && g_logits)), PANGNN_E_BADARG, "pangnn_bce_logits_f32: null pointer");
+  PG_CHECK_ARG(workspace && workspace_bytes >= kBceBlocks * sizeof(float), PANGNN_E_WORKSPACE,
+               "pangnn_bce_logits_f32: workspace too small (%zu < %zu)", workspace_bytes, (size_t)(kBceBlocks * sizeof(float)));
   hipStream_t s = (hipStream_t)stream;
   int blocks = (int)((n + kBlock - 1) / kBlock);
   if (blocks > kBceBlocks) blocks = kBceBlocks;
@@ -828,9 +828,10 @@ extern "C" int pangnn_weighted_colsum_f32(const float* g, int64_t ldg, const flo
                                           pangnn_stream_t stream) {
   PG_CHECK_ARG(n >= 0 && F > 0 && F <= kBlock && kBlock % F == 0 && ldg >= F, PANGNN_E_BADARG,
                "pangnn_weighted_colsum_f32: F must divide 256 (got %d)", (int)F);
-  PG_CHECK_ARG(out && workspace && workspace_bytes >= (size_t)kColsumBlocks * 2 * F * sizeof(float) &&
-                   (n == 0 || (g && r && s)),
-               PANGNN_E_BADARG, "pangnn_weighted_colsum_f32: null pointer / workspace");
+  PG_CHECK_ARG(out && (n == 0 || (g && r && s)), PANGNN_E_BADARG, "pangnn_weighted_colsum_f32: null pointer");
+  PG_CHECK_ARG(workspace && workspace_bytes >= (size_t)kColsumBlocks * 2 * F * sizeof(float), PANGNN_E_WORKSPACE,
+               "pangnn_weighted_colsum_f32: workspace too small (%zu < %zu)", workspace_bytes,
+               (size_t)kColsumBlocks * 2 * F * sizeof(float));
   hipStream_t st = (hipStream_t)stream;
   const int groups = kBlock / F;            // rows per block pass of the scalar form; the float4 form takes 4x
   int blocks = (int)((n + 4 * groups - 1) / (4 * groups));
@@ -912,8 +913,9 @@ extern "C" int pangnn_weighted_colsum3(const void* g, int32_t g_dtype, int64_t l
                PANGNN_E_BADARG, "%s: F must be a multiple of 4 dividing 1024, at most 256; ldg >= F and a multiple of 4 (got %d)", who, (int)F);
   PG_CHECK_ARG(g_dtype == PANGNN_DTYPE_F32 || g_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
                "%s: g_dtype is PANGNN_DTYPE_F32 / _BF16", who);
-  PG_CHECK_ARG(out && workspace && workspace_bytes >= pangnn_weighted_colsum3_workspace_bytes(F) && (n == 0 || (g && r && s)),
-               PANGNN_E_BADARG, "%s: null pointer / workspace", who);
+  PG_CHECK_ARG(out && (n == 0 || (g && r && s)), PANGNN_E_BADARG, "%s: null pointer", who);
+  PG_CHECK_ARG(workspace && workspace_bytes >= pangnn_weighted_colsum3_workspace_bytes(F), PANGNN_E_WORKSPACE,
+               "%s: workspace too small (%zu < %zu)", who, workspace_bytes, pangnn_weighted_colsum3_workspace_bytes(F));
   PG_CHECK_ARG(n == 0 || (g_dtype == PANGNN_DTYPE_F32 ? aligned16(g) : (reinterpret_cast<uintptr_t>(g) & 7u) == 0),
                PANGNN_E_ALIGN, "%s: g rows must be 16-byte (bf16: 8-byte) aligned", who);
   hipStream_t st = (hipStream_t)stream;

@@ -135,6 +135,9 @@ def _all_to_all_v(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_spli
             w.wait()
 
 
+_FORCED_LOGGED = False
+
+
 def force_exchange() -> bool:
     """PANGNN_FORCE_EXCHANGE=1: test hook that makes a ONE-rank run exchange rows with itself (HaloPlan.__init__)"""
     return os.environ.get("PANGNN_FORCE_EXCHANGE") == "1"
@@ -158,6 +161,13 @@ class HaloPlan:
         # back end (RCCL on a one-GPU box) and can be compared with the single-GPU model.  Sources are then read from
         # the halo COPIES of those rows, their gradients return through the back-exchange like any boundary row's.
         q = n_local // 4 if (world == 1 and force_exchange()) else 0
+        if q:
+            global _FORCED_LOGGED
+            if not _FORCED_LOGGED:
+                _FORCED_LOGGED = True
+                import warnings
+                warnings.warn("pangnn_amd.dist: PANGNN_FORCE_EXCHANGE=1 — this ONE-rank run treats the outer quarters of its node "
+                              "range as remote rows and exchanges them with itself (a test hook; unset it for real runs)")
         lo_own, hi_own = lo + q, hi - q                                    # sources in [lo_own, hi_own) are read in place
         remote = (src < lo_own) | (src >= hi_own)
         need = torch.unique(src[remote])                                   # sorted global ids
@@ -197,7 +207,7 @@ class HaloPlan:
         # behind — and hang a back end that implements all-to-all as a true collective): both flags are global.
         flag = torch.tensor([[0 if sorted_here else 1]], dtype=torch.int64, device=dev)
         self.sorted_by_src = int(_all_gather_rows(flag, group).sum()) == 0      # MIN over ranks of "sorted here"
-        self.any_exchange = bool(int(all_counts.sum()) > 0)                      # anyone needs any row of anyone
+        self.any_exchange = any(c > 0 for row in counts_host for c in row)      # anyone needs any row of anyone (host copy: no second read-back)
         self.e_lo = int((new_src < self.n_low).sum())
         self.e_hi = int((new_src < self.n_low + n_local).sum())
         self._split_cache = {}

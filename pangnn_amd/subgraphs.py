@@ -209,8 +209,14 @@ class SubGraphDataset:
             ei, nb = gr.edge_index, gr.neighbour_edge_index
             if ei.dim() != 2 or ei.shape[0] != 2 or nb.dim() != 2 or nb.shape[0] != 2:
                 raise ValueError(f"sub-graph {i}: edge_index / neighbour_edge_index must be [2, E]")
-            if gr.edge_attr.shape[0] < ei.shape[1] or gr.y.shape[0] != ei.shape[1]:
-                raise ValueError(f"sub-graph {i}: edge_attr / y do not match edge_index")
+            if hasattr(gr, "union_edge_index") and not hasattr(gr, "neighbour_edge_index"):
+                raise ValueError(f"sub-graph {i} is a --union_edge_weights sub-graph (src/dataset.py:286-299: union_edge_index, "
+                                 f"edge_attr = [1 per neighbour edge | similarity weights]); the flat data set holds the default "
+                                 f"layout (edge_index + neighbour_edge_index, one weight per similarity edge)")
+            if gr.edge_attr.shape[0] != ei.shape[1] or gr.y.shape[0] != ei.shape[1]:
+                # (a longer edge_attr is the union layout, whose similarity weights are the LAST e entries: never slice it)
+                raise ValueError(f"sub-graph {i}: edge_attr has {gr.edge_attr.shape[0]} and y {gr.y.shape[0]} entries for "
+                                 f"{ei.shape[1]} similarity edges")
             for name, t in (("edge_index", ei), ("neighbour_edge_index", nb)):
                 if t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
                     raise ValueError(f"sub-graph {i}: {name} holds ids outside [0, {n})")
@@ -225,7 +231,7 @@ class SubGraphDataset:
         nb_off = offsets([int(gr.neighbour_edge_index.shape[1]) for gr in graphs])
         ei = torch.cat([gr.edge_index.to("cpu", torch.int64) + int(node_off[i]) for i, gr in enumerate(graphs)], dim=1)
         nb = torch.cat([gr.neighbour_edge_index.to("cpu", torch.int64) + int(node_off[i]) for i, gr in enumerate(graphs)], dim=1)
-        w = torch.cat([gr.edge_attr[: gr.edge_index.shape[1]].to("cpu", torch.float32) for gr in graphs])
+        w = torch.cat([gr.edge_attr.to("cpu", torch.float32) for gr in graphs])
         y = torch.cat([gr.y.to("cpu", torch.float32) for gr in graphs])
         dev = torch.device(device)
         return cls(num_graphs=len(graphs), node_off=node_off.to(dev), edge_off=edge_off.to(dev), nb_off=nb_off.to(dev),
@@ -344,7 +350,11 @@ class SubGraphDataset:
         """the fixed buffers of a padded batch + the device list of sub-graph ids it is collated from.  `orders`: also the
         buffers of both CSR orders (and the decoder's run-sum plans) of both edge lists, written by the collation itself —
         no per-batch sort (`structure_index`); False, or shapes beyond the small-structure limits: built per batch by
-        graph.EdgeStructure as for any other batch."""
+        graph.EdgeStructure as for any other batch.
+        Layout facts a consumer of the PyG-like fields needs: `ptr` has spec[0] + 1 entries (entries past the real graphs
+        repeat the real node count); `batch` gives a PADDED node the id of a dedicated padding segment — the number of real
+        graphs of the current batch, which for a full batch equals spec[0] — so per-graph pooling over `batch` must be sized
+        `num_graphs` = spec[0] + 1 (what this buffer reports), and its last used row is the padding's."""
         g, n, e, b = spec
         dev = self.edge_index.device
         i64 = torch.empty(2 * e + 2 * b + (g + 1) + n + 8 + g + 16, dtype=torch.int64, device=dev)
@@ -364,7 +374,7 @@ class SubGraphDataset:
         hints = {"sim": {"valid_ids": True, "sorted_by_src": self._host().sorted_by_src, "band_width": 0},
                  "nb": {"valid_ids": True, "band_width": 0}}
         buf = SimpleNamespace(_pangnn_hints=hints, x=x, edge_index=ei, edge_attr=w, y=y, neighbour_edge_index=nb, ptr=ptr,
-                              batch=bid, live=live, live_edges=live[:1], graph_ids=ids, spec=tuple(spec), num_graphs=g,
+                              batch=bid, live=live, live_edges=live[:1], graph_ids=ids, spec=tuple(spec), num_graphs=g + 1,
                               orders=None)
         from . import _lib
         lib = _lib.load()

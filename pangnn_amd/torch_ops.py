@@ -23,7 +23,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-TLIB_PATH = os.path.join(_HERE, "libpangnn_torch.so")
+TLIB_PATH = os.environ.get("PANGNN_TORCH_LIB") or os.path.join(_HERE, "libpangnn_torch.so")   # override: the host-sanitizer build
 
 if not os.path.exists(TLIB_PATH):
     raise ImportError(f"pangnn_amd: {TLIB_PATH} is missing — build it with `make -C pangnn_amd/csrc` "

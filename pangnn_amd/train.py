@@ -217,7 +217,8 @@ class ReplayedFreshStep:
 
     def __call__(self, graph_ids):
         """train on the disjoint union of the sub-graphs `graph_ids` (host ints, any order, at most batch_size);
-        returns (loss, logits of the batch's real edges) as device tensors without synchronising"""
+        returns (loss, logits of the batch's real edges) as device tensors without synchronising.  With capture the two
+        are VIEWS of the captured graph's static outputs: the next call overwrites them — clone what must outlive it."""
         spec = self.spec if self.ds.fits(self.spec, graph_ids) else self.spec_worst
         buf, graph, loss, logits = self._slot(spec)
         edges = self.ds.set_graph_ids(buf, graph_ids)[1]

@@ -56,7 +56,7 @@ def test_bench_single_gpu_line_carries_roofline_step_bytes_and_cpu_baseline():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
         assert k in r, k
     # `bound` names what binds the kernel (vector-instruction issue); achieved / peak / frac stay the byte figures
-    assert r["bound"] == "issue" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "hbm" and r["limiter"] == "issue" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     gf = d["general_features"]                        # the same step with the * propagate and its transpose inside it
     assert gf["ms_per_step"] > 0 and gf["propagate_fwd_ms"] > 0 and gf["propagate_bwd_ms"] > 0
     assert 0 < gf["propagate_share_of_step"] < 1 and abs(gf["final_loss"] - d["config"]["final_loss"]) < 0.5

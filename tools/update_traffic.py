@@ -6,7 +6,9 @@ for 16-byte-per-lane streaming reads only: for the dgrad kernel's random 32-byte
 
 Every entry records what it was measured on — full kernel name, workload, GPU count, similarity-edge count of the
 profiled run (read from the bench line that run printed) — and bench.py only quotes an entry whose four match its own
-run (`"traffic": null` otherwise).  usage: python tools/update_traffic.py <out_dir> <tag> [workload]"""
+run (`"traffic": null` otherwise) and whose `kernel_source_sha16` (hash of csrc/decoder16.hip, spmm.hip, common.h at
+collection time; `collected_at_head` = $PANGNN_HEAD, the commit the collecting call was made from) equals the hash of the
+running tree's sources.  usage: PANGNN_HEAD=$(git rev-parse --short HEAD) python tools/update_traffic.py <out_dir> <tag> [workload]"""
 import collections
 import csv
 import json
@@ -17,7 +19,7 @@ out, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "cfg4"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
-from bench import TRAFFIC_KERNELS  # noqa: E402  (one table of kernel-name substrings for the collector and the reader)
+from bench import TRAFFIC_KERNELS, kernel_source_sha16  # noqa: E402  (one table of kernel-name substrings / one source hash for the collector and the reader)
 
 
 def bench_line(path):
@@ -66,7 +68,9 @@ for short, v in acc.items():
     ent = {"key": short, "kernel": names[short], "workload": workload, "n_gpus": n_gpus, "sim_edges": e_sim,
            "launches_averaged": len(v["fetch_size"]), "fetch_kib_raw": fetch, "write_kib": write,
            "bytes_fetch_doubled": int((2 * fetch + write) * 1024), "bytes_fetch_raw": int((fetch + write) * 1024),
-           "source": d["_source"]}
+           "source": d["_source"],
+           # what the counters were collected ON: bench.py prints "traffic": null once the kernel sources differ
+           "kernel_source_sha16": kernel_source_sha16(), "collected_at_head": os.environ.get("PANGNN_HEAD", "unknown")}
     d["entries"].append(ent)
     print(short, "fetch KiB (raw)", fetch, "write KiB", write, "=> bytes", ent["bytes_fetch_doubled"], "E =", e_sim)
 json.dump(d, open(path, "w"), indent=1)
