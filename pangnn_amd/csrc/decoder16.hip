@@ -194,6 +194,24 @@ __device__ unsigned long long* d16_stamps = nullptr;     // wave 0 of workgroup 
 #else
 #define D16_STAMP(i) ((void)0)
 #endif
+#ifdef PANGNN_D16_CYC                     // diagnostic builds only (tools/probe_decoder_cycles.py): where the S kernel's waves spend their
+// cycles AT FULL SIZE: every wave adds the shader-clock cycles (s_memtime) between consecutive marks of its loop body into
+// per-phase sums over all of its half tiles — scalar registers, no waits of its own beyond the counter read's lgkmcnt — and
+// the eight waves of workgroup 0 write theirs out at the end: d16_cyc[wave][0 .. 5] = cycles in phase 0 .. 5, [6] = half tiles,
+// [7] = cycles from kernel entry to loop exit.
+__device__ unsigned long long* d16_cyc = nullptr;
+#define D16_CYC_DECL unsigned long long cyc_acc[6] = {0, 0, 0, 0, 0, 0}, cyc_halves = 0; \
+  const unsigned long long cyc_t0 = __builtin_readcyclecounter(); unsigned long long cyc_last = cyc_t0
+#define D16_CYC(i)                                                  \
+  do {                                                              \
+    const unsigned long long t__ = __builtin_readcyclecounter();    \
+    cyc_acc[i] += t__ - cyc_last;                                   \
+    cyc_last = t__;                                                 \
+  } while (0)
+#else
+#define D16_CYC_DECL ((void)0)
+#define D16_CYC(i) ((void)0)
+#endif
 
 struct D16Params {
   const void* p; const void* q; uint32_t ldp_b; uint32_t ldq_b;     // row strides in bytes; rows are f32 or bf16 (PQ16)
@@ -715,6 +733,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
   float carry = 0.f;
   int64_t pidx = 0;
   D16_STAMP(3);
+  D16_CYC_DECL;
 
   while (tile < n_tiles) {
     // chunk bookkeeping as selects (no branch in the loop body): a chunk's first tile starts from its part offset with
@@ -733,6 +752,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
 #pragma unroll 1
     for (int hx = 0; hx < 2; ++hx) {
       // ids of the next half tile (this tile's second half, or the first half of the wave's next tile)
+      D16_CYC(5);                          // phase 5: loop / chunk bookkeeping between half tiles
       const HalfIn in_nxt = load_half<EXTRA>(a, auxp, hx == 0 ? tile : tile_nxt, n_tiles, hx ^ 1, c);    // one load site
       const int pos = 16 * hx + c;
       const bool live = pos <= live_lim;
@@ -745,8 +765,10 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       f32x4 acc[4];
       uint32_t m1 = 0;                     // relu mask bits of h1 (packed inside the first product, off its split terms)
       D16_STAMP(4 + 4 * hx);
+      D16_CYC(0);                          // phase 0: next ids requested, the gathered rows of THIS half awaited, h1 = relu(p + q)
       const float xv = p1_logit<false, true>(lds, h, wfrag0, wfrag1, g, b3v, acc, one2, &m1);
       D16_STAMP(5 + 4 * hx);
+      D16_CYC(1);                          // phase 1: P1 (splits, 48 matrix instructions, relu, w3 dot, lane sums)
       // the rows of the next half tile fly during the epilogue and the other two products
       issue_half_rows(a, in_nxt, g, rows);
 
@@ -861,6 +883,7 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
       D16_SETPRIO(0);
 
       D16_STAMP(6 + 4 * hx);
+      D16_CYC(2);                          // phase 2: row requests of the next half, loss, m2 operands, g_e h1 splits, P3, records
       // ---- P2 + run sums by source
       if (RUNSUM || has_extra) {
         f32x4 v[4], gm[4];
@@ -900,14 +923,27 @@ __global__ __launch_bounds__(S_WAVES * 64) void decoder_train16_kernel(
           run_sums(v, gm, m16, carry, rs.part, pidx, wv, lane, c, g, colp);
         }
       }
+      D16_CYC(3);                          // phase 3: P2 (24 matrix instructions), mask factors, run sums
       wave_sync();          // the next half tile overwrites the images / recl / gl
       D16_STAMP(7 + 4 * hx);
+      D16_CYC(4);                          // phase 4: the wave barrier that frees the tile images
+#ifdef PANGNN_D16_CYC
+      ++cyc_halves;
+#endif
       in_cur = in_nxt;
     }
     poff_cur = last_tile ? poff_nxt : poff_cur;
     tile = tile_nxt;
   }
 
+#ifdef PANGNN_D16_CYC
+  if (d16_cyc != nullptr && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d16_cyc[wave * 8 + i] = cyc_acc[i];
+    d16_cyc[wave * 8 + 6] = cyc_halves;
+    d16_cyc[wave * 8 + 7] = cyc_last - cyc_t0;
+  }
+#endif
   // ---- finish: per-lane partials -> workgroup slab.  The eight waves are added as a fixed binary tree,
   // ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)), through LDS: in round d the waves with bit d set (lower bits clear)
   // write their values, their partners d below add them — every value at its own address (value v of lane l at
@@ -1324,6 +1360,11 @@ using namespace pangnn;
 #ifdef PANGNN_D16_STAMP
 extern "C" int pangnn_debug_set_stamps(unsigned long long* ptr) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(d16_stamps), &ptr, sizeof(ptr));
+}
+#endif
+#ifdef PANGNN_D16_CYC
+extern "C" int pangnn_debug_set_cyc(unsigned long long* ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(d16_cyc), &ptr, sizeof(ptr));
 }
 #endif
 #ifdef PANGNN_D16_DEBUG

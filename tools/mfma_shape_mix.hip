@@ -5,6 +5,7 @@
 // instruction); what differs is the VALU issue time an MFMA holds (8 cycles either way: 384 vs 192 per tile).
 // Two cost models were on the table after round 4: "issue slots" (4 x VALU + 8 x MFMA: the 32x32 form saves
 // 192 of ~1 490 cycles) and "additive" (4 x VALU + matrix-pipe cycles: the shape changes nothing).  This program measures it:
+// (cycles at the NOMINAL clock from event times, and shader-clock cycles from s_memtime: the clock a mix sustains differs)
 // per iteration a burst of NM matrix instructions (operands in registers, accumulator chains as in the kernel: 8 chains of 6
 // for the 16x16 form, 2 chains of 12 for the 32x32 form) between s_setprio 1 / 0, then NV independent v_fma_f32.
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_shape_mix.hip -o /tmp/mfma_shape_mix && /tmp/mfma_shape_mix
@@ -16,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int SHAPE, int NV, bool PRIO, int IL>
-__global__ __launch_bounds__(1024) void k(float* out, int iters, float a, float b, int stagger) {
+__global__ __launch_bounds__(1024) void k(float* out, int iters, float a, float b, int stagger, unsigned long long* cyc) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
   bf16x8 A[2], B[3];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -94,17 +96,21 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float a, float 
 #pragma unroll
   for (int i = 0; i < 2; ++i) s += c32[i][0] + c32[i][15];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  // shader-clock cycles of this wave's lifetime (s_memtime): the REAL clock under this instruction mix, not the nominal one
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = __builtin_readcyclecounter() - t0;
 }
 
 template <int SHAPE, int NV, int IL>
-static double run(float* out, int cus, int waves_per_simd, int iters, bool prio, int stagger) {
+static double run(float* out, int cus, int waves_per_simd, int iters, bool prio, int stagger, double* real_cyc) {
+  static unsigned long long* cyc = nullptr;
+  if (!cyc) (void)hipMalloc(&cyc, 16 * sizeof(unsigned long long));
   const int threads = 64 * 4 * waves_per_simd;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   auto launch = [&]() {
-    if (prio) hipLaunchKernelGGL((k<SHAPE, NV, true, IL>), dim3(cus), dim3(threads), 0, 0, out, iters, 1.0001f, 0.5f, stagger);
-    else hipLaunchKernelGGL((k<SHAPE, NV, false, IL>), dim3(cus), dim3(threads), 0, 0, out, iters, 1.0001f, 0.5f, stagger);
+    if (prio) hipLaunchKernelGGL((k<SHAPE, NV, true, IL>), dim3(cus), dim3(threads), 0, 0, out, iters, 1.0001f, 0.5f, stagger, cyc);
+    else hipLaunchKernelGGL((k<SHAPE, NV, false, IL>), dim3(cus), dim3(threads), 0, 0, out, iters, 1.0001f, 0.5f, stagger, cyc);
   };
   launch();
   (void)hipDeviceSynchronize();
@@ -118,6 +124,12 @@ static double run(float* out, int cus, int waves_per_simd, int iters, bool prio,
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
+  unsigned long long h[16];
+  (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+  double sum = 0;
+  for (int w = 0; w < 4 * waves_per_simd; ++w) sum += (double)h[w];
+  // the waves of one SIMD run side by side: SIMD time per (wave, tile) = a wave's lifetime / (tiles x waves per SIMD)
+  *real_cyc = sum / (4.0 * waves_per_simd) / ((double)iters * waves_per_simd);
   return best;
 }
 
@@ -127,12 +139,13 @@ static void row(float* out, int cus, int clk_khz) {
   for (int w : {1, 2, 4})
     for (int stagger = 0; stagger <= (w > 1 ? 1 : 0); ++stagger)
       for (int prio = 1; prio >= 0; --prio) {
-        const double a = run<0, NV, IL>(out, cus, w, iters, prio, stagger), b = run<1, NV, IL>(out, cus, w, iters, prio, stagger);
+        double ra = 0, rb = 0;
+        const double a = run<0, NV, IL>(out, cus, w, iters, prio, stagger, &ra), b = run<1, NV, IL>(out, cus, w, iters, prio, stagger, &rb);
         // cycles of SIMD time per wave-iteration (one "tile"): kernel time x clock / (iterations x waves on the SIMD)
         const double ca = a * 1e-3 * clk_khz * 1e3 / ((double)iters * w), cb = b * 1e-3 * clk_khz * 1e3 / ((double)iters * w);
         printf("VALU %3d (%d / %d behind each MFMA)  waves/SIMD %d  stagger %d  setprio %d :  48 x 16x16x32  %7.1f cyc/tile   24 x 32x32x16  %7.1f cyc/tile   ratio "
-               "%.3f   [4 VALU + 8 MFMA: %4d / %4d;  4 VALU + pipe: %4d;  max(pipe, ...) floor: 768]\n",
-               NV, IL, 2 * IL, w, stagger, prio, ca, cb, cb / ca, 4 * NV + 8 * 48, 4 * NV + 8 * 24, 4 * NV + 768);
+               "%.3f | s_memtime cycles/tile %7.1f  %7.1f  (clock %.2f / %.2f GHz)\n",
+               NV, IL, 2 * IL, w, stagger, prio, ca, cb, cb / ca, ra, rb, ra / ca * clk_khz / 1e6, rb / cb * clk_khz / 1e6);
       }
 }
 
