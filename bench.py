@@ -404,6 +404,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sibling timings (general-feature step, strict fp32, cfg5slice, mini-batch regimes)")
     ap.add_argument("--reference-loop", action="store_true", help="time the reference_loop / eval siblings with --genes too")
+    ap.add_argument("--emulate-rank", type=int, default=None,
+                    help="ONE process stands in for rank r of an --of W rank job (compute side of the partitioned step on one GPU; "
+                         "the halo exchange is a self-exchange of the true row counts over RCCL: dist.HaloPlan._emulate)")
+    ap.add_argument("--of", type=int, default=8, help="world size the emulated rank belongs to")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -453,7 +457,10 @@ def main():
         genes = args.genes
     if args.workload in ("cfg2mb", "cfg2mb_fresh"):
         return minibatch_bench(args, dev, json_fd)
-    force_dist = os.environ.get("PANGNN_FORCE_DIST") == "1"      # exercise the partitioned path at world = 1
+    emu = args.emulate_rank is not None
+    if emu and (world != 1 or not 0 <= args.emulate_rank < args.of):
+        sys.exit("--emulate-rank r --of W runs as ONE process with 0 <= r < W")
+    force_dist = os.environ.get("PANGNN_FORCE_DIST") == "1" or emu   # exercise the partitioned path at world = 1
     if force_dist and world == 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -464,28 +471,32 @@ def main():
     mean_neg = 220 if args.workload == "cfg5slice" else None       # floor(49 / 2 * 9): config 5's law on a 6-genome slice
     model_flags = dict(skip_connections=True) if cfg5 else {}
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if cfg5 else contextlib.nullcontext()
-    if args.workload == "cfg5" and world < 8 and not args.genes:
+    if args.workload == "cfg5" and world < 8 and not args.genes and not (emu and args.of >= 8):
         sys.exit("cfg5 (4.3e9 edges) only runs partitioned over 8 GPUs; on one GPU use --workload cfg5slice")
     replicated = os.environ.get("PANGNN_BENCH_REPLICATED") == "1"    # round-1 way: every rank builds the whole graph
     # node ranges with equal expected in-edge counts (the two end genomes have one neighbour genome, the others two):
     # PANGNN_PARTITION=nodes keeps equal node ranges
     bounds = None
-    if partitioned and world > 1 and os.environ.get("PANGNN_PARTITION", "edges") == "edges":
+    gen_rank, gen_world = (args.emulate_rank, args.of) if emu else (rank, world)
+    if partitioned and gen_world > 1 and os.environ.get("PANGNN_PARTITION", "edges") == "edges":
         from pangnn_amd.dist import balanced_bounds
-        bounds = balanced_bounds(genes, G, world)
+        bounds = balanced_bounds(genes, G, gen_world)
     t_gen = time.perf_counter()
     g = None
     if partitioned and not replicated:
         # rank-local generation: a rank draws only the genome pairs around its node range (simulate.simulate_shard,
         # bit-identical to partitioning the whole graph: tests/test_construct.py) — what lets config 5 exist at all
-        part = simulate.simulate_shard(genes, G, frac, frags, shuf, seed=args.seed, device=dev, rank=rank, world=world,
+        part = simulate.simulate_shard(genes, G, frac, frags, shuf, seed=args.seed, device=dev, rank=gen_rank, world=gen_world,
                                        mean_neg=mean_neg, bounds=bounds)
+        if emu:
+            part.emulated_world = gen_world      # the halo plan of the real rank, served by a self-exchange (HaloPlan._emulate)
         cnt = torch.tensor([part.e_sim_local, part.n_pos_local, part.neighbour_edge_index.shape[1]], dtype=torch.int64,
                            device=dev)
         if world > 1:
             all_reduce_(cnt, torch.distributed.ReduceOp.SUM)
         e_sim, n_pos, e_nb = (int(v) for v in cnt.tolist())
-        part.e_sim_total = e_sim
+        part.e_sim_total = e_sim * (gen_world if emu else 1)     # an emulated rank only knows its own count: the loss
+        #                                                          denominator (a scale) is taken as W times it
         n = part.n_global
         class_balance = torch.tensor((e_sim - n_pos) / max(n_pos, 1), dtype=torch.float32, device=dev)   # dataset.py:346
     else:
@@ -559,6 +570,38 @@ def main():
     def _avg(tag, tm=None):
         ev = (tm or timer).get(tag, [])
         return (sum(a.elapsed_time(b) for a, b in ev) * 1e-3 / len(ev)) if ev else None
+
+    if emu:
+        # one line per emulated rank: the compute side of the partitioned step on ONE GPU — NOT a scaling curve
+        plans = getattr(graph, "_dist_plans", {})
+        s_ev, t_ev = timer.get("dec.bwd", []), timer.get("dec.dgrad", [])
+        per = max(len(s_ev) // max(args.steps, 1), 1)
+        s_ms = [sum(a.elapsed_time(b) for a, b in s_ev[k::per]) / max(len(s_ev[k::per]), 1) for k in range(per)]
+        rows_bytes = 2 if cfg5 else 4
+        sim = plans.get("sim")
+        line = {"emulated_rank": gen_rank, "of": gen_world, "workload": args.workload, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "nodes_local": int(graph.n_local), "sim_edges_local": int(graph.e_sim_local),
+                "neighbour_edges_local": int(graph.neighbour_edge_index.shape[1]),
+                "node_range": [int(graph.lo), int(graph.hi)], "partition": "equal expected in-edge counts" if bounds else "equal node ranges",
+                "halo_rows": {k: int(p.n_halo) for k, p in plans.items()},
+                "halo_rows_by_owner": {k: getattr(p, "peer_counts", None) for k, p in plans.items()},
+                "own_source_edges": int(sim.e_hi - sim.e_lo) if sim is not None else None,
+                "halo_source_edges": int(sim.edge_index.shape[1] - (sim.e_hi - sim.e_lo)) if sim is not None else None,
+                "per_step_exchange_bytes": {
+                    "decoder_P_halo_forward": int(sim.n_halo) * 64 * rows_bytes if sim is not None else None,
+                    "decoder_P_halo_gradient_back": int(sim.n_halo) * 64 * rows_bytes if sim is not None else None,
+                    "neighbour_graph_halos_fwd_plus_bwd": 2 * int(plans["nb"].n_halo) * 64 * 4 if "nb" in plans else None,
+                    "gradient_all_reduce": sum(p.numel() for p in model.parameters() if p.requires_grad) * 4},
+                "decoder_S_launch_ms": s_ms, "decoder_S_launch_note": "own-source edges first (the P halo travels under it), then the halo-source edges",
+                "decoder_T_ms_per_step": (sum(a.elapsed_time(b) for a, b in t_ev) / max(args.steps, 1)) if t_ev else None,
+                "xgmi_time_at_link_rate_ms": (int(sim.n_halo) * 64 * rows_bytes / 2 / 153e9 * 1e3) if sim is not None else None,
+                "xgmi_note": "the P halo comes from two neighbour ranks over two xGMI links (153 GB/s each, MI355X_MICROARCH.md): bytes / 2 / 153 GB/s",
+                "exchange_here": "self-exchange of the same row counts over RCCL on one GPU (values meaningless, launches / bytes / streams real)",
+                "graph_build_s": round(t_gen, 3), "final_loss": float(loss.item()), "dtype": "bf16 rows / f32" if cfg5 else "f32"}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
 
     t_prop, t_dec, t_dgr = _avg("sim.fwd"), _avg("dec.bwd"), _avg("dec.dgrad")
     n_dgr = len(timer.get("dec.dgrad", [])) // max(args.steps, 1)

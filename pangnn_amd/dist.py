@@ -149,12 +149,19 @@ class HaloPlan:
     global-id order, so an edge list that was sorted by source stays sorted (the decoder's per-source
     partial sums keep working on shards).  Built once per (graph, partition)."""
 
-    def __init__(self, ei_local: torch.Tensor, lo: int, n_local: int, group=None, make_csr=None, bounds=None):
-        """`bounds` [world + 1]: first node of every rank's range when the ranges are not equal (balanced_bounds)"""
+    def __init__(self, ei_local: torch.Tensor, lo: int, n_local: int, group=None, make_csr=None, bounds=None,
+                 emulated_world: Optional[int] = None):
+        """`bounds` [world + 1]: first node of every rank's range when the ranges are not equal (balanced_bounds).
+        `emulated_world` (bench.py --emulate-rank r --of W): this ONE process stands in for one rank of a W-rank job — see
+        `_emulate`."""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         dev = ei_local.device
         src = ei_local[0]
         hi = lo + n_local
+        if emulated_world is not None and emulated_world > 1:
+            if world != 1:
+                raise ValueError("an emulated rank runs as a one-process job")
+            return self._emulate(ei_local, lo, n_local, group, make_csr, bounds, int(emulated_world))
         # Test hook (PANGNN_FORCE_EXCHANGE=1, one rank only): the lower and upper quarter of the node range count as
         # "remote" rows — owned by rank 0 itself — so that every exchange of the N > 1 path (all-to-all-v with split
         # lists, the side-stream decoder exchange, the halo gradient return, the flat all-reduce) executes on the real
@@ -214,6 +221,42 @@ class HaloPlan:
         # fixed-order accumulation of returned halo gradients into the owner's rows
         self.back_csr = make_csr(self.send_idx, n_local) if (make_csr is not None and self.send_idx.numel()) else None
 
+
+    def _emulate(self, ei_local, lo, n_local, group, make_csr, bounds, emulated_world):
+        """The plan of ONE rank of an `emulated_world`-rank job, built by a one-process job (a one-GPU box: the only per-rank
+        evidence obtainable without a node).  The remote-source set is the shard's TRUE one (every source outside [lo, hi)),
+        the table layout, the re-indexed edge list, the own-source / halo-source split of the decoder and the back
+        accumulation are what the real rank would build; what cannot exist is the peers: the exchange is served by a
+        SELF-exchange of the same row counts over the process group (rows `k mod n_local` of the own block stand in for halo
+        row k, and as many rows are sent as received — the adjacent-genome halo is symmetric), so kernels, launches, bytes
+        through RCCL and stream structure are the real rank's while the VALUES of the halo rows are not.  For timing only."""
+        dev = ei_local.device
+        src = ei_local[0]
+        hi = lo + n_local
+        remote = (src < lo) | (src >= hi)
+        need = torch.unique(src[remote])
+        if bounds is None:
+            owner = torch.div(need, n_local, rounding_mode="floor")
+        else:
+            owner = torch.searchsorted(torch.as_tensor(list(bounds), dtype=torch.int64, device=dev), need, right=True) - 1
+        self.peer_counts = torch.bincount(owner, minlength=emulated_world).tolist()       # halo rows asked of every rank
+        self.emulated_world = emulated_world
+        n_halo = int(need.numel())
+        self.send_splits, self.recv_splits = [n_halo], [n_halo]
+        self.send_idx = (torch.arange(n_halo, device=dev, dtype=torch.int64) % max(n_local, 1)).contiguous()
+        self.n_local, self.n_halo = n_local, n_halo
+        self.n_table = n_local + n_halo
+        self.n_low = int((need < lo).sum())
+        pos = torch.searchsorted(need, src)
+        new_src = torch.where(remote, torch.where(src < lo, pos, pos + n_local), src - lo + self.n_low)
+        self.edge_index = torch.stack([new_src, ei_local[1]]).contiguous()
+        self.group = group
+        self.sorted_by_src = bool((new_src[1:] >= new_src[:-1]).all()) if new_src.numel() > 1 else True
+        self.any_exchange = n_halo > 0
+        self.e_lo = int((new_src < self.n_low).sum())
+        self.e_hi = int((new_src < self.n_low + n_local).sum())
+        self._split_cache = {}
+        self.back_csr = make_csr(self.send_idx, n_local) if (make_csr is not None and n_halo) else None
 
     def split_edges(self):
         """(own-source edges, halo-source edges) of the re-indexed list, each still sorted by source"""
@@ -552,7 +595,8 @@ class DistAlternateGCN(AlternateGCN):
             ei = {"sim": shard.edge_index, "nb": getattr(shard, "neighbour_edge_index", None),
                   "union": getattr(shard, "union_edge_index", None)}[name]
             cache[name] = HaloPlan(ei, shard.lo, shard.n_local, self.group,
-                                   getattr(self.ops, "make_back_csr", None), getattr(shard, "bounds", None))
+                                   getattr(self.ops, "make_back_csr", None), getattr(shard, "bounds", None),
+                                   getattr(shard, "emulated_world", None))
         return cache[name]
 
     def _st(self, shard, name):
