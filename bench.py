@@ -591,7 +591,8 @@ def main():
                     "decoder_P_halo_forward": int(sim.n_halo) * 64 * rows_bytes if sim is not None else None,
                     "decoder_P_halo_gradient_back": int(sim.n_halo) * 64 * rows_bytes if sim is not None else None,
                     "neighbour_graph_halos_fwd_plus_bwd": 2 * int(plans["nb"].n_halo) * 64 * 4 if "nb" in plans else None,
-                    "gradient_all_reduce": sum(p.numel() for p in model.parameters() if p.requires_grad) * 4},
+                    "gradient_all_reduce": sum(p.numel() for k_, p in model.named_parameters() if p.requires_grad and not
+                                               (getattr(model, "sharded_embedding", False) and k_ == "embedding.weight")) * 4},
                 "decoder_S_launch_ms": s_ms, "decoder_S_launch_note": "own-source edges first (the P halo travels under it), then the halo-source edges",
                 "decoder_T_ms_per_step": (sum(a.elapsed_time(b) for a, b in t_ev) / max(args.steps, 1)) if t_ev else None,
                 "xgmi_time_at_link_rate_ms": (int(sim.n_halo) * 64 * rows_bytes / 2 / 153e9 * 1e3) if sim is not None else None,
