@@ -623,6 +623,13 @@ class _DecoderMLP(torch.autograd.Function):
         return gp, gq, None, None, g_cv, g_w2, g_b2, g_w3, g_b3, None
 
 
+def _timed_decoder():
+    """a kernel-timer tag when bench.py asked for per-launch times of the decoder kernels (KERNEL_TIMER holds their tags): the
+    event pairs are recorded by the ctypes route (same kernels, same order), so such a call takes it — like a tagged propagate"""
+    t = KERNEL_TIMER
+    return "dec" if (t is not None and ("dec.bwd" in t or "dec.fwd" in t or "dec.dgrad" in t)) else None
+
+
 def decoder_mlp(p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
     return _DecoderMLP.apply(p, q, st, extra, cvec, w2, b2, w3, b3, False)
 
@@ -630,7 +637,7 @@ def decoder_mlp(p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
 def decoder_mlp_pq(pq, st: EdgeStructure, extra, cvec, w2, b2, w3, b3):
     """p = pq[:, :D], q = pq[:, D:] (one [N, 2D] node-level product)"""
     _lib.require_device(pq, extra, cvec, w2, b2, w3, b3)
-    if _via_ops(st) and DECODER_PRECISION == 1:
+    if _via_ops(st, _timed_decoder()) and DECODER_PRECISION == 1:
         from . import torch_ops
         return torch_ops.decoder_mlp_pq(pq, st, extra, cvec, w2, b2, w3, b3)
     return _DecoderMLP.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, True)
@@ -648,6 +655,9 @@ def unit_grad(device) -> torch.Tensor:
     t = _UNIT_GRAD.get(key)
     if t is None:
         t = _UNIT_GRAD[key] = torch.ones((), dtype=torch.float32, device=key)
+        if key.type == "cuda":             # the C++ autograd formula of pangnn::decoder_loss recognises it by address too
+            from . import torch_ops
+            torch_ops.ops._set_unit_grad(t)
     return t
 
 
@@ -789,7 +799,7 @@ def decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, l
     """`live` (device int64[1]): a padded fixed-shape batch whose first live[0] edges are real (train.ReplayedFreshStep):
     the loss is their mean and the padding contributes to no gradient"""
     _lib.require_device(pq, extra, cvec, w2, b2, w3, b3, y, pos_weight, live)
-    if _via_ops(st) and DECODER_PRECISION == 1:
+    if _via_ops(st, _timed_decoder()) and DECODER_PRECISION == 1:
         from . import torch_ops
         return torch_ops.decoder_loss_pq(pq, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, live)
     return _DecoderLoss.apply(pq, None, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, True, live)

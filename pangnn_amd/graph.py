@@ -24,6 +24,14 @@ from . import _lib
 SMALL_STRUCTURE = os.environ.get("PANGNN_SMALL_STRUCTURE", "1") != "0"
 
 
+# components of a structure as the native registry (csrc/graph_ops.cpp) names them: bits of `push_native(need)` and of
+# pangnn::_prepare_structure(..., need)
+(NEED_BY_DST, NEED_BY_SRC, NEED_BAND, NEED_RUNSUM, NEED_PLAN_DST, NEED_PLAN_SRC, NEED_NORM, NEED_NORM_SRC, NEED_ACTIONS,
+ NEED_ENTRY) = (1 << i for i in range(10))
+_STRUCT_BITS = NEED_BY_DST | NEED_BY_SRC | NEED_BAND | NEED_RUNSUM | NEED_ENTRY
+_NORM_BITS = NEED_NORM | NEED_NORM_SRC | NEED_ACTIONS
+
+
 @dataclass
 class CSR:
     rowptr: torch.Tensor   # int64 [N+1]
@@ -88,6 +96,7 @@ class EdgeStructure:
         self._runsum = None
         self._band: Optional[int] = None
         self._small_built = False
+        self._native = 0                     # NEED_* bits already pushed to the native registry (push_native)
 
     def _small_build(self) -> bool:
         """A small square structure (a mini-batch of sub-graphs): both CSR orders and the S / T kernels' chunk plans of both
@@ -236,6 +245,78 @@ class EdgeStructure:
                 self._plan_of_sorted_keys(self.edge_index[0], self.num_src, ct)
         return self._runsum[ct]
 
+    def native_has(self, need: int, norm=None, x=None) -> bool:
+        """everything `need` names is in the native registry already (as far as this object knows: the registry may have
+        evicted it, in which case the op that misses it calls pangnn::_prepare_structure, i.e. push_native(force=True))"""
+        if (self._native & need & (_STRUCT_BITS | NEED_PLAN_DST | NEED_PLAN_SRC)) != (need & (_STRUCT_BITS | NEED_PLAN_DST | NEED_PLAN_SRC)) \
+                or not (self._native & NEED_ENTRY):
+            return False
+        nb = need & _NORM_BITS
+        if not nb:
+            return True
+        if norm is None or (norm._native & nb & ~NEED_ACTIONS) != (nb & ~NEED_ACTIONS):
+            return False
+        return not (nb & NEED_ACTIONS) or (x is not None and norm._native_actions == (x.data_ptr(), x._version))
+
+    def push_native(self, need: int, edge_weight: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None,
+                    force: bool = False):
+        """Build (lazily, with the C entry points this class already uses) and push to the native structure registry
+        (csrc/graph_ops.cpp) the components `need` names — NEED_* bits — so that the per-step ops `torch.ops.pangnn.
+        {gcn_propagate, embed_conv_in[_linear], decoder_loss, decoder_mlp}` and their backward ops find them by the identity of
+        `edge_index` (/ `edge_weight` / `x`) without entering Python.  Square structures only (a partitioned shard's
+        rectangular structures take the ctypes route).  `force`: push again what this object believes is there (the
+        registry evicts least-recently-used entries)."""
+        if self.num_src != self.num_nodes:
+            raise ValueError("the native registry holds square structures (whole graphs, collated batches)")
+        from .torch_ops import ops
+        ei, n, e = self._key_tensor, self.num_nodes, self.num_edges
+        have = 0 if force else self._native
+        ct = int(_lib.load().pangnn_decoder_chunk_tiles_for(e))
+        todo = need & _STRUCT_BITS & ~have
+        if todo or not (have & NEED_ENTRY):
+            by_dst, by_src, band, srt, plan = [], [], -1, -1, None
+            if todo & NEED_BY_DST:
+                c = self.by_dst
+                by_dst = [c.rowptr, c.other, c.perm]
+            if todo & NEED_BY_SRC:
+                c = self.by_src
+                by_src = [c.rowptr, c.other, c.perm]
+            if todo & NEED_BAND:
+                band = self.band_width()
+            if todo & NEED_RUNSUM:
+                plan = self.runsum_plan(ct)
+                srt = 0 if plan is None else 1
+            ops._register_structure(ei, n, self.num_src, self.edge_index, by_dst, by_src, band, srt)
+            if plan is not None:
+                ops._register_plan(ei, n, 0, ct, plan.part_off, plan.part_rowptr, plan.keys, int(plan.n_parts))
+            have |= todo | NEED_ENTRY
+        for bit, by, kind in ((NEED_PLAN_DST, "dst", 1), (NEED_PLAN_SRC, "src", 2)):
+            if need & bit & ~have:
+                if e:
+                    plan = self.csr_plan(by, ct)
+                    ops._register_plan(ei, n, kind, ct, plan.part_off, plan.part_rowptr, plan.keys, int(plan.n_parts))
+                have |= bit
+        self._native = have
+        nb = need & _NORM_BITS
+        if nb:
+            norm = self.gcn_norm(edge_weight)
+            nh = 0 if force else norm._native
+            want_src = bool(nb & NEED_NORM_SRC)
+            if (NEED_NORM & ~nh) or (want_src and (NEED_NORM_SRC & ~nh)):
+                by_src = norm.by_src if want_src else norm._by_src
+                ops._register_norm(ei, n, norm.weight_ref, norm.deg_inv_sqrt, norm.by_dst, norm.orig, by_src)
+                nh |= NEED_NORM | (NEED_NORM_SRC if by_src is not None else 0)
+            if nb & NEED_ACTIONS:
+                if x is None:
+                    raise ValueError("NEED_ACTIONS needs the feature tensor")
+                key = (x.data_ptr(), x._version)
+                if force or norm._native_actions != key:
+                    from .functional import _node_actions
+                    r, s_ = _node_actions(x, self, norm)
+                    ops._register_actions(ei, n, norm.weight_ref, x, r, s_)
+                    norm._native_actions = key
+            norm._native = nh
+
     def gcn_norm(self, edge_weight: Optional[torch.Tensor], gather_dis=None) -> "GcnNorm":
         """norm for this edge_weight tensor (None = unit weights); cached on tensor identity.
         `gather_dis(dis_local [n_dst]) -> dis_src [n_src]` supplies the source nodes' deg^-1/2 for a
@@ -295,6 +376,8 @@ class GcnNorm:
                            "pangnn_gcn_edge_norm_f32")
         self._st = st
         self._by_src: Optional[torch.Tensor] = None
+        self._native, self._native_actions = 0, None          # what the native registry holds of this normalisation
+        self.weight_ref = None                                # the caller's tensor (set by EdgeStructure.gcn_norm)
 
     @property
     def by_src(self) -> torch.Tensor:
@@ -391,9 +474,19 @@ def register(st, key=None):
 
 
 def clear_cache():
+    for st in _CACHE.values():
+        st._native = 0
     _CACHE.clear()
+    from .torch_ops import ops
+    ops._registry_clear(torch.empty(0))
 
 
-def forget(key):
-    """drop one entry of the identity-keyed cache (a buffer whose content was rewritten in place)"""
-    _CACHE.pop(key, None)
+def forget(key, edge_index: Optional[torch.Tensor] = None):
+    """drop one entry of the identity-keyed cache (a buffer whose content was rewritten in place) — and, given the buffer,
+    its entry of the native registry (same address, same version counter, new content)"""
+    st = _CACHE.pop(key, None)
+    if st is not None:
+        st._native = 0
+    if edge_index is not None and edge_index.is_cuda:
+        from .torch_ops import ops
+        ops._registry_forget(edge_index, int(key[3]))

@@ -475,7 +475,7 @@ class SubGraphDataset:
         # by the structures over the tables this collation wrote, or drop it (built on first use as for any batch)
         from .graph import forget, structure_key
         for ei in (buf.edge_index, buf.neighbour_edge_index):        # only THIS batch's entries of the identity-keyed cache
-            forget(structure_key(ei, n))
+            forget(structure_key(ei, n), ei)
         if buf.orders is None:
             buf.__dict__.pop("_pangnn_structs", None)
         else:

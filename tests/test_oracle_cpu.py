@@ -189,7 +189,7 @@ def test_shipped_code_objects_pass_the_isa_gate():
     import subprocess
     import sys
     objs = sorted(os.path.join(ROOT, "pangnn_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "pangnn_amd", "csrc"))
-                  if f.endswith(".o"))
+                  if f.endswith(".o") and not f.startswith("t_"))      # t_*.o: host objects of libpangnn_torch.so
     assert len(objs) >= 6, "build first: python -c 'import __graft_entry__ as g; g.build()'"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py")] + objs, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
