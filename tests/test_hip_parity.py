@@ -1079,8 +1079,7 @@ def test_full_size_config4_invariants():
     x, y = torch.randn(n, 64, device=dev()), torch.randn(n, 64, device=dev())
     ax = PF.propagate(x, None, st, nrm)
     aty = PF.spmm_csr(st.by_src, nrm.by_src, y, n)
-    l, r = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
-    assert abs(l - r) <= 1e-6 * max(abs(l), abs(r), 1.0)
+    _adjoint_identity(ax, y, x, aty)
     torch.manual_seed(0)
     model = pangnn_amd.AlternateGCN(dev(), None, False, dims=[64, 128], deferred_logits=False)
     out = model(g)
@@ -1096,6 +1095,16 @@ def test_full_size_config4_invariants():
         if p.grad is not None:
             assert close(p.grad, gu[k], atol=1e-4 * (float(gu[k].abs().max()) + 1e-12) + 1e-10, rtol=1e-3), k
 
+
+
+def _adjoint_identity(ax, y, x, aty):
+    """<A x, y> == <x, A^T y>.  Both sides are sums of ~1e8 signed terms that largely cancel, so the bound is taken against
+    the sum of the terms' MAGNITUDES (what the fp32 rounding of ax / aty — a few 1e-8 per element — is proportional to), not
+    against the result: a bound relative to the result holds or fails with the random draw (round 5: it failed at 3e-6 of a
+    result of 457 when the test ran in another order)."""
+    l, r = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
+    scale = max((ax.double().abs() * y.double().abs()).sum().item(), (x.double().abs() * aty.double().abs()).sum().item(), 1.0)
+    assert abs(l - r) <= 1e-8 * scale, (l, r, scale)
 
 def _chunks(e, step=1 << 22):
     for a in range(0, e, step):
@@ -2080,8 +2089,7 @@ def test_full_size_config5_slice_invariants():
     ax = PF.spmm_csr(st.by_dst, nrm.by_dst, x, n)                       # pangnn_spmm_csr_bf16: rows gathered as stored
     aty = PF.spmm_csr(st.by_src, nrm.by_src, y, n)
     assert ax.dtype == torch.float32
-    l, r = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
-    assert abs(l - r) <= 1e-6 * max(abs(l), abs(r), 1.0)
+    _adjoint_identity(ax, y, x, aty)
     del x, y, ax, aty
     torch.manual_seed(0)
     model = pangnn_amd.AlternateGCN(dev(), None, True, dims=[64, 128], num_nodes=n, skip_connections=True,
