@@ -403,3 +403,65 @@ def test_opcheck_of_the_step_operators():
     ]
     for op, args in cases:
         torch.library.opcheck(op, args, test_utils=tests)
+
+
+@pytest.mark.gpu
+def test_native_structure_registry_builds_on_miss_keys_on_identity_and_forgets():
+    """csrc/graph_ops.cpp: an op called on raw tensors nobody prepared finds nothing in the registry, calls the one Python
+    hook (pangnn::_prepare_structure), and carries on; entries are keyed on the tensor's IDENTITY (address, version counter,
+    storage): an equal copy is another entry, an in-place change of the edge list is another structure, a freed tensor's
+    address handed to a new tensor is not a stale hit; clear_cache / forget empty it."""
+    import pangnn_amd  # noqa: F401
+    from pangnn_amd import graph as G
+    ops = torch.ops.pangnn
+    dev = torch.device("cuda")
+    n = 300
+    ei, w = random_graph(n, 2000, seed=3)
+    ei, w = ei.to(dev), w.to(dev)
+    x = torch.randn(n, 64, device=dev)
+
+    def ref(ei_, w_):
+        return go.propagate_add(x.cpu(), ei_.cpu(), go.gcn_norm(ei_.cpu(), None if w_ is None else w_.cpu(), n))
+
+    G.clear_cache()
+    assert ops._registry_size(ei) == 0
+    y = ops.gcn_propagate(x, None, ei, w, False, False)                 # miss -> hook -> built, pushed, used
+    assert ops._registry_size(ei) == 1 and torch.allclose(y.cpu(), ref(ei, w), rtol=1e-4, atol=1e-4)
+    assert torch.equal(ops.gcn_propagate(x, None, ei, w, False, False), y) and ops._registry_size(ei) == 1      # hit
+    y_unit = ops.gcn_propagate(x, None, ei, None, False, False)         # another normalisation of the same structure
+    assert ops._registry_size(ei) == 1 and torch.allclose(y_unit.cpu(), ref(ei, None), rtol=1e-4, atol=1e-4)
+    ei2 = ei.clone()                                                     # equal content, another tensor: another entry
+    assert torch.equal(ops.gcn_propagate(x, None, ei2, w, False, False), y) and ops._registry_size(ei) == 2
+    k = int(((ei[0] < 200) & (ei[1] < 200)).nonzero()[10])               # an edge between nodes that have in-edges (norm != 0)
+    ei2[0, k] = (ei2[0, k] + 7) % 200                                    # in-place: the version counter moves on
+    y3 = ops.gcn_propagate(x, None, ei2, w, False, False)
+    assert torch.allclose(y3.cpu(), ref(ei2, w), rtol=1e-4, atol=1e-4) and not torch.equal(y3, y)
+    # backward through the C++ autograd formula (transposed propagate over the by-source order, built on ITS miss)
+    xg = x.clone().requires_grad_(True)
+    b = torch.zeros(64, device=dev, requires_grad=True)
+    ops.gcn_propagate(xg, b, ei, w, False, False).square().sum().backward()
+    xr = x.cpu().clone().requires_grad_(True)
+    (go.propagate_add(xr, ei.cpu(), go.gcn_norm(ei.cpu(), w.cpu(), n))).square().sum().backward()
+    assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-3) and b.grad.shape == (64,)
+    # a freed tensor's address handed to a new tensor of the same shape must not hit the dead entry
+    ptr = ei2.data_ptr()
+    del ei2
+    for _ in range(8):
+        t = torch.randint(0, n, (2, 2000), device=dev)
+        if t.data_ptr() == ptr:
+            break
+    out = ops.gcn_propagate(x, None, t, None, False, False)
+    assert torch.allclose(out.cpu(), ref(t, None), rtol=1e-4, atol=1e-4)
+    G.forget(G.structure_key(ei, n), ei)
+    G.clear_cache()
+    assert ops._registry_size(ei) == 0
+    # the decoder ops need no table for inference and the run-sum plans for training: both through the hook
+    pq = torch.randn(n, 128, device=dev)
+    w2, b2, w3, b3 = torch.randn(64, 64, device=dev) / 8, torch.randn(64, device=dev) / 8, torch.randn(64, device=dev) / 8, torch.zeros(1, device=dev)
+    lg = ops.decoder_mlp(pq, ei, None, None, w2, b2, w3, b3)
+    yl = (torch.rand(ei.shape[1], device=dev) < 0.3).float()
+    out = ops.decoder_loss(pq, ei, None, None, w2, b2, w3, b3, yl, None, ei.shape[1], None)
+    assert torch.equal(out[1], lg) and out[2].shape == pq.shape and ops._registry_size(ei) == 1
+    h1 = torch.relu(pq[ei[0], :64] + pq[ei[1], 64:])
+    want = torch.relu(h1 @ w2.t() + b2) @ w3 + b3
+    assert torch.allclose(lg, want, rtol=1e-3, atol=1e-3)
