@@ -31,7 +31,7 @@ enum Need : int64_t {          // bits of pangnn::_prepare_structure(..., need);
   kEntry = 512                 // the structure itself (edge count, contiguous edge list): what an op that needs no table asks for
 };
 
-struct Csr { at::Tensor rowptr, other, perm; };
+struct Csr { at::Tensor rowptr, other, perm, seg_ptr, parts_rowptr; };     // seg_ptr / parts_rowptr: long rows (graph.CSR.long_rows)
 struct Plan { at::Tensor part_off, part_rowptr, keys; int64_t n_parts = 0; };
 
 struct Ident {                 // identity of a tensor: storage (weak), address, version
@@ -129,8 +129,10 @@ void check_edge_index(const char* op, const at::Tensor& edge_index) {
 void register_structure(const at::Tensor& edge_index, int64_t n_dst, int64_t n_src, const at::Tensor& ei_contig,
                         at::TensorList by_dst, at::TensorList by_src, int64_t band, int64_t sorted_by_src) {
   check_edge_index("_register_structure", edge_index);
-  TORCH_CHECK(by_dst.size() == 0 || by_dst.size() == 3, "pangnn::_register_structure: by_dst is [] or [rowptr, other, perm]");
-  TORCH_CHECK(by_src.size() == 0 || by_src.size() == 3, "pangnn::_register_structure: by_src is [] or [rowptr, other, perm]");
+  TORCH_CHECK(by_dst.size() == 0 || by_dst.size() == 3 || by_dst.size() == 5,
+              "pangnn::_register_structure: by_dst is [] or [rowptr, other, perm (, seg_ptr, parts_rowptr)]");
+  TORCH_CHECK(by_src.size() == 0 || by_src.size() == 3 || by_src.size() == 5,
+              "pangnn::_register_structure: by_src is [] or [rowptr, other, perm (, seg_ptr, parts_rowptr)]");
   const int64_t e = edge_index.size(1);
   auto check = [&](at::TensorList c, int64_t rows, const char* which) {
     if (c.size() == 0) return;
@@ -138,7 +140,14 @@ void register_structure(const at::Tensor& edge_index, int64_t n_dst, int64_t n_s
     operand("_register_structure", "perm", c[2], edge_index, at::kInt);
     TORCH_CHECK(c[1].size(0) == e && c[2].size(0) == e, "pangnn::_register_structure: ", which, " holds ", c[1].size(0),
                 " entries for ", e, " edges");
+    if (c.size() == 5) {
+      operand("_register_structure", "seg_ptr", c[3], edge_index, at::kLong);
+      operand("_register_structure", "parts_rowptr", c[4], edge_index, at::kLong);
+      TORCH_CHECK(c[3].dim() == 1 && c[3].size(0) >= 2 && c[4].dim() == 1 && c[4].size(0) == rows + 1,
+                  "pangnn::_register_structure: ", which, ": seg_ptr [V + 1], parts_rowptr [rows + 1]");
+    }
   };
+  auto make = [](at::TensorList c) { return c.size() == 5 ? Csr{c[0], c[1], c[2], c[3], c[4]} : Csr{c[0], c[1], c[2], {}, {}}; };
   check(by_dst, n_dst, "by_dst");
   check(by_src, n_src, "by_src");
   operand("_register_structure", "ei_contig", ei_contig, edge_index, at::kLong);
@@ -147,8 +156,8 @@ void register_structure(const at::Tensor& edge_index, int64_t n_dst, int64_t n_s
   std::lock_guard<std::mutex> lock(g_mu);
   Entry& en = find_or_add_locked(edge_index, n_dst, n_src);
   en.ei = ei_contig;
-  if (by_dst.size()) en.by_dst = Csr{by_dst[0], by_dst[1], by_dst[2]};
-  if (by_src.size()) en.by_src = Csr{by_src[0], by_src[1], by_src[2]};
+  if (by_dst.size()) en.by_dst = make(by_dst);
+  if (by_src.size()) en.by_src = make(by_src);
   if (band >= 0) en.band = (int)band;
   if (sorted_by_src >= 0) en.sorted_by_src = (int)sorted_by_src;
 }
@@ -314,6 +323,19 @@ at::Tensor bytes(size_t n, const at::Tensor& ref) { return at::empty({(int64_t)n
 at::Tensor spmm_rows(const Csr& csr, const at::Tensor& val, const at::Tensor& x, int64_t n_rows,
                      const c10::optional<at::Tensor>& bias) {
   const int64_t f = x.size(1);
+  if (csr.seg_ptr.defined() && (f == 16 || f == 32 || f == 64 || f == 128 || f == 256)) {
+    // a hub row: the same kernel over segments (one partial row each), then the contiguous part sum adds a row's partials in
+    // order together with the bias (graph.CSR.long_rows)
+    const Csr segs{csr.seg_ptr, csr.other, csr.perm, {}, {}};
+    const at::Tensor parts = spmm_rows(segs, val, x, csr.seg_ptr.size(0) - 1, c10::nullopt);
+    const auto bc = f32c(bias);
+    auto out = at::empty({n_rows, f}, parts.options());
+    check_rc(pangnn_spmm_csr_f32(csr.parts_rowptr.data_ptr<int64_t>(), nullptr, nullptr, parts.data_ptr<float>(), parts.stride(0),
+                                 parts.size(0), opt_ptr<float>(bc), out.data_ptr<float>(), out.stride(0), n_rows, parts.size(0),
+                                 (int32_t)f, 0, stream_of(x)),
+             "pangnn_spmm_csr_f32(long-row parts)");
+    return out;
+  }
   const bool bf16 = x.scalar_type() == at::kBFloat16 && (f == 32 || f == 64 || f == 128 || f == 256);
   at::Tensor xc;
   if (bf16) {

@@ -53,6 +53,21 @@ def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int
     lib = _lib.load()
     _lib.require_device(x, csr.rowptr, val, bias)
     f = x.shape[1]
+    long = csr.long_rows() if csr.other is not None and f in (16, 32, 64, 128, 256) else None
+    if long is not None:
+        # a hub row: the same kernel over segments of at most LONG_SEG entries (one partial row each), then the contiguous
+        # part sum adds a row's partials in order, with the bias / accumulation of the call (graph.CSR.long_rows)
+        seg_ptr, parts_rowptr = long
+        parts = spmm_csr(_SegmentRows(seg_ptr, csr.other), val, x, seg_ptr.shape[0] - 1, tag=tag)
+        if out is None:
+            out = torch.empty(n_rows, f, dtype=torch.float32, device=x.device)
+            accumulate = False
+        with _lib.device_guard(x.device):
+            _lib.check(lib.pangnn_spmm_csr_f32(parts_rowptr.data_ptr(), None, None, parts.data_ptr(), parts.stride(0),
+                                               parts.shape[0], _lib.ptr(None if bias is None else _f32c(bias)), out.data_ptr(),
+                                               out.stride(0), n_rows, parts.shape[0], f, int(accumulate), _lib.stream_ptr()),
+                       "pangnn_spmm_csr_f32(long-row parts)")
+        return out
     bf16 = x.dtype == torch.bfloat16 and f in (32, 64, 128, 256)
     if bf16:
         if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 8:
@@ -77,6 +92,16 @@ def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int
             ev1.record()
             KERNEL_TIMER[tag].append((ev0, ev1))
     return out
+
+
+class _SegmentRows:
+    """the segment table of a CSR with long rows, shaped like a CSR for spmm_csr (virtual rows = segments)"""
+
+    def __init__(self, seg_ptr, other):
+        self.rowptr, self.other = seg_ptr, other
+
+    def long_rows(self):
+        return None
 
 
 def segment_sum_rows(csr: CSR, m: torch.Tensor, col_off: int, f: int, n_rows: int,

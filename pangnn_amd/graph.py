@@ -32,11 +32,57 @@ _STRUCT_BITS = NEED_BY_DST | NEED_BY_SRC | NEED_BAND | NEED_RUNSUM | NEED_ENTRY
 _NORM_BITS = NEED_NORM | NEED_NORM_SRC | NEED_ACTIONS
 
 
+# Long rows of the propagate kernels (one wave walks one row: spmm_row_kernel): a row of more than LONG_ROW entries — a hub of
+# the similarity graph — would keep ONE wave busy for its whole length while the rest of the chip has finished (1e5 entries of
+# 256-byte rows: 25 MB through one wave, ~0.5 ms).  A CSR whose longest row exceeds LONG_ROW is therefore run as SEGMENTS of at
+# most ~sqrt(longest row) entries (long_segment): the same kernel over the segment table (a row pointer over virtual rows) writes one partial row per
+# segment, and the contiguous part sum that the decoder's run sums already use adds a row's partials in order — fixed order,
+# no atomics, independent of the grid.  SURVEY.md §7 step 3 ("long rows split across wavefronts with a second-pass reduce").
+LONG_ROW = int(os.environ.get("PANGNN_LONG_ROW", "8192"))
+LONG_SEG = int(os.environ.get("PANGNN_LONG_SEG", "0"))       # 0: about the square root of the longest row (below)
+
+
+def long_segment(max_len: int) -> int:
+    """entries per segment for a CSR whose longest row has `max_len` entries: the wave that walks a segment and the wave that
+    adds the hub's partial rows both work serially (~25 ns per entry / per part row), so the critical path seg + max_len / seg
+    is shortest at seg = sqrt(max_len); a power of two in [256, 4096]"""
+    if LONG_SEG > 0:
+        return LONG_SEG
+    seg = 256
+    while seg < 4096 and seg * seg < max_len:
+        seg *= 2
+    return seg
+
+
 @dataclass
 class CSR:
     rowptr: torch.Tensor   # int64 [N+1]
     other: torch.Tensor    # int32 [E]  opposite endpoint of each sorted edge
     perm: torch.Tensor     # int32 [E]  original edge id of each sorted edge
+
+    def long_rows(self, known_short: bool = False):
+        """None, or (seg_ptr int64 [V + 1], parts_rowptr int64 [N + 1]) when the longest row exceeds LONG_ROW: segment v covers
+        entries [seg_ptr[v], seg_ptr[v + 1]), the segments of row r are [parts_rowptr[r], parts_rowptr[r + 1]) (every row has
+        at least one).  Decided once per CSR (one host read-back of the longest row, none for structures whose producer
+        vouches for short rows: `known_short`)."""
+        hit = self.__dict__.get("_long")
+        if hit is None:
+            hit = False
+            n = self.rowptr.shape[0] - 1
+            if not known_short and n > 0 and self.other.shape[0] > LONG_ROW:
+                lens = self.rowptr[1:] - self.rowptr[:-1]
+                longest = int(lens.max())
+                if longest > LONG_ROW:
+                    seg = long_segment(longest)
+                    nseg = torch.div(lens + (seg - 1), seg, rounding_mode="floor").clamp_(min=1)
+                    parts_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=lens.device)
+                    torch.cumsum(nseg, 0, out=parts_rowptr[1:])
+                    row_of = torch.repeat_interleave(torch.arange(n, device=lens.device), nseg)
+                    j = torch.arange(row_of.shape[0], device=lens.device) - parts_rowptr[row_of]
+                    seg_ptr = torch.cat([self.rowptr[row_of] + j * seg, self.rowptr[-1:]]).contiguous()
+                    hit = (seg_ptr, parts_rowptr)
+            self.__dict__["_long"] = hit
+        return hit or None
 
 
 def build_csr(edge_index: torch.Tensor, num_nodes: int, group_by: int, validate: bool = True,
@@ -129,6 +175,7 @@ class EdgeStructure:
             if not self.hints.get("valid_ids", False) and int(bad.item()) != 0:
                 raise ValueError(f"edge_index contains node ids outside [0, {n})")
         self._by_dst, self._by_src = CSR(rp_d, other_d, perm_d), CSR(rp_s, other_s, perm_s)
+        self._by_dst.__dict__["_long"] = self._by_src.__dict__["_long"] = False      # <= 16384 edges in all: no split, no read-back
         self._small_built = True
         from types import SimpleNamespace
         n_bound = nc + min(n, e)
@@ -149,6 +196,8 @@ class EdgeStructure:
                                      num_rows=self.num_nodes)
             if self.num_nodes < nmax and self.num_edges and int(self.edge_index[1].max()) >= self.num_nodes:
                 raise ValueError("target id outside the local row range")
+            if self.hints.get("valid_ids", False):       # a producer-vouched list (a collated batch): built without any
+                self._by_dst.__dict__["_long"] = False   # read-back, so no read-back of the longest row either
         return self._by_dst
 
     @property
@@ -158,6 +207,8 @@ class EdgeStructure:
         if self._by_src is None:
             nmax = max(self.num_nodes, self.num_src)
             self._by_src = build_csr(self.edge_index, nmax, 0, validate=False, num_rows=self.num_src)
+            if self.hints.get("valid_ids", False):
+                self._by_src.__dict__["_long"] = False
         return self._by_src
 
     def band_width(self) -> int:
@@ -275,12 +326,13 @@ class EdgeStructure:
         todo = need & _STRUCT_BITS & ~have
         if todo or not (have & NEED_ENTRY):
             by_dst, by_src, band, srt, plan = [], [], -1, -1, None
+            short = self._small_built or bool(self.hints.get("valid_ids", False))
             if todo & NEED_BY_DST:
                 c = self.by_dst
-                by_dst = [c.rowptr, c.other, c.perm]
+                by_dst = [c.rowptr, c.other, c.perm] + list(c.long_rows(short) or ())
             if todo & NEED_BY_SRC:
                 c = self.by_src
-                by_src = [c.rowptr, c.other, c.perm]
+                by_src = [c.rowptr, c.other, c.perm] + list(c.long_rows(short) or ())
             if todo & NEED_BAND:
                 band = self.band_width()
             if todo & NEED_RUNSUM:

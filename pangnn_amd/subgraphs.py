@@ -436,6 +436,7 @@ class SubGraphDataset:
             td, ts = buf.orders.tables[name + "_dst"], buf.orders.tables[name + "_src"]
             st = EdgeStructure(ei, n, hints=buf._pangnn_hints[name])
             st._by_dst, st._by_src = CSR(td["rowptr"], td["other"], td["perm"]), CSR(ts["rowptr"], ts["other"], ts["perm"])
+            st._by_dst.__dict__["_long"] = st._by_src.__dict__["_long"] = False    # a collated batch of small sub-graphs
             st._small_built = True
             if name == "sim":
                 ct, nc = buf.orders.chunk_tiles, buf.orders.n_chunks

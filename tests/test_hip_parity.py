@@ -2224,3 +2224,60 @@ def test_model_under_bf16_autocast_stores_linear_outputs_as_bf16():
     scale = float(exact.abs().max())
     assert float((logits.cpu() - ref).abs().max()) < 5e-2 * scale
     assert float((logits.cpu() - exact).abs().max()) <= float((ref - exact).abs().max()) + 1e-3 * scale
+
+
+# ---------------------------------------------------------------- long rows
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16-rows"])
+def test_hub_rows_are_split_into_segments_and_summed_in_order(bf16):
+    """A hub of the similarity graph (one target with 60 000 in-edges among 3 000 nodes, and a source with 20 000 out-edges):
+    the propagate runs the wave-per-row kernel over segments of about sqrt(longest row) entries (graph.long_segment) and adds a row's partials with
+    the contiguous part sum (graph.CSR.long_rows) — same sums as the oracle, forward and transposed, through both routes
+    (ctypes and the C++ op), bitwise reproducible; a graph without long rows has no segment table."""
+    from pangnn_amd import functional as PF
+    from pangnn_amd import graph as G
+    from pangnn_amd.graph import structure_of
+    n, e = 3000, 120_000
+    gen = torch.Generator().manual_seed(11)
+    src = torch.randint(0, n, (e,), generator=gen)
+    dst = torch.randint(0, n, (e,), generator=gen)
+    dst[:60_000] = 17                                   # the hub target
+    src[60_000:80_000] = 23                             # a hub source (long row of the transposed structure)
+    w = torch.rand(e, generator=gen) * 80 + 1
+    ei = torch.stack([src, dst])
+    x = torch.randn(n, 64, generator=gen)
+    eid, wd = ei.to(dev()), w.to(dev())
+    xd = x.to(dev()).bfloat16() if bf16 else x.to(dev())
+    xr = xd.float().cpu()
+    st = structure_of(eid, n)
+    assert st.by_dst.long_rows() is not None and st.by_src.long_rows() is not None
+    seg_ptr, parts_rowptr = st.by_dst.long_rows()
+    lens = (seg_ptr[1:] - seg_ptr[:-1])
+    seg = G.long_segment(int((st.by_dst.rowptr[1:] - st.by_dst.rowptr[:-1]).max()))
+    assert seg == 256 and int(lens.max()) <= seg and int(parts_rowptr[-1]) == seg_ptr.shape[0] - 1
+    assert int(parts_rowptr[18] - parts_rowptr[17]) == -(-int(st.by_dst.rowptr[18] - st.by_dst.rowptr[17]) // seg)
+    nrm = st.gcn_norm(wd)
+    bias = torch.randn(64, device=dev())
+    norm_ref = go.gcn_norm(ei, w, n)
+    want = go.propagate_add(xr, ei, norm_ref) + bias.cpu()
+    tol = dict(atol=2e-3, rtol=2e-3)                    # 60 000-term fp32 sums against the oracle's index_add order
+    y1 = PF.spmm_csr(st.by_dst, nrm.by_dst, xd, n, bias=bias)
+    y2 = torch.ops.pangnn.gcn_propagate(xd, bias, eid, wd, False, False)
+    assert torch.equal(y1, y2) and torch.equal(y1, PF.spmm_csr(st.by_dst, nrm.by_dst, xd, n, bias=bias))
+    assert close(y1, want, **tol)
+    hub = float((y1[17].cpu() - want[17]).abs().max() / want[17].abs().max())
+    assert hub < 1e-4                                   # the hub row itself: relative to its own scale
+    # transposed propagate (the backward of the layer): by-source order, its own segment table
+    g = torch.randn(n, 64, device=dev())
+    gx = PF.spmm_csr(st.by_src, nrm.by_src, g, n)
+    want_t = torch.zeros(n, 64).index_add_(0, ei[0], g.cpu()[ei[1]] * norm_ref[:, None])
+    assert close(gx, want_t, **tol)
+    xg = xd.float().clone().requires_grad_(True)
+    torch.ops.pangnn.gcn_propagate(xg, None, eid, wd, False, False).backward(g)
+    assert torch.equal(xg.grad, gx)
+    # accumulate into a given buffer
+    acc = torch.ones(n, 64, device=dev())
+    PF.spmm_csr(st.by_src, nrm.by_src, g, n, out=acc, accumulate=True)
+    assert close(acc, gx + 1.0, atol=1e-5, rtol=1e-6)
+    # no long rows: no table
+    ei_s, _ = random_graph(500, 20_000, seed=2)
+    assert structure_of(ei_s.to(dev()), 500).by_dst.long_rows() is None
