@@ -66,3 +66,17 @@ def test_bench_single_gpu_line_carries_roofline_step_bytes_and_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "oracle" in c["sample"]
     assert d["value"] > 10 * c["value"]
+
+
+def test_bench_emulated_rank_line():
+    """bench.py --emulate-rank r --of W (the per-rank compute side of the W-way split on one GPU; tools/rank_emulation.py):
+    one JSON line with the shard's sizes, its halo rows per owner, the S launches of the own-source and halo-source ranges"""
+    common = ["--workload", "cfg2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    lines = [_run([sys.executable, "bench.py", "--emulate-rank", str(r), "--of", "4"] + common, {"MASTER_PORT": str(29660 + r)})
+             for r in (0, 2)]
+    for r, d in zip((0, 2), lines):
+        assert d["emulated_rank"] == r and d["of"] == 4 and d["ms_per_step"] > 0 and d["steps"] == 3
+        assert d["sim_edges_local"] == d["own_source_edges"] + d["halo_source_edges"] > 0
+        assert sum(d["halo_rows_by_owner"]["sim"]) == d["halo_rows"]["sim"] and d["halo_rows_by_owner"]["sim"][r] == 0
+        assert len(d["decoder_S_launch_ms"]) == 2 and d["per_step_exchange_bytes"]["gradient_all_reduce"] == 4 * 29249   # node_dim 64, hidden_dim 64: 29 249 parameters
+    assert lines[0]["node_range"][0] == 0 and lines[1]["node_range"][0] > lines[0]["node_range"][1] - 1

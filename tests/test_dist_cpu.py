@@ -284,3 +284,38 @@ def test_all_gather_rows_backward_is_reduce_scatter():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_ag_worker, args=(2, os.path.join(d, "rdzv"), d), nprocs=2, join=True)
         assert os.path.exists(os.path.join(d, "ok0")) and os.path.exists(os.path.join(d, "ok1"))
+
+
+def test_emulated_rank_plan_is_the_real_ranks_layout():
+    """dist.HaloPlan(..., emulated_world=W) in a ONE-process job (bench.py --emulate-rank r --of W): the remote-source set, the
+    table layout [halo of lower ranks | own | halo of higher ranks], the re-indexed edge list and the own-source / halo-source
+    split are those of the real rank; only the exchange is a self-exchange of the same row count."""
+    from pangnn_amd import dist as pdist
+    g = whole_graph_from_golden("cfg2_sim_1000x5")
+    order = torch.argsort(g.edge_index[0], stable=True)        # source-sorted, as the simulator / construct.py emit their lists
+    g.edge_index, g.edge_attr, g.y = g.edge_index[:, order].contiguous(), g.edge_attr[order], g.y[order]
+    world = 4
+    port = 29791
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        bounds = pdist.balanced_bounds(1000, 5, world)
+        for r in range(world):
+            shard = pdist.partition_graph(g, r, world, bounds)
+            plan = pdist.HaloPlan(shard.edge_index, shard.lo, shard.n_local, None, None, bounds, emulated_world=world)
+            src = shard.edge_index[0]
+            remote = (src < shard.lo) | (src >= shard.hi)
+            need = torch.unique(src[remote])
+            assert plan.n_halo == need.numel() and plan.n_table == shard.n_local + need.numel()
+            assert plan.send_splits == [plan.n_halo] and plan.recv_splits == [plan.n_halo] and plan.send_idx.numel() == plan.n_halo
+            assert sum(plan.peer_counts) == plan.n_halo and plan.peer_counts[r] == 0
+            # the table in global ids: what row k of the table stands for
+            table_ids = torch.cat([need[need < shard.lo], torch.arange(shard.lo, shard.hi), need[need >= shard.hi]])
+            assert torch.equal(table_ids[plan.edge_index[0]], src) and torch.equal(plan.edge_index[1], shard.edge_index[1])
+            assert plan.sorted_by_src
+            own = plan.edge_index[0][plan.e_lo:plan.e_hi]
+            assert bool(((own >= plan.n_low) & (own < plan.n_low + shard.n_local)).all())
+            rest = torch.cat([plan.edge_index[0][:plan.e_lo], plan.edge_index[0][plan.e_hi:]])
+            assert bool(((rest < plan.n_low) | (rest >= plan.n_low + shard.n_local)).all())
+            assert plan.any_exchange == (plan.n_halo > 0)
+    finally:
+        dist.destroy_process_group()
