@@ -269,3 +269,48 @@ def test_padded_fixed_shape_batch_reaches_the_fused_pass_through_the_handle():
     assert torch.equal(loss2.detach(), loss.detach()) and torch.equal(out.detach(), logits)
     with pytest.raises(NotImplementedError):
         torch.sigmoid(model(buf))
+
+
+def test_reference_loop_under_accelerate_fp16_runs_at_fp32_level():
+    """`--mixed_precision fp16` (/root/reference/src/setup.py:50): accelerate wraps `forward` in float16 autocast and drives
+    `accelerator.backward(loss)` through a GradScaler (loss x 65 536).  This package has no float16 row format: its operators
+    keep fp32 storage under float16 autocast, so the loop's results sit at the FP32 oracle's level — better than
+    the reference's own fp16 run would — and the scaled loss exercises the in-place gradient scaling behind the fused decoder
+    pass (pangnn_scale_unless_one_f32 with a scalar that is NOT 1), unscaled again by the scaler before Adam."""
+    import pangnn_amd
+    from pangnn_amd import DeferredLogits
+    g = whole_graph_from_golden("cfg2_sim_1000x5")
+    class_balance = float((g.y == 0).sum() / g.y.sum())
+    torch.manual_seed(0)
+    oracle = go.AlternateGCNOracle(dims=(64, 64))
+    init = {k: v.clone() for k, v in oracle.state_dict().items()}
+    opt_o = torch.optim.Adam(oracle.parameters(), lr=0.001)
+    ref = []
+    for _ in range(3):
+        lo, out_o = go.train_step(oracle, opt_o, g, g.y, torch.tensor(class_balance))
+        ref.append((float(lo), out_o))
+    accelerator = _accelerator("fp16")
+    assert accelerator.scaler is not None
+    model = pangnn_amd.AlternateGCN(device=accelerator.device, dataset=None, categorical_nodes=False, dims=[64, 64])
+    model.load_state_dict(init)
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.001)
+    criterion = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(class_balance))
+    model, optimizer = accelerator.prepare(model, optimizer)
+    batch = copy_graph(g, accelerator.device)
+    for step in range(3):
+        model.train()
+        optimizer.zero_grad()
+        output = model(batch)
+        assert type(output) is DeferredLogits
+        loss = criterion(output, batch.y)
+        accelerator.backward(loss)                      # scaler.scale(loss).backward(): upstream gradient = the scale
+        optimizer.step()                                # scaler.step: unscale, inf check, Adam; scaler.update
+        assert output.route == "fused" and not optimizer.step_was_skipped
+        tol = 1e-4 if step == 0 else 5e-4
+        assert torch.allclose(output.detach().cpu(), ref[step][1], atol=tol, rtol=tol), step
+        assert abs(loss.item() - ref[step][0]) <= (1e-5 if step == 0 else 1e-4) * max(1.0, abs(ref[step][0]))
+    state = accelerator.unwrap_model(model).state_dict()
+    moved = sum(int(((v.cpu() - oracle.state_dict()[k]).abs() > 2e-5).sum()) for k, v in state.items())
+    assert moved <= 0.002 * sum(v.numel() for v in state.values())
+    from accelerate.state import AcceleratorState
+    AcceleratorState._reset_state(True)
