@@ -363,8 +363,8 @@ int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm, const int
  *   wgrad: gw[M,K]    = g[N,M]^T . x[N,K],  gb[M] = sum_n g[n,:]  (gb nullable)
  * fp32 storage and accumulation; the products run on the bf16 matrix pipe with both operands split into three exact
  * bf16 terms (six partial products: the error against an fp64 evaluation is that of an fp32 FMA chain; the 128 x 128 shape
- * and builds with -DPANGNN_LIN_F32_MFMA use v_mfma_f32_32x32x2_f32).  HBM-bound streaming kernels; wgrad is slab-reduced
- * (reproducible).
+ * forward and builds with -DPANGNN_LIN_F32_MFMA use v_mfma_f32_32x32x2_f32; the 128 x 128 weight gradient runs as two
+ * 64-column halves of g).  HBM-bound streaming kernels; wgrad is slab-reduced (reproducible).
  * pangnn_linear_supported(K, M, wgrad) tells the caller whether a shape is covered.
  * ---------------------------------------------------------------------------------------- */
 int    pangnn_linear_supported(int32_t K, int32_t M, int wgrad);

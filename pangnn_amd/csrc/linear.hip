@@ -151,10 +151,13 @@ struct FwdGeo {
   static constexpr int KS = K + 4;
 #ifdef PANGNN_LIN_WAVES      // diagnostic builds only
   static constexpr int WAVES = PANGNN_LIN_WAVES;
-#elif defined(PANGNN_LIN_F32_MFMA)
+#elif defined(PANGNN_LIN_F32_MFMA) || defined(PANGNN_LIN_128_W4)
   static constexpr int WAVES = 4;
 #else
-  static constexpr int WAVES = 4;        // (8 waves for K = 64 measured: no gain — these kernels are at their HBM time)
+  // (8 waves for K = 64 measured: no gain — these kernels are at their HBM time.)  128 x 128: the three split images of the
+  // weight take 102 KB, which leaves room for THREE 16.5 KB row tiles — three waves on the split-bf16 product beat four on
+  // v_mfma_f32_32x32x2_f32 (round 5, N = 1e6: forward 0.23-0.25 ms vs 0.30, dL/dx + dL/dW 0.65 vs 0.71; -DPANGNN_LIN_128_W4)
+  static constexpr int WAVES = (K == 128 && M == 128) ? 3 : 4;
 #endif
 };
 
@@ -242,8 +245,9 @@ constexpr bool kLinX3 = true;
 template <int K, int M>
 struct WImg {
   static constexpr int WS = K + 8;                                     // bf16 row stride of a split image
-  // 128 x 128 (three 34 KB images + four 17 KB row tiles) does not fit the 160 KB of LDS: that shape keeps the f32 product
-  static constexpr bool X3 = kLinX3 && (3 * M * WS * 2 + 4 * 32 * (K + 4) * 4 <= 150 * 1024);
+  // 128 x 128: three 34 KB images + three 16.5 KB row tiles (FwdGeo: three waves) = 152 KB of the 160 KB; with four tiles it
+  // does not fit and the f32 product is used
+  static constexpr bool X3 = kLinX3 && (3 * M * WS * 2 + FwdGeo<K, M>::WAVES * 32 * (K + 4) * 4 <= 156 * 1024);
   static constexpr int FLOATS = X3 ? (3 * M * WS + 1) / 2 : M * (K + 4);
 };
 
@@ -1121,7 +1125,7 @@ using namespace pangnn;
 extern "C" int pangnn_linear_supported(int32_t K, int32_t M, int wgrad) {
   const bool km = (K == 64 || K == 128) && (M == 64 || M == 128);
   if (!km) return 0;
-  if (wgrad && K == 128 && M == 128) return 0;   // 256 accumulator registers: left to the library
+  (void)wgrad;   // the 128 x 128 weight gradient (256 accumulator registers as one tile) runs as two 64-column halves of g
   return 1;
 }
 
@@ -1202,6 +1206,15 @@ extern "C" int pangnn_linear_act_wgrad_mixed(const void* g, int32_t g_dtype, int
   const int gbf = g_dtype == PANGNN_DTYPE_BF16, xbf = x_dtype == PANGNN_DTYPE_BF16;
   if (K == 64 && M == 64) return launch_wgrad<64, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
   if (K == 64 && M == 128) return launch_wgrad<64, 128>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+  if (K == 128 && M == 128) {
+    // dW[0:64) from g[:, 0:64), dW[64:128) from g[:, 64:128): the <128, 64> kernel twice over column windows of g (same ldg),
+    // stream-ordered on one workspace.  x is read twice (N * 512 B more than a single pass would need).
+    const char* g_hi = static_cast<const char*>(g) + (size_t)64 * (gbf ? 2 : 4);
+    int rc = launch_wgrad<128, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+    if (rc) return rc;
+    return launch_wgrad<128, 64>(g_hi, gbf, ldg, x, xbf, ldx, n, in_act, gw + (size_t)64 * 128, gb ? gb + 64 : nullptr, ws,
+                                 workspace_bytes, s);
+  }
   return launch_wgrad<128, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
 }
 
@@ -1219,7 +1232,9 @@ extern "C" int pangnn_linear_wgrad_f32(const float* g, int64_t ldg, const float*
 }
 
 // ---- first layer by linearity fused into the following dense layer (see gen_linear_*_kernel above) ----
-extern "C" int pangnn_embed_linear_supported(int32_t H, int32_t M) { return pangnn_linear_supported(H, M, 1); }
+extern "C" int pangnn_embed_linear_supported(int32_t H, int32_t M) {
+  return pangnn_linear_supported(H, M, 1) && !(H == 128 && M == 128);   // no generated-rows kernels for the square 128 shape
+}
 
 extern "C" int pangnn_embed_linear_fwd(const float* r, const float* s, int64_t n, const float* w_emb, const float* b_emb,
                                        const float* w_in, const float* b_in, int32_t D, int32_t H, const float* w_out,

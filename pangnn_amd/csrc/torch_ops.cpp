@@ -233,7 +233,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> linear_bwd(const at::Tensor& g, c
                   g.size(1) == w.size(0),
               "pangnn::linear_backward: g must be a floating-point [N, M] on ", x.device());
   TORCH_CHECK(pangnn_linear_supported((int32_t)w.size(1), (int32_t)w.size(0), 1),
-              "pangnn::linear_backward: this shape's weight gradient is left to the library (pangnn_linear_supported)");
+              "pangnn::linear_backward: shape not covered (pangnn_linear_supported)");
   const DeviceGuard guard(x.device());
   const at::Tensor xr = rows_any(x), gr = rows_any(g), wc = w.to(at::kFloat).contiguous();
   const int64_t n = xr.size(0), k = xr.size(1), m = wc.size(0);

@@ -838,7 +838,7 @@ def _linear_supported(k: int, m: int) -> bool:
 
 def linear(x, w, bias=None, in_act: int = 0, out_dtype=None):
     """torch.nn.functional.linear for node-level layers; shapes the HIP kernels do not cover
-    (K or M outside {64,128}, or the 128x128 weight gradient) go to hipBLASLt via torch.
+    (K or M outside {64,128}) go to hipBLASLt via torch.
     in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels — forward: ELU applied to the rows on their
     way into LDS; backward: dL/dx comes out already multiplied by ELU'(x), the weight gradient re-applies ELU (no activation
     kernel, no activated tensor in HBM; pangnn::linear / linear_backward, csrc/torch_ops.cpp).
@@ -1061,8 +1061,9 @@ class _EmbedConvInLinear(torch.autograd.Function):
         return (None, g_w, g_b, g_win, g_bin if ctx.has_bin else None, g_wout, g_bout if ctx.has_bout else None, None, None)
 
 
+@torch.compiler.assume_constant_result
 def embed_linear_supported(h: int, m: int) -> bool:
-    return _linear_supported(int(h), int(m))           # the same (K, M) set as the weight-gradient kernel
+    return bool(_lib.load().pangnn_embed_linear_supported(int(h), int(m)))     # (64, 64), (64, 128), (128, 64)
 
 
 def embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):

@@ -30,6 +30,9 @@ TLIB_PATH = os.environ.get("PANGNN_TORCH_LIB") or os.path.join(_HERE, "libpangnn
 if not os.path.exists(TLIB_PATH):
     raise ImportError(f"pangnn_amd: {TLIB_PATH} is missing — build it with `make -C pangnn_amd/csrc` "
                       f"(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+from . import _lib                                     # noqa: E402
+_lib.load()     # first: libpangnn_torch.so needs "libpangnn_hip.so" by SONAME, which the library already in the process (the in-tree
+#                 one, or a diagnostic build chosen through PANGNN_HIP_LIB and linked with the same -soname) then satisfies
 torch.ops.load_library(TLIB_PATH)
 ops = torch.ops.pangnn
 

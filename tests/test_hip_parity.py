@@ -712,6 +712,43 @@ def test_linear_kernels_match_torch(k, m, n):
         assert close(a.grad, r.grad, atol=2e-5 * scale + 1e-7, rtol=1e-4)
 
 
+@pytest.mark.parametrize("n", [1, 33, 40007])
+@pytest.mark.parametrize("in_act", [0, 1])
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_linear_wgrad_128x128_is_the_two_column_halves(n, in_act, bf16):
+    """pangnn_linear_act_wgrad_mixed(K = M = 128) (conv_hidden of --union_edge_weights, gnn.py:128-139): rows [0, 64) and
+    [64, 128) of dL/dW come from the 64-column windows of g through the <128, 64> kernel — bit for bit what that kernel gives on
+    contiguous copies of the windows; also inside a wider matrix (ldg = 192); and within fp32 of an fp64 evaluation."""
+    from pangnn_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(n + in_act)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    wide = torch.randn(n, 192, generator=gen).to(dev()).to(dt)
+    g = wide[:, 64:]                                           # [n, 128] window, ld = 192
+    x = torch.randn(n, 128, generator=gen).to(dev()).to(dt)
+    ws_bytes = lib.pangnn_linear_wgrad_workspace_bytes(128, 128)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev())
+
+    def wgrad(gm, m):
+        gw = torch.full((m, 128), float("nan"), device=dev())
+        gb = torch.full((m,), float("nan"), device=dev())
+        with torch.cuda.device(dev()):
+            _lib.check(lib.pangnn_linear_act_wgrad_mixed(gm.data_ptr(), int(bf16), gm.stride(0), x.data_ptr(), int(bf16),
+                                                         x.stride(0), n, 128, m, in_act, gw.data_ptr(), gb.data_ptr(),
+                                                         ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "linear_wgrad")
+        return gw, gb
+
+    gw, gb = wgrad(g, 128)
+    lo, hi = wgrad(g[:, :64].contiguous(), 64), wgrad(g[:, 64:].contiguous(), 64)
+    assert torch.equal(gw, torch.cat([lo[0], hi[0]])) and torch.equal(gb, torch.cat([lo[1], hi[1]]))
+    xd = x.double()
+    xd = torch.nn.functional.elu(xd) if in_act else xd
+    ref = g.double().t() @ xd
+    scale = float(ref.abs().max()) + 1e-12
+    assert close(gw, ref, atol=2e-5 * scale, rtol=1e-4)
+    assert close(gb, g.double().sum(0), atol=2e-5 * (float(g.double().sum(0).abs().max()) + 1e-12), rtol=1e-4)
+
+
 def test_linear_strided_input_window():
     from pangnn_amd import functional as PF
     big = torch.randn(500, 192, device=dev())
@@ -2128,8 +2165,6 @@ def test_linear_bf16_storage_is_the_f32_kernel_with_one_rounding(k, m, n, x_bf16
     what the f32 entry points give on the up-converted inputs (followed by torch's RNE cast where the storage is
     bf16).  Gradients of bf16 tensors are bf16 (autograd's rule, and the reference's under autocast)."""
     from pangnn_amd import functional as PF
-    if k == 128 and m == 128:
-        pytest.skip("128x128 weight gradient is left to the library (pangnn_linear_supported)")
     torch.manual_seed(n + k + m + in_act)
     bf, f32 = torch.bfloat16, torch.float32
     x = torch.randn(n, k, device=dev()).to(bf if x_bf16 else f32)

@@ -28,7 +28,7 @@ def timed(fn, reps=12):
 
 
 print("library:", os.environ.get("PANGNN_HIP_LIB", "(in-tree)"))
-for k, m in ((64, 128), (128, 64), (64, 64)):
+for k, m in ((64, 128), (128, 64), (64, 64), (128, 128)):
     x = torch.randn(n, k, device=dev)
     w = (torch.randn(m, k, device=dev) / 8).requires_grad_(True)
     b = torch.randn(m, device=dev).requires_grad_(True)
@@ -43,6 +43,13 @@ for k, m in ((64, 128), (128, 64), (64, 64)):
     y = PF.linear(xr, w, b, 1)
     t = timed(lambda: torch.autograd.grad(y, (xr, w, b), g, retain_graph=True))
     print(f"bwd<{k},{m}> act=1 (dgrad with gate + wgrad): {t:.3f} ms")
+    if (k, m) == (128, 128):        # what the layer cost through the library (torch -> hipBLASLt) until round 5
+        F = torch.nn.functional
+        t = timed(lambda: F.linear(F.elu(x), w, b))
+        print(f"torch fwd<{k},{m}> (elu kernel + addmm): {t:.3f} ms")
+        yt = F.linear(F.elu(xr), w, b)
+        t = timed(lambda: torch.autograd.grad(yt, (xr, w, b), g, retain_graph=True))
+        print(f"torch bwd<{k},{m}>: {t:.3f} ms")
 
 # the generated first layer + conv_out's dense part
 ei = torch.stack([torch.arange(n, device=dev), torch.arange(n, device=dev)])
