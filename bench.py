@@ -93,7 +93,9 @@ def step_alg_bytes(n, e, e_nb, d, h, parts_s, parts_t, s_rows=4):
 
 
 # kernel-name substrings of the three kernels whose counter traffic profiles/traffic.json holds (tools/update_traffic.py)
-TRAFFIC_KERNELS = {"decoder_train": "decoder_train16_kernel", "decoder_dgrad": "decoder_dgrad16_kernel",
+# (the S kernel by its exact instance — fused loss, run sums, no skip feature, f32 tables: the headline step's — so that launches of
+# the literal route's / another workload's instance in the same counter pass are not averaged in)
+TRAFFIC_KERNELS = {"decoder_train": "decoder_train16_kernel<true, true, false, false>", "decoder_dgrad": "decoder_dgrad16_kernel<true, true>",
                    "spmm_fwd": "spmm_row_kernel<64, 4, false, false>"}
 
 
@@ -400,7 +402,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-siblings", action="store_true",
                     help="keep the general-feature and strict-fp32 timings but skip the siblings that build their own data "
-                         "(cfg5slice, mini-batch regimes): what the counter passes of tools/pmc_traffic.sh want")
+                         "(cfg5slice, mini-batch regimes) and the reference_loop / eval ones: what the counter passes of "
+                         "tools/pmc_traffic.sh want")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sibling timings (general-feature step, strict fp32, cfg5slice, mini-batch regimes)")
     ap.add_argument("--reference-loop", action="store_true", help="time the reference_loop / eval siblings with --genes too")
@@ -674,7 +677,7 @@ def main():
             PF.KERNEL_TIMER = None
         # (ii-b) the reference's own loop under accelerate on the same graph (deferred logits = the package default, and
         # round 4's literal route beside it), and the validation pass
-        if not args.genes or args.reference_loop:
+        if (not args.genes and not args.no_siblings) or args.reference_loop:
             n_ref = max(args.steps, 10)
             for key, fn in (("reference_loop", lambda: reference_loop_sibling(dev, graph, labels, pos_weight, d, h, e_sim, n_ref)),
                             ("reference_loop_literal", lambda: reference_loop_sibling(dev, graph, labels, pos_weight, d, h, e_sim,
