@@ -96,7 +96,7 @@ def step_alg_bytes(n, e, e_nb, d, h, parts_s, parts_t, s_rows=4):
 # (the S kernel by its exact instance — fused loss, run sums, no skip feature, f32 tables: the headline step's — so that launches of
 # the literal route's / another workload's instance in the same counter pass are not averaged in)
 TRAFFIC_KERNELS = {"decoder_train": "decoder_train16_kernel<true, true, false, false>", "decoder_dgrad": "decoder_dgrad16_kernel<true, true>",
-                   "spmm_fwd": "spmm_row_kernel<64, 4, false, false>"}
+                   "spmm_fwd": "spmm_row_kernel<64, 4, false, 0>"}
 
 
 # the sources the three counted kernels are compiled from: profiles/traffic.json carries their hash at collection time

@@ -27,7 +27,9 @@ extern "C" {
 /* 2 (round 5): pangnn_decoder_train_f32 / _mixed / pangnn_decoder_dgrad_f32 took live_edges in round 4 and the 32-byte record
  * layout changed without a bump; pangnn_scale_unless_one_f32 added.  A library of another version is refused
  * by pangnn_amd/_lib.py and by libpangnn_torch.so when it resolves this ABI. */
-#define PANGNN_ABI_VERSION 2
+/* 3 (round 5, later): PANGNN_DTYPE_F16 accepted by the node-level *_dtype arguments, pangnn_spmm_csr_f16 added; the 128 x 128
+ * weight gradient is covered (pangnn_linear_supported(128, 128, 1) = 1). */
+#define PANGNN_ABI_VERSION 3
 
 #define PANGNN_E_BADARG    (-1)  /* null pointer / negative size / unsupported feature width */
 #define PANGNN_E_TOOLARGE  (-2)  /* size exceeds an int32 index range used by the kernels    */
@@ -37,6 +39,9 @@ extern "C" {
 /* storage types of the *_mixed entry points: the arithmetic is fp32 either way, a matrix may be STORED as bfloat16 */
 #define PANGNN_DTYPE_F32  0
 #define PANGNN_DTYPE_BF16 1
+#define PANGNN_DTYPE_F16  2   /* IEEE half rows (--mixed_precision fp16): accepted wherever a *_dtype argument of the node-level
+                               * entry points (dense layers, propagate gathers, generated rows, column sums) accepts _BF16; the
+                               * 2-byte operands of one call are all bfloat16 or all float16.  The decoder's pq_dtype is F32 / BF16. */
 
 typedef void* pangnn_stream_t;   /* hipStream_t */
 
@@ -182,6 +187,10 @@ int pangnn_spmm_csr_f32(const int64_t* rowptr, const int32_t* idx, const float* 
 int pangnn_spmm_csr_bf16(const int64_t* rowptr, const int32_t* idx, const float* val, const void* x_bf16,
                          int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
                          int64_t n_rows, int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream);
+/* ... and as IEEE half (`--mixed_precision fp16`, /root/reference/src/setup.py:50: PyG's propagate under float16 autocast) */
+int pangnn_spmm_csr_f16(const int64_t* rowptr, const int32_t* idx, const float* val, const void* x_f16,
+                        int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
+                        int64_t n_rows, int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * edge decoder gather (k7; src/gnn.py:171-177):

@@ -41,6 +41,7 @@ SIGNATURES = {
     "pangnn_permute_f32": (C.c_int, [_p, _p, _p, _i64, _p]),
     "pangnn_spmm_csr_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, C.c_int, _p]),
     "pangnn_spmm_csr_bf16": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, C.c_int, _p]),
+    "pangnn_spmm_csr_f16": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, C.c_int, _p]),
     "pangnn_edge_gather_concat_f32": (C.c_int, [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _i32, _p]),
     "pangnn_edge_pair_add_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _i32, _p]),
     "pangnn_segment_sum_rows_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _i64, _i32, C.c_int, _p]),
@@ -109,7 +110,7 @@ SIGNATURES = {
     "pangnn_scale_unless_one_f32": (C.c_int, [_p, _p, _i32, _p, _p]),
 }
 
-ABI_VERSION = 2          # PANGNN_ABI_VERSION of include/pangnn_hip.h this binding was written against
+ABI_VERSION = 3          # PANGNN_ABI_VERSION of include/pangnn_hip.h this binding was written against
 
 _lib = None
 

@@ -138,25 +138,27 @@ class GCNConv(MessagePassing):
             if self.in_channels < self.out_channels or x.shape[1] != self.out_channels:
                 raise ValueError("dense_done=True needs a dense-first layer (in >= out) and x = lin(input)")
             return PF.propagate_any(x, self.bias, st, norm, edge_weight is None, tag=name or None)
-        if not (x.dtype == torch.bfloat16 and self.in_channels >= self.out_channels):
-            x = x.float()          # (a bf16-stored input of a dense-first layer is read as stored by the linear kernel)
-        # Under bf16 autocast (`accelerate` mixed precision) PyG's propagate gathers bf16 rows — the
-        # output of its autocast Linear — and multiplies / accumulates in fp32: the rows this layer propagates are
-        # stored in bfloat16 (half the gather bytes, pangnn_spmm_csr_bf16); the dense part itself stays fp32.
-        rows_bf16 = x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if not (x.dtype in PF.ROWS16 and self.in_channels >= self.out_channels):
+            x = x.float()          # (a 16-bit-stored input of a dense-first layer is read as stored by the linear kernel)
+        # Under bf16 / fp16 autocast (`accelerate` mixed precision, SURVEY.md §8b, src/setup.py:50) PyG's propagate gathers
+        # 16-bit rows — the output of its autocast Linear — and multiplies / accumulates in fp32: the rows this layer
+        # propagates are stored in that type (half the gather bytes, pangnn_spmm_csr_bf16 / _f16); the dense part stays fp32.
+        rows16 = PF.autocast_rows_dtype(x)                       # torch.bfloat16 / torch.float16 / None
+        if x.dtype in PF.ROWS16 and x.dtype != rows16:
+            x = x.float()          # (rows stored in the other 16-bit type than the autocast one: one call never mixes the two)
         if in_elu and self.in_channels < self.out_channels:
             x, in_elu = torch.nn.functional.elu(x), False       # propagate comes first: nothing to fold into
         if self.in_channels < self.out_channels:
             # A_hat (x W^T) == (A_hat x) W^T: propagate on the narrower side (half the gather bytes for
             # 64 -> 128), then the dense layer with the bias fused
-            # ... and their sum is what the autocast Linear casts to bfloat16 first thing: cast once, stored (out_bf16), so
-            # that the Linear reads 2-byte rows and the transposed propagate gathers its bfloat16 gradient as stored
-            agg = PF.propagate_any(x.to(torch.bfloat16) if rows_bf16 else x, None, st, norm, edge_weight is None,
-                                   tag=name or None, out_bf16=rows_bf16)
-            # the autocast Linear's output is a bf16 tensor (src/gnn.py:111 under mixed precision): stored as such
-            return PF.linear(agg, self.lin.weight, self.bias, 0, torch.bfloat16 if rows_bf16 else None)
-        # dense part first: under bf16 autocast its result is WRITTEN as bfloat16 by the linear kernel (no separate cast)
-        xw = self.lin(x, 1 if in_elu else 0, torch.bfloat16 if rows_bf16 else None)
+            # ... and their sum is what the autocast Linear casts to the autocast type first thing: cast once, stored
+            # (out_dtype), so that the Linear reads 2-byte rows and the transposed propagate gathers its 16-bit gradient as stored
+            agg = PF.propagate_any(x.to(rows16) if rows16 else x, None, st, norm, edge_weight is None,
+                                   tag=name or None, out_dtype=rows16)
+            # the autocast Linear's output is a 16-bit tensor (src/gnn.py:111 under mixed precision): stored as such
+            return PF.linear(agg, self.lin.weight, self.bias, 0, rows16)
+        # dense part first: under autocast its result is WRITTEN in the autocast type by the linear kernel (no separate cast)
+        xw = self.lin(x, 1 if in_elu else 0, rows16)
         return PF.propagate_any(xw, self.bias, st, norm, edge_weight is None, tag=name or None)
 
     def message(self, x_j, edge_weight):            # kept for API parity; forward() is fused

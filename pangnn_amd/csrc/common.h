@@ -39,6 +39,37 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kSumGroups = 16;
 constexpr int kSumThreads = kSumGroups * kWave;
 #ifdef __HIPCC__
+// ---- 2-byte row formats (storage only; every sum and product is fp32).  A kernel templated on its storage type uses
+// `unsigned short` for bfloat16 bits (bf16 -> f32 is a shift) and `_Float16` for IEEE half (`--mixed_precision fp16`,
+// src/setup.py:50; v_cvt_f32_f16 / v_cvt_f16_f32); RowFmt<T>::value is the PANGNN_DTYPE_* code of T.
+template <typename T> struct RowFmt { static constexpr int value = 0; };
+template <> struct RowFmt<unsigned short> { static constexpr int value = 1; };
+template <> struct RowFmt<_Float16> { static constexpr int value = 2; };
+// four consecutive stored elements (8 bytes) -> f32, exact
+__device__ __forceinline__ float4 rows16_to_f32(uint2 t, int fmt) {
+  if (fmt == 2) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, t.x), b = __builtin_bit_cast(h2, t.y);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+  }
+  return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                     __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+}
+__device__ __forceinline__ float row16_to_f32(unsigned short bits, int fmt) {
+  return fmt == 2 ? (float)__builtin_bit_cast(_Float16, bits) : __uint_as_float((uint32_t)bits << 16);
+}
+// f32 -> four stored elements, each rounded to nearest even
+__device__ __forceinline__ uint2 f32_to_rows16(float v0, float v1, float v2, float v3, int fmt) {
+  if (fmt == 2) {
+    // f32 values first, then one rounding each (no v_fma_mixlo_f16 folding of the producing multiply-add: see linear.hip)
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+    const _Float16 o[4] = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+    return *reinterpret_cast<const uint2*>(o);
+  }
+  const __bf16 o[4] = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+  return *reinterpret_cast<const uint2*>(o);
+}
+
 __device__ __forceinline__ float ordered_parts_sum(const float* __restrict__ part, int n_parts, int64_t stride, int i,
                                                    int len) {
   __shared__ float red[kSumGroups][kWave];

@@ -303,8 +303,7 @@ __global__ __launch_bounds__(kBlock) void rank2_rows_kernel(const float* __restr
     if constexpr (sizeof(TY) == 4) {
       *reinterpret_cast<float4*>(out + row * ldo + col) = make_float4(v0, v1, v2, v3);
     } else {
-      __bf16 o[4] = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};            // round to nearest even
-      *reinterpret_cast<uint2*>(out + row * ldo + col) = *reinterpret_cast<const uint2*>(o);
+      *reinterpret_cast<uint2*>(out + row * ldo + col) = f32_to_rows16(v0, v1, v2, v3, RowFmt<TY>::value);   // round to nearest even
     }
   }
 }
@@ -326,9 +325,8 @@ __global__ __launch_bounds__(kBlock) void weighted_colsum3_kernel(const TG* __re
       const float4 t = *reinterpret_cast<const float4*>(g + row * ldg + 4 * c);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
-      const uint2 t = *reinterpret_cast<const uint2*>(g + row * ldg + 4 * c);
-      v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-      v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+      const float4 t = rows16_to_f32(*reinterpret_cast<const uint2*>(g + row * ldg + 4 * c), RowFmt<TG>::value);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     const float rv = r[row], sw = sv[row];
 #pragma unroll
@@ -388,8 +386,7 @@ __global__ __launch_bounds__(kBlock) void embed_conv_in_rows_kernel(const float*
     if constexpr (sizeof(TY) == 4) {
       *reinterpret_cast<float4*>(out + row * ldo + col) = make_float4(v0, v1, v2, v3);
     } else {
-      __bf16 o[4] = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
-      *reinterpret_cast<uint2*>(out + row * ldo + col) = *reinterpret_cast<const uint2*>(o);
+      *reinterpret_cast<uint2*>(out + row * ldo + col) = f32_to_rows16(v0, v1, v2, v3, RowFmt<TY>::value);   // round to nearest even
     }
   }
 }
@@ -534,13 +531,12 @@ __global__ __launch_bounds__(kSumThreads) void colsum_small_kernel(const TG* __r
       const float4 t = *reinterpret_cast<const float4*>(p);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else if constexpr (VEC == 4) {
-      const uint2 t = *reinterpret_cast<const uint2*>(p);   // four bfloat16: exact in f32
-      v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-      v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+      const float4 t = rows16_to_f32(*reinterpret_cast<const uint2*>(p), RowFmt<TG>::value);   // four 2-byte elements: exact in f32
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else if constexpr (sizeof(TG) == 4) {
       v[0] = *p;
     } else {
-      v[0] = __uint_as_float((uint32_t)*p << 16);
+      v[0] = row16_to_f32(__builtin_bit_cast(unsigned short, *p), RowFmt<TG>::value);
     }
   };
   if (q < groups) {
@@ -801,20 +797,18 @@ extern "C" int pangnn_colsum_small(const void* g, int32_t g_dtype, int64_t ldg, 
                                    pangnn_stream_t stream) {
   PG_CHECK_ARG(n >= 0 && F > 0 && F <= kSumThreads && ldg >= F && out && (n == 0 || g), PANGNN_E_BADARG,
                "pangnn_colsum_small: bad argument (F = %d: 1 .. %d)", (int)F, kSumThreads);
-  PG_CHECK_ARG(g_dtype == PANGNN_DTYPE_F32 || g_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
-               "pangnn_colsum_small: storage types are PANGNN_DTYPE_F32 / PANGNN_DTYPE_BF16");
-  const bool bf = g_dtype == PANGNN_DTYPE_BF16;
+  PG_CHECK_ARG(g_dtype == PANGNN_DTYPE_F32 || g_dtype == PANGNN_DTYPE_BF16 || g_dtype == PANGNN_DTYPE_F16, PANGNN_E_BADARG,
+               "pangnn_colsum_small: storage types are PANGNN_DTYPE_F32 / _BF16 / _F16");
+  const bool bf = g_dtype != PANGNN_DTYPE_F32;
   const bool vec = F % 4 == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(g) & (bf ? 7u : 15u)) == 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(1), block(kSumThreads);
-  if (bf && vec)
-    hipLaunchKernelGGL((colsum_small_kernel<uint16_t, 4>), grid, block, 0, st, static_cast<const uint16_t*>(g), ldg, n, (int)F, out);
-  else if (bf)
-    hipLaunchKernelGGL((colsum_small_kernel<uint16_t, 1>), grid, block, 0, st, static_cast<const uint16_t*>(g), ldg, n, (int)F, out);
-  else if (vec)
-    hipLaunchKernelGGL((colsum_small_kernel<float, 4>), grid, block, 0, st, static_cast<const float*>(g), ldg, n, (int)F, out);
-  else
-    hipLaunchKernelGGL((colsum_small_kernel<float, 1>), grid, block, 0, st, static_cast<const float*>(g), ldg, n, (int)F, out);
+#define PG_CS(T, V) hipLaunchKernelGGL((colsum_small_kernel<T, V>), grid, block, 0, st, static_cast<const T*>(g), ldg, n, (int)F, out)
+  if (g_dtype == PANGNN_DTYPE_F16) { if (vec) PG_CS(_Float16, 4); else PG_CS(_Float16, 1); }
+  else if (bf) { if (vec) PG_CS(unsigned short, 4); else PG_CS(unsigned short, 1); }
+  else if (vec) PG_CS(float, 4);
+  else PG_CS(float, 1);
+#undef PG_CS
   PG_CHECK_LAUNCH("pangnn_colsum_small");
   return 0;
 }
@@ -855,8 +849,8 @@ extern "C" int pangnn_rank2_rows(const float* r, const float* s, const float* a,
   const char* who = "pangnn_rank2_rows";
   PG_CHECK_ARG(n >= 0 && F > 0 && F % 4 == 0 && F <= 4 * kBlock && (4 * kBlock) % F == 0 && ldo >= F && ldo % 4 == 0,
                PANGNN_E_BADARG, "%s: F must be a multiple of 4 dividing 1024, ldo >= F and a multiple of 4 (got %d)", who, (int)F);
-  PG_CHECK_ARG(out_dtype == PANGNN_DTYPE_F32 || out_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
-               "%s: out_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  PG_CHECK_ARG(out_dtype == PANGNN_DTYPE_F32 || out_dtype == PANGNN_DTYPE_BF16 || out_dtype == PANGNN_DTYPE_F16, PANGNN_E_BADARG,
+               "%s: out_dtype is PANGNN_DTYPE_F32 / _BF16 / _F16", who);
   if (n == 0) return 0;
   PG_CHECK_ARG(r && s && a && c && out, PANGNN_E_BADARG, "%s: null pointer", who);
   PG_CHECK_ARG(aligned16(a) && aligned16(c) && (!bias || aligned16(bias)) &&
@@ -868,6 +862,9 @@ extern "C" int pangnn_rank2_rows(const float* r, const float* s, const float* a,
   if (out_dtype == PANGNN_DTYPE_F32)
     hipLaunchKernelGGL(rank2_rows_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r, s, a, c, bias,
                        static_cast<float*>(out), ldo, n, (int)F);
+  else if (out_dtype == PANGNN_DTYPE_F16)
+    hipLaunchKernelGGL(rank2_rows_kernel<_Float16>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r, s, a,
+                       c, bias, static_cast<_Float16*>(out), ldo, n, (int)F);
   else
     hipLaunchKernelGGL(rank2_rows_kernel<unsigned short>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r, s, a,
                        c, bias, static_cast<unsigned short*>(out), ldo, n, (int)F);
@@ -881,8 +878,8 @@ extern "C" int pangnn_embed_conv_in_rows(const float* r, const float* s, const f
   const char* who = "pangnn_embed_conv_in_rows";
   PG_CHECK_ARG(n >= 0 && D > 0 && H > 0 && H % 4 == 0 && H <= kBlock && (4 * kBlock) % H == 0 && ldo >= H && ldo % 4 == 0,
                PANGNN_E_BADARG, "%s: H must be a multiple of 4 dividing 1024, at most 256; ldo >= H (H=%d)", who, (int)H);
-  PG_CHECK_ARG(out_dtype == PANGNN_DTYPE_F32 || out_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
-               "%s: out_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  PG_CHECK_ARG(out_dtype == PANGNN_DTYPE_F32 || out_dtype == PANGNN_DTYPE_BF16 || out_dtype == PANGNN_DTYPE_F16, PANGNN_E_BADARG,
+               "%s: out_dtype is PANGNN_DTYPE_F32 / _BF16 / _F16", who);
   if (n == 0) return 0;
   PG_CHECK_ARG(r && s && w_emb && b_emb && w_in && out, PANGNN_E_BADARG, "%s: null pointer", who);
   PG_CHECK_ARG((!b_in || aligned16(b_in)) &&
@@ -894,6 +891,9 @@ extern "C" int pangnn_embed_conv_in_rows(const float* r, const float* s, const f
   if (out_dtype == PANGNN_DTYPE_F32)
     hipLaunchKernelGGL(embed_conv_in_rows_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r, s, w_emb,
                        b_emb, w_in, b_in, (int)D, static_cast<float*>(out), ldo, n, (int)H);
+  else if (out_dtype == PANGNN_DTYPE_F16)
+    hipLaunchKernelGGL(embed_conv_in_rows_kernel<_Float16>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r,
+                       s, w_emb, b_emb, w_in, b_in, (int)D, static_cast<_Float16*>(out), ldo, n, (int)H);
   else
     hipLaunchKernelGGL(embed_conv_in_rows_kernel<unsigned short>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r,
                        s, w_emb, b_emb, w_in, b_in, (int)D, static_cast<unsigned short*>(out), ldo, n, (int)H);
@@ -911,8 +911,8 @@ extern "C" int pangnn_weighted_colsum3(const void* g, int32_t g_dtype, int64_t l
   const char* who = "pangnn_weighted_colsum3";
   PG_CHECK_ARG(n >= 0 && F > 0 && F % 4 == 0 && F <= kBlock && (4 * kBlock) % F == 0 && ldg >= F && ldg % 4 == 0,
                PANGNN_E_BADARG, "%s: F must be a multiple of 4 dividing 1024, at most 256; ldg >= F and a multiple of 4 (got %d)", who, (int)F);
-  PG_CHECK_ARG(g_dtype == PANGNN_DTYPE_F32 || g_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
-               "%s: g_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  PG_CHECK_ARG(g_dtype == PANGNN_DTYPE_F32 || g_dtype == PANGNN_DTYPE_BF16 || g_dtype == PANGNN_DTYPE_F16, PANGNN_E_BADARG,
+               "%s: g_dtype is PANGNN_DTYPE_F32 / _BF16 / _F16", who);
   PG_CHECK_ARG(out && (n == 0 || (g && r && s)), PANGNN_E_BADARG, "%s: null pointer", who);
   PG_CHECK_ARG(workspace && workspace_bytes >= pangnn_weighted_colsum3_workspace_bytes(F), PANGNN_E_WORKSPACE,
                "%s: workspace too small (%zu < %zu)", who, workspace_bytes, pangnn_weighted_colsum3_workspace_bytes(F));
@@ -926,6 +926,9 @@ extern "C" int pangnn_weighted_colsum3(const void* g, int32_t g_dtype, int64_t l
   if (g_dtype == PANGNN_DTYPE_F32)
     hipLaunchKernelGGL(weighted_colsum3_kernel<float>, dim3(blocks), dim3(kBlock), 0, st, static_cast<const float*>(g), ldg, r,
                        s, n, (int)F, static_cast<float*>(workspace));
+  else if (g_dtype == PANGNN_DTYPE_F16)
+    hipLaunchKernelGGL(weighted_colsum3_kernel<_Float16>, dim3(blocks), dim3(kBlock), 0, st,
+                       static_cast<const _Float16*>(g), ldg, r, s, n, (int)F, static_cast<float*>(workspace));
   else
     hipLaunchKernelGGL(weighted_colsum3_kernel<unsigned short>, dim3(blocks), dim3(kBlock), 0, st,
                        static_cast<const unsigned short*>(g), ldg, r, s, n, (int)F, static_cast<float*>(workspace));

@@ -336,9 +336,9 @@ at::Tensor spmm_rows(const Csr& csr, const at::Tensor& val, const at::Tensor& x,
              "pangnn_spmm_csr_f32(long-row parts)");
     return out;
   }
-  const bool bf16 = x.scalar_type() == at::kBFloat16 && (f == 32 || f == 64 || f == 128 || f == 256);
+  const bool rows16 = is_rows16(x) && (f == 32 || f == 64 || f == 128 || f == 256);
   at::Tensor xc;
-  if (bf16) {
+  if (rows16) {
     const bool ok = x.stride(1) == 1 && x.stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(x.data_ptr()) % 8 == 0;
     xc = ok ? x : x.contiguous();
   } else {
@@ -346,13 +346,14 @@ at::Tensor spmm_rows(const Csr& csr, const at::Tensor& val, const at::Tensor& x,
   }
   const auto bc = f32c(bias);
   auto out = at::empty({n_rows, f}, x.options().dtype(at::kFloat));
-  const int rc = bf16 ? pangnn_spmm_csr_bf16(csr.rowptr.data_ptr<int64_t>(), csr.other.data_ptr<int32_t>(), val.data_ptr<float>(),
-                                             xc.data_ptr(), xc.stride(0), xc.size(0), opt_ptr<float>(bc), out.data_ptr<float>(),
-                                             out.stride(0), n_rows, csr.other.size(0), (int32_t)f, 0, stream_of(x))
-                      : pangnn_spmm_csr_f32(csr.rowptr.data_ptr<int64_t>(), csr.other.data_ptr<int32_t>(), val.data_ptr<float>(),
-                                            xc.data_ptr<float>(), xc.stride(0), xc.size(0), opt_ptr<float>(bc),
-                                            out.data_ptr<float>(), out.stride(0), n_rows, csr.other.size(0), (int32_t)f, 0,
-                                            stream_of(x));
+  const auto fn16 = xc.scalar_type() == at::kHalf ? pangnn_spmm_csr_f16 : pangnn_spmm_csr_bf16;
+  const int rc = rows16 ? fn16(csr.rowptr.data_ptr<int64_t>(), csr.other.data_ptr<int32_t>(), val.data_ptr<float>(), xc.data_ptr(),
+                               xc.stride(0), xc.size(0), opt_ptr<float>(bc), out.data_ptr<float>(), out.stride(0), n_rows,
+                               csr.other.size(0), (int32_t)f, 0, stream_of(x))
+                        : pangnn_spmm_csr_f32(csr.rowptr.data_ptr<int64_t>(), csr.other.data_ptr<int32_t>(), val.data_ptr<float>(),
+                                              xc.data_ptr<float>(), xc.stride(0), xc.size(0), opt_ptr<float>(bc),
+                                              out.data_ptr<float>(), out.stride(0), n_rows, csr.other.size(0), (int32_t)f, 0,
+                                              stream_of(x));
   check_rc(rc, "pangnn_spmm_csr");
   return out;
 }
@@ -360,7 +361,7 @@ at::Tensor spmm_rows(const Csr& csr, const at::Tensor& val, const at::Tensor& x,
 // column sums of dL/dout in fp32 (GCNConv's bias gradient): one launch for the short matrices of a mini-batch
 at::Tensor colsum(const at::Tensor& g) {
   if (g.dim() == 2 && g.size(0) <= 4096 && g.stride(1) == 1 && g.size(1) > 0 && g.size(1) <= 1024 &&
-      (g.scalar_type() == at::kFloat || g.scalar_type() == at::kBFloat16)) {
+      (g.scalar_type() == at::kFloat || is_rows16(g))) {
     auto out = at::empty({g.size(1)}, g.options().dtype(at::kFloat));
     check_rc(pangnn_colsum_small(g.data_ptr(), dtype_code(g), g.stride(0), g.size(0), (int32_t)g.size(1), out.data_ptr<float>(),
                                  stream_of(g)),
@@ -399,7 +400,7 @@ std::pair<at::Tensor, at::Tensor> band_call(const at::Tensor& x, const c10::opti
 // gcn_propagate: A_hat x + bias  (PyG MessagePassing.propagate + GCNConv.message + bias, gnn.py:158,165)
 // ---------------------------------------------------------------------------------------------------------------
 at::Tensor gcn_propagate(const at::Tensor& x, const c10::optional<at::Tensor>& bias, const at::Tensor& edge_index,
-                         const c10::optional<at::Tensor>& edge_weight, bool allow_band, bool out_bf16) {
+                         const c10::optional<at::Tensor>& edge_weight, bool allow_band, int64_t out_dtype) {
   on_gpu(x, "x");
   TORCH_CHECK(x.dim() == 2 && x.is_floating_point(), "pangnn::gcn_propagate: x must be a floating-point [N, F]");
   operand_any_float("gcn_propagate", "bias", bias, x);
@@ -413,12 +414,12 @@ at::Tensor gcn_propagate(const at::Tensor& x, const c10::optional<at::Tensor>& b
   at::Tensor y;
   if (maybe_band && band_ok(x, v, unit)) y = band_call(x, bias, v.dis, v.band, false).first;
   else y = spmm_rows(v.by_dst, v.norm_dst, x, v.n_dst, bias);
-  return out_bf16 ? y.to(at::kBFloat16) : y;
+  return out_dtype ? y.to(scalar_of(out_dtype)) : y;
 }
 
 std::tuple<at::Tensor, at::Tensor> gcn_propagate_backward(const at::Tensor& g, const at::Tensor& edge_index,
                                                          const c10::optional<at::Tensor>& edge_weight, bool allow_band,
-                                                         bool has_bias, bool x_bf16) {
+                                                         bool has_bias, int64_t x_dtype) {
   on_gpu(g, "g");
   TORCH_CHECK(g.dim() == 2 && g.is_floating_point(), "pangnn::gcn_propagate_backward: g must be a floating-point [N, F]");
   const DeviceGuard guard(g.device());
@@ -434,12 +435,12 @@ std::tuple<at::Tensor, at::Tensor> gcn_propagate_backward(const at::Tensor& g, c
   } else {
     const View vs = lookup("gcn_propagate_backward", edge_index, g.size(0), edge_weight, c10::nullopt, kBySrc | kNorm | kNormSrc);
     const int64_t f = g.size(1);
-    const bool keep_bf16 = g.scalar_type() == at::kBFloat16 && (f == 32 || f == 64 || f == 128 || f == 256);
-    const at::Tensor gg = keep_bf16 ? g : f32c(g);
+    const bool keep16 = is_rows16(g) && (f == 32 || f == 64 || f == 128 || f == 256);
+    const at::Tensor gg = keep16 ? g : f32c(g);
     gx = spmm_rows(vs.by_src, vs.norm_src, gg, vs.n_src, c10::nullopt);
     if (has_bias) gb = colsum(gg);
   }
-  if (x_bf16) gx = gx.to(at::kBFloat16);
+  if (x_dtype) gx = gx.to(scalar_of(x_dtype));
   if (!gb.defined()) gb = at::empty({0}, g.options().dtype(at::kFloat));
   return {gx, gb};
 }
@@ -470,11 +471,11 @@ FirstLayer first_layer(const char* op, const at::Tensor& x, const at::Tensor& w,
 
 at::Tensor embed_conv_in(const at::Tensor& x, const at::Tensor& w, const at::Tensor& b, const at::Tensor& w_in,
                          const c10::optional<at::Tensor>& b_in, const at::Tensor& edge_index,
-                         const c10::optional<at::Tensor>& edge_weight, bool out_bf16) {
+                         const c10::optional<at::Tensor>& edge_weight, int64_t out_dtype) {
   const FirstLayer p = first_layer("embed_conv_in", x, w, b, w_in, b_in);
   const DeviceGuard guard(x.device());
   const View v = lookup("embed_conv_in", edge_index, p.n, edge_weight, x, kByDst | kNorm | kActions);
-  auto out = at::empty({p.n, p.h}, p.win.options().dtype(out_bf16 ? at::kBFloat16 : at::kFloat));
+  auto out = at::empty({p.n, p.h}, p.win.options().dtype(scalar_of(out_dtype)));
   check_rc(pangnn_embed_conv_in_rows(v.r.data_ptr<float>(), v.s.data_ptr<float>(), p.wv.data_ptr<float>(), p.bv.data_ptr<float>(),
                                      p.win.data_ptr<float>(), opt_ptr<float>(p.bin), (int32_t)p.d, out.data_ptr(), dtype_code(out),
                                      out.stride(0), p.n, (int32_t)p.h, stream_of(x)),
@@ -769,43 +770,43 @@ OptT opt_of(const at::Tensor& t) { return t.defined() ? OptT(t) : OptT(); }
 class GcnPropagateFunction : public torch::autograd::Function<GcnPropagateFunction> {
  public:
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const OptT& bias, const at::Tensor& edge_index,
-                            const OptT& edge_weight, bool allow_band, bool out_bf16) {
+                            const OptT& edge_weight, bool allow_band, int64_t out_dtype) {
     at::AutoDispatchBelowADInplaceOrView below;
     ctx->save_for_backward({edge_index, or_undef(edge_weight)});
     ctx->saved_data["allow_band"] = allow_band;
     ctx->saved_data["has_bias"] = defined(bias);
-    ctx->saved_data["x_bf16"] = x.scalar_type() == at::kBFloat16;
-    static auto op = typed_op<at::Tensor(const at::Tensor&, const OptT&, const at::Tensor&, const OptT&, bool, bool)>(
+    ctx->saved_data["x_dtype"] = (int64_t)dtype_code(x);
+    static auto op = typed_op<at::Tensor(const at::Tensor&, const OptT&, const at::Tensor&, const OptT&, bool, int64_t)>(
         "pangnn::gcn_propagate");
-    return op.call(x, bias, edge_index, edge_weight, allow_band, out_bf16);
+    return op.call(x, bias, edge_index, edge_weight, allow_band, out_dtype);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto saved = ctx->get_saved_variables();
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
-    static auto op = typed_op<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const OptT&, bool, bool, bool)>(
+    static auto op = typed_op<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const OptT&, bool, bool, int64_t)>(
         "pangnn::gcn_propagate_backward");
     auto [gx, gb] = op.call(grads[0], saved[0], opt_of(saved[1]), ctx->saved_data["allow_band"].toBool(), has_bias,
-                            ctx->saved_data["x_bf16"].toBool());
+                            ctx->saved_data["x_dtype"].toInt());
     return {ctx->needs_input_grad(0) ? gx : at::Tensor(), has_bias ? gb : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
             at::Tensor()};
   }
 };
 at::Tensor gcn_propagate_autograd(const at::Tensor& x, const OptT& bias, const at::Tensor& edge_index, const OptT& edge_weight,
-                                  bool allow_band, bool out_bf16) {
-  return GcnPropagateFunction::apply(x, bias, edge_index, edge_weight, allow_band, out_bf16);
+                                  bool allow_band, int64_t out_dtype) {
+  return GcnPropagateFunction::apply(x, bias, edge_index, edge_weight, allow_band, out_dtype);
 }
 
 class EmbedConvInFunction : public torch::autograd::Function<EmbedConvInFunction> {
  public:
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w, const at::Tensor& b,
                             const at::Tensor& w_in, const OptT& b_in, const at::Tensor& edge_index, const OptT& edge_weight,
-                            bool out_bf16) {
+                            int64_t out_dtype) {
     at::AutoDispatchBelowADInplaceOrView below;
     ctx->save_for_backward({x, w, b, w_in, edge_index, or_undef(edge_weight)});
     ctx->saved_data["has_bias"] = defined(b_in);
     static auto op = typed_op<at::Tensor(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&, const OptT&,
-                                         const at::Tensor&, const OptT&, bool)>("pangnn::embed_conv_in");
-    return op.call(x, w, b, w_in, b_in, edge_index, edge_weight, out_bf16);
+                                         const at::Tensor&, const OptT&, int64_t)>("pangnn::embed_conv_in");
+    return op.call(x, w, b, w_in, b_in, edge_index, edge_weight, out_dtype);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto s = ctx->get_saved_variables();
@@ -819,8 +820,8 @@ class EmbedConvInFunction : public torch::autograd::Function<EmbedConvInFunction
   }
 };
 at::Tensor embed_conv_in_autograd(const at::Tensor& x, const at::Tensor& w, const at::Tensor& b, const at::Tensor& w_in,
-                                  const OptT& b_in, const at::Tensor& edge_index, const OptT& edge_weight, bool out_bf16) {
-  return EmbedConvInFunction::apply(x, w, b, w_in, b_in, edge_index, edge_weight, out_bf16);
+                                  const OptT& b_in, const at::Tensor& edge_index, const OptT& edge_weight, int64_t out_dtype) {
+  return EmbedConvInFunction::apply(x, w, b, w_in, b_in, edge_index, edge_weight, out_dtype);
 }
 
 class EmbedConvInLinearFunction : public torch::autograd::Function<EmbedConvInLinearFunction> {
@@ -1003,11 +1004,11 @@ TORCH_LIBRARY_FRAGMENT(pangnn, m) {
   m.def("_registry_forget(Tensor edge_index, int n_dst) -> ()");
   m.def("_set_unit_grad(Tensor t) -> ()");
   // the per-step operators that read a graph
-  m.def("gcn_propagate(Tensor x, Tensor? bias, Tensor edge_index, Tensor? edge_weight, bool allow_band, bool out_bf16) -> Tensor");
-  m.def("gcn_propagate_backward(Tensor g, Tensor edge_index, Tensor? edge_weight, bool allow_band, bool has_bias, bool x_bf16) -> "
+  m.def("gcn_propagate(Tensor x, Tensor? bias, Tensor edge_index, Tensor? edge_weight, bool allow_band, int out_dtype) -> Tensor");
+  m.def("gcn_propagate_backward(Tensor g, Tensor edge_index, Tensor? edge_weight, bool allow_band, bool has_bias, int x_dtype) -> "
         "(Tensor, Tensor)");
   m.def("embed_conv_in(Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor? b_in, Tensor edge_index, Tensor? edge_weight, "
-        "bool out_bf16) -> Tensor");
+        "int out_dtype) -> Tensor");
   m.def("embed_conv_in_backward(Tensor g, Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor edge_index, Tensor? edge_weight, "
         "bool has_bias) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("embed_conv_in_linear(Tensor x, Tensor w, Tensor b, Tensor w_in, Tensor? b_in, Tensor w_out, Tensor? bias_out, "

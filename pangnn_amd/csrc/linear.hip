@@ -84,6 +84,35 @@ template <> struct Elem<bf16s> {
   }
 };
 
+// IEEE half rows (`--mixed_precision fp16`, src/setup.py:50: the autocast Linear outputs are float16 tensors): the same
+// 2-byte row streams, f16 -> f32 exact (v_cvt_f32_f16), f32 -> f16 rounds to nearest even (v_cvt_f16_f32)
+struct f16s { unsigned short bits; };
+template <> struct Elem<f16s> {
+  typedef uint2 raw4;
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ raw4 ld4(const f16s* ubase, uint32_t byte_off) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(ubase) + byte_off));
+    return make_uint2(t[0], t[1]);
+  }
+  static __device__ __forceinline__ raw4 ld4_plain(const f16s* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ raw4 zero4() { return make_uint2(0u, 0u); }
+  static __device__ __forceinline__ float4 cvt4(raw4 r) {
+    const h2 a = __builtin_bit_cast(h2, r.x), b = __builtin_bit_cast(h2, r.y);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+  }
+  static __device__ __forceinline__ float ld1(const f16s* ubase, uint32_t byte_off) {
+    return (float)*reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(ubase) + byte_off);
+  }
+  static __device__ __forceinline__ void st1(f16s* ubase, uint32_t byte_off, float v) {
+    // the value is rounded to f32 FIRST (as every other storage type sees it), then to nearest-even f16: without the barrier the
+    // compiler folds a preceding multiply into v_fma_mixlo_f16 — one rounding of the exact product, one ulp away from the f32
+    // kernel's result in about one element of 10^4
+    asm volatile("" : "+v"(v));
+    *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(ubase) + byte_off) = (_Float16)v;
+  }
+};
+
 // rows [base, base+32) of a [n, C] matrix (leading dim ld): issued into registers one tile ahead
 // (`load_rows`), written to the LDS tile [32][C+4] when the previous tile's MFMAs are done
 // (`store_rows`); rows >= n are zero.
@@ -674,19 +703,20 @@ static int launch_fwd_t(const void* x, int64_t ldx, const float* w, int w_trans,
 }
 
 // storage-type dispatch.  A gated product (dL/dx of "dense after ELU") writes the gradient of the gate tensor, so its
-// result is stored like the gate: (TG, TY) is (f32, f32) or (bf16, bf16).
-template <int K, int M>
-static int launch_fwd(const void* x, int x_bf16, int64_t ldx, const float* w, int w_trans, const float* bias, void* y,
-                      int y_bf16, int64_t ldy, int64_t n, int in_act, const void* gate, int gate_bf16, int64_t ldgate,
+// result is stored like the gate: (TG, TY) is (f32, f32) or (H, H).  H: the 2-byte format of this call's 16-bit operands
+// (bf16s or f16s — one call never mixes the two; x16 / y16 / gate16 say which operands are stored in it).
+template <int K, int M, typename H>
+static int launch_fwd(const void* x, int x16, int64_t ldx, const float* w, int w_trans, const float* bias, void* y,
+                      int y16, int64_t ldy, int64_t n, int in_act, const void* gate, int gate16, int64_t ldgate,
                       hipStream_t s) {
 #define PG_FWD(TX, TY, TG) return launch_fwd_t<K, M, TX, TY, TG>(x, ldx, w, w_trans, bias, y, ldy, n, in_act, gate, ldgate, s)
   if (gate) {
-    if (gate_bf16) { if (x_bf16) PG_FWD(bf16s, bf16s, bf16s); PG_FWD(float, bf16s, bf16s); }
-    if (x_bf16) PG_FWD(bf16s, float, float);
+    if (gate16) { if (x16) PG_FWD(H, H, H); PG_FWD(float, H, H); }
+    if (x16) PG_FWD(H, float, float);
     PG_FWD(float, float, float);
   }
-  if (x_bf16) { if (y_bf16) PG_FWD(bf16s, bf16s, float); PG_FWD(bf16s, float, float); }
-  if (y_bf16) PG_FWD(float, bf16s, float);
+  if (x16) { if (y16) PG_FWD(H, H, float); PG_FWD(H, float, float); }
+  if (y16) PG_FWD(float, H, float);
   PG_FWD(float, float, float);
 #undef PG_FWD
 }
@@ -717,12 +747,12 @@ static int launch_wgrad_t(const void* g, int64_t ldg, const void* x, int64_t ldx
   return 0;
 }
 
-template <int K, int M>
-static int launch_wgrad(const void* g, int g_bf16, int64_t ldg, const void* x, int x_bf16, int64_t ldx, int64_t n,
+template <int K, int M, typename H>
+static int launch_wgrad(const void* g, int g16, int64_t ldg, const void* x, int x16, int64_t ldx, int64_t n,
                         int in_act, float* gw, float* gb, float* ws, size_t ws_bytes, hipStream_t s) {
 #define PG_WG(TG, TX) return launch_wgrad_t<K, M, TG, TX>(g, ldg, x, ldx, n, in_act, gw, gb, ws, ws_bytes, s)
-  if (g_bf16) { if (x_bf16) PG_WG(bf16s, bf16s); PG_WG(bf16s, float); }
-  if (x_bf16) PG_WG(float, bf16s);
+  if (g16) { if (x16) PG_WG(H, H); PG_WG(H, float); }
+  if (x16) PG_WG(float, H);
   PG_WG(float, float);
 #undef PG_WG
 }
@@ -1129,7 +1159,17 @@ extern "C" int pangnn_linear_supported(int32_t K, int32_t M, int wgrad) {
   return 1;
 }
 
-static bool dtype_ok(int32_t d) { return d == PANGNN_DTYPE_F32 || d == PANGNN_DTYPE_BF16; }
+static bool dtype_ok(int32_t d) { return d == PANGNN_DTYPE_F32 || d == PANGNN_DTYPE_BF16 || d == PANGNN_DTYPE_F16; }
+// the one 2-byte format of a call's operands (0 when all are f32), -1 when bfloat16 and float16 operands are mixed
+static int fmt16_of(int32_t a, int32_t b, int32_t c = PANGNN_DTYPE_F32) {
+  int f = 0;
+  for (int32_t d : {a, b, c}) {
+    if (d == PANGNN_DTYPE_F32) continue;
+    if (f && f != d) return -1;
+    f = d;
+  }
+  return f;
+}
 static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 static int linear_fwd_common(const void* x, int32_t x_dtype, int64_t ldx, const float* w, int w_trans, const float* bias,
@@ -1139,21 +1179,29 @@ static int linear_fwd_common(const void* x, int32_t x_dtype, int64_t ldx, const 
   PG_CHECK_ARG(pangnn_linear_supported(K, M, 0), PANGNN_E_BADARG,
                "pangnn_linear_fwd: K and M must be 64 or 128 (got %d, %d)", (int)K, (int)M);
   PG_CHECK_ARG(dtype_ok(x_dtype) && dtype_ok(y_dtype) && (!gate || dtype_ok(gate_dtype)), PANGNN_E_BADARG,
-               "pangnn_linear_fwd: storage types are PANGNN_DTYPE_F32 / PANGNN_DTYPE_BF16");
+               "pangnn_linear_fwd: storage types are PANGNN_DTYPE_F32 / _BF16 / _F16");
   PG_CHECK_ARG((in_act == 0 || in_act == 1) && !(in_act && gate) && (!gate || ldgate >= M), PANGNN_E_BADARG,
                "pangnn_linear_act_fwd: in_act must be 0 or 1 (ELU) and excludes gate; ldgate >= M");
   PG_CHECK_ARG(!gate || gate_dtype == y_dtype, PANGNN_E_BADARG,
                "pangnn_linear_act_fwd: a gated product is stored like its gate (it is the gate tensor's gradient)");
   if (n == 0) return 0;
   PG_CHECK_ARG(x && w && y && ldx >= K && ldy >= M, PANGNN_E_BADARG, "pangnn_linear_fwd: bad pointer / ld");
-  PG_CHECK_ARG((x_dtype == PANGNN_DTYPE_BF16 ? aligned8(x) : aligned16(x)) && aligned16(w) && ldx % 4 == 0,
-               PANGNN_E_ALIGN, "pangnn_linear_fwd: x rows must start on 16 bytes (f32) / 8 bytes (bf16), w on 16, ldx % 4 == 0");
+  PG_CHECK_ARG((x_dtype != PANGNN_DTYPE_F32 ? aligned8(x) : aligned16(x)) && aligned16(w) && ldx % 4 == 0,
+               PANGNN_E_ALIGN, "pangnn_linear_fwd: x rows must start on 16 bytes (f32) / 8 bytes (bf16, f16), w on 16, ldx % 4 == 0");
+  const int fmt = fmt16_of(x_dtype, y_dtype, gate ? gate_dtype : PANGNN_DTYPE_F32);
+  PG_CHECK_ARG(fmt >= 0, PANGNN_E_BADARG, "pangnn_linear_fwd: the 2-byte operands of one call are all bfloat16 or all float16");
   hipStream_t s = (hipStream_t)stream;
-  const int xb = x_dtype == PANGNN_DTYPE_BF16, yb = y_dtype == PANGNN_DTYPE_BF16, gb = gate_dtype == PANGNN_DTYPE_BF16;
-  if (K == 64 && M == 64) return launch_fwd<64, 64>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
-  if (K == 64 && M == 128) return launch_fwd<64, 128>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
-  if (K == 128 && M == 64) return launch_fwd<128, 64>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
-  return launch_fwd<128, 128>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);
+  const int xb = x_dtype != PANGNN_DTYPE_F32, yb = y_dtype != PANGNN_DTYPE_F32, gb = gate && gate_dtype != PANGNN_DTYPE_F32;
+#define PG_SHAPES(H)                                                                                                              \
+  do {                                                                                                                            \
+    if (K == 64 && M == 64) return launch_fwd<64, 64, H>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);   \
+    if (K == 64 && M == 128) return launch_fwd<64, 128, H>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s); \
+    if (K == 128 && M == 64) return launch_fwd<128, 64, H>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s); \
+    return launch_fwd<128, 128, H>(x, xb, ldx, w, w_trans, bias, y, yb, ldy, n, in_act, gate, gb, ldgate, s);                         \
+  } while (0)
+  if (fmt == PANGNN_DTYPE_F16) PG_SHAPES(f16s);
+  PG_SHAPES(bf16s);
+#undef PG_SHAPES
 }
 
 extern "C" int pangnn_linear_act_fwd_mixed(const void* x, int32_t x_dtype, int64_t ldx, const float* w, const float* bias,
@@ -1195,27 +1243,35 @@ extern "C" int pangnn_linear_act_wgrad_mixed(const void* g, int32_t g_dtype, int
                "pangnn_linear_wgrad: unsupported (K, M) = (%d, %d)", (int)K, (int)M);
   PG_CHECK_ARG(in_act == 0 || in_act == 1, PANGNN_E_BADARG, "pangnn_linear_act_wgrad: in_act must be 0 or 1");
   PG_CHECK_ARG(dtype_ok(g_dtype) && dtype_ok(x_dtype), PANGNN_E_BADARG,
-               "pangnn_linear_wgrad: storage types are PANGNN_DTYPE_F32 / PANGNN_DTYPE_BF16");
+               "pangnn_linear_wgrad: storage types are PANGNN_DTYPE_F32 / _BF16 / _F16");
   PG_CHECK_ARG(gw && (n == 0 || (g && x)) && ldg >= M && ldx >= K, PANGNN_E_BADARG,
                "pangnn_linear_wgrad: bad pointer / ld");
-  PG_CHECK_ARG((g_dtype == PANGNN_DTYPE_BF16 ? aligned8(g) : aligned16(g)) &&
-                   (x_dtype == PANGNN_DTYPE_BF16 ? aligned8(x) : aligned16(x)) && ldg % 4 == 0 && ldx % 4 == 0,
-               PANGNN_E_ALIGN, "pangnn_linear_wgrad: rows must start on 16 bytes (f32) / 8 bytes (bf16), ld multiples of 4");
+  PG_CHECK_ARG((g_dtype != PANGNN_DTYPE_F32 ? aligned8(g) : aligned16(g)) &&
+                   (x_dtype != PANGNN_DTYPE_F32 ? aligned8(x) : aligned16(x)) && ldg % 4 == 0 && ldx % 4 == 0,
+               PANGNN_E_ALIGN, "pangnn_linear_wgrad: rows must start on 16 bytes (f32) / 8 bytes (bf16, f16), ld multiples of 4");
+  const int fmt = fmt16_of(g_dtype, x_dtype);
+  PG_CHECK_ARG(fmt >= 0, PANGNN_E_BADARG, "pangnn_linear_wgrad: the 2-byte operands of one call are all bfloat16 or all float16");
   hipStream_t s = (hipStream_t)stream;
   float* ws = static_cast<float*>(workspace);
-  const int gbf = g_dtype == PANGNN_DTYPE_BF16, xbf = x_dtype == PANGNN_DTYPE_BF16;
-  if (K == 64 && M == 64) return launch_wgrad<64, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
-  if (K == 64 && M == 128) return launch_wgrad<64, 128>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
-  if (K == 128 && M == 128) {
-    // dW[0:64) from g[:, 0:64), dW[64:128) from g[:, 64:128): the <128, 64> kernel twice over column windows of g (same ldg),
-    // stream-ordered on one workspace.  x is read twice (N * 512 B more than a single pass would need).
-    const char* g_hi = static_cast<const char*>(g) + (size_t)64 * (gbf ? 2 : 4);
-    int rc = launch_wgrad<128, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
-    if (rc) return rc;
-    return launch_wgrad<128, 64>(g_hi, gbf, ldg, x, xbf, ldx, n, in_act, gw + (size_t)64 * 128, gb ? gb + 64 : nullptr, ws,
-                                 workspace_bytes, s);
-  }
-  return launch_wgrad<128, 64>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);
+  const int gbf = g_dtype != PANGNN_DTYPE_F32, xbf = x_dtype != PANGNN_DTYPE_F32;
+#define PG_SHAPES(H)                                                                                                                 \
+  do {                                                                                                                               \
+    if (K == 64 && M == 64) return launch_wgrad<64, 64, H>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);      \
+    if (K == 64 && M == 128) return launch_wgrad<64, 128, H>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);    \
+    if (K == 128 && M == 128) {                                                                                                      \
+      /* dW[0:64) from g[:, 0:64), dW[64:128) from g[:, 64:128): the <128, 64> kernel twice over column windows of g (same ldg), */  \
+      /* stream-ordered on one workspace.  x is read twice (N * 512 B more than a single pass would need). */                        \
+      const char* g_hi = static_cast<const char*>(g) + (size_t)64 * (gbf ? 2 : 4);                                                   \
+      int rc = launch_wgrad<128, 64, H>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);                         \
+      if (rc) return rc;                                                                                                             \
+      return launch_wgrad<128, 64, H>(g_hi, gbf, ldg, x, xbf, ldx, n, in_act, gw + (size_t)64 * 128, gb ? gb + 64 : nullptr, ws,      \
+                                      workspace_bytes, s);                                                                           \
+    }                                                                                                                                \
+    return launch_wgrad<128, 64, H>(g, gbf, ldg, x, xbf, ldx, n, in_act, gw, gb, ws, workspace_bytes, s);                             \
+  } while (0)
+  if (fmt == PANGNN_DTYPE_F16) PG_SHAPES(f16s);
+  PG_SHAPES(bf16s);
+#undef PG_SHAPES
 }
 
 extern "C" int pangnn_linear_act_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t n,

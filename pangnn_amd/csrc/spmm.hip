@@ -11,17 +11,16 @@
 
 namespace pangnn {
 
-// XBF: the gathered rows are stored as bfloat16 (8 bytes per lane instead of 16; SURVEY.md §8b `X f32/bf16`, the
-// storage format of config 5).  Weights, accumulation and the result stay fp32 — what PyG's propagate computes
-// under bf16 autocast (bf16 x_j times fp32 edge weight promotes to fp32, scatter-add into an fp32 output).
-__device__ __forceinline__ float4 row_piece(const char* p, bool xbf) {
-  if (!xbf) return *reinterpret_cast<const float4*>(p);
-  const uint2 t = *reinterpret_cast<const uint2*>(p);
-  return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
-                     __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+// XF: storage format of the gathered rows — 0 float32, 1 bfloat16, 2 float16 (PANGNN_DTYPE_*; the 2-byte formats: 8 bytes per
+// lane instead of 16; SURVEY.md §8b `X f32/bf16`, the storage format of config 5, and `--mixed_precision fp16`).  Weights,
+// accumulation and the result stay fp32 — what PyG's propagate computes under autocast (a 16-bit x_j times an fp32 edge
+// weight promotes to fp32, scatter-add into an fp32 output).
+__device__ __forceinline__ float4 row_piece(const char* p, int xf) {
+  if (!xf) return *reinterpret_cast<const float4*>(p);
+  return rows16_to_f32(*reinterpret_cast<const uint2*>(p), xf);
 }
 
-template <int F, int U, bool BIG, bool XBF = false>
+template <int F, int U, bool BIG, int XF = 0>
 __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
     const float* __restrict__ val, const float* __restrict__ x, int64_t ldx,
@@ -42,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
   const int64_t end = rowptr[row + 1];
 
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int ES = XBF ? 2 : 4;                     // bytes per stored element
+  constexpr int ES = XF ? 2 : 4;                      // bytes per stored element
   const char* xbase = reinterpret_cast<const char*>(x) + fl * 4 * ES;
   const uint32_t ldx_b32 = (uint32_t)(ldx * ES);
 
@@ -77,15 +76,15 @@ __global__ __launch_bounds__(kBlock) void spmm_row_kernel(
         const int c = __shfl(c_cur, k);
         vv[u] = __shfl(v_cur, k);
         if (k < cnt) {
-          if (BIG && !XBF) {
+          if (BIG && !XF) {
             // > 4 GiB tables are the per-edge gradient rows of the decoder: each row is read exactly once
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (int64_t)c * ldx * 4));
             xv[u] = make_float4(t[0], t[1], t[2], t[3]);
           } else if (BIG) {
-            xv[u] = row_piece(xbase + (int64_t)c * ldx * ES, XBF);
+            xv[u] = row_piece(xbase + (int64_t)c * ldx * ES, XF);
           } else {
-            xv[u] = row_piece(xbase + (uint32_t)c * ldx_b32, XBF);
+            xv[u] = row_piece(xbase + (uint32_t)c * ldx_b32, XF);
           }
         } else {
           xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -185,20 +184,20 @@ __global__ __launch_bounds__(kBlock) void spmm_row_generic_kernel(
   }
 }
 
-template <int F, int U>
-static int launch_spmm_bf16(const int64_t* rowptr, const int32_t* idx, const float* val, const void* x,
-                            int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
-                            int64_t n_rows, int accumulate, hipStream_t s) {
+template <int F, int U, int XF>
+static int launch_spmm_16(const int64_t* rowptr, const int32_t* idx, const float* val, const void* x,
+                          int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo,
+                          int64_t n_rows, int accumulate, hipStream_t s) {
   const int64_t blocks = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
   const bool big = (double)n_src_rows * (double)ldx * 2.0 >= 4294967296.0;
   const float* xf = static_cast<const float*>(x);
   if (big)
-    hipLaunchKernelGGL((spmm_row_kernel<F, U, true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL((spmm_row_kernel<F, U, true, XF>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
                        rowptr, idx, val, xf, ldx, bias, out, ldo, n_rows, accumulate);
   else
-    hipLaunchKernelGGL((spmm_row_kernel<F, U, false, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL((spmm_row_kernel<F, U, false, XF>), dim3((unsigned)blocks), dim3(kBlock), 0, s,
                        rowptr, idx, val, xf, ldx, bias, out, ldo, n_rows, accumulate);
-  PG_CHECK_LAUNCH("pangnn_spmm_csr_bf16");
+  PG_CHECK_LAUNCH("pangnn_spmm_csr_16");
   return 0;
 }
 
@@ -265,10 +264,8 @@ __global__ __launch_bounds__(kBlock) void band_propagate_kernel(const TX* __rest
       float4 xv;
       if constexpr (sizeof(TX) == 4) {
         xv = *reinterpret_cast<const float4*>(x + sidx * ldx + 4 * fl);
-      } else {
-        const uint2 r = *reinterpret_cast<const uint2*>(x + sidx * ldx + 4 * fl);
-        xv = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
-                         __uint_as_float(r.y & 0xffff0000u));
+      } else {       // TX = unsigned short: bfloat16 bits; TX = _Float16: IEEE half
+        xv = rows16_to_f32(*reinterpret_cast<const uint2*>(x + sidx * ldx + 4 * fl), RowFmt<TX>::value);
       }
       const float v = dis[sidx] * dt;                       // gcn_norm: (dis[src] * 1) * dis[dst]
       acc.x = fmaf(v, xv.x, acc.x);
@@ -302,14 +299,15 @@ __global__ __launch_bounds__(kSumThreads) void band_colsum_finish_kernel(const f
 constexpr int kBandBlocks = 2048;
 
 template <int F>
-static int launch_band(const void* x, int x_bf16, int64_t ldx, const float* dis, const float* bias, float* out, int64_t ldo,
+static int launch_band(const void* x, int x_fmt, int64_t ldx, const float* dis, const float* bias, float* out, int64_t ldo,
                        int64_t n, int k, float* colsum, float* ws, hipStream_t s) {
   constexpr int RPB = kBlock / (F / 4);
   int64_t blocks = (n + RPB - 1) / RPB;
   if (blocks > kBandBlocks) blocks = kBandBlocks;
   const dim3 g((unsigned)blocks), b(kBlock);
 #define PG_BAND(T, CS) hipLaunchKernelGGL((band_propagate_kernel<F, T, CS>), g, b, 0, s, static_cast<const T*>(x), ldx, dis, bias, out, ldo, n, k, ws)
-  if (x_bf16) { if (colsum) PG_BAND(unsigned short, true); else PG_BAND(unsigned short, false); }
+  if (x_fmt == PANGNN_DTYPE_F16) { if (colsum) PG_BAND(_Float16, true); else PG_BAND(_Float16, false); }
+  else if (x_fmt) { if (colsum) PG_BAND(unsigned short, true); else PG_BAND(unsigned short, false); }
   else { if (colsum) PG_BAND(float, true); else PG_BAND(float, false); }
 #undef PG_BAND
   PG_CHECK_LAUNCH("pangnn_band_propagate");
@@ -378,30 +376,52 @@ extern "C" int pangnn_segment_sum_rows_f32(const int64_t* rowptr, const int32_t*
                              out, ldo, n_rows, n_m_rows, F, accumulate, stream);
 }
 
+static int spmm_csr_16(const char* who, int fmt, const int64_t* rowptr, const int32_t* idx, const float* val, const void* x16,
+                       int64_t ldx, int64_t n_src_rows, const float* bias, float* out, int64_t ldo, int64_t n_rows, int32_t F,
+                       int accumulate, pangnn_stream_t stream) {
+  PG_CHECK_ARG(n_rows >= 0 && n_src_rows >= 0 && F > 0, PANGNN_E_BADARG, "%s: negative size", who);
+  if (n_rows == 0) return 0;
+  PG_CHECK_ARG(rowptr && out && (x16 || n_src_rows == 0) && ldx >= F && ldo >= F, PANGNN_E_BADARG,
+               "%s: null pointer / leading dimension smaller than F", who);
+  PG_CHECK_ARG((reinterpret_cast<uintptr_t>(x16) & 7u) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
+                   ldx % 4 == 0 && ldo % 4 == 0,
+               PANGNN_E_ALIGN, "%s: x must be 8-byte aligned, out / bias 16-byte, ld multiples of 4", who);
+  PG_CHECK_ARG((n_rows + kWavesPerBlock - 1) / kWavesPerBlock < 2147483647LL, PANGNN_E_TOOLARGE,
+               "%s: too many rows for one launch", who);
+  hipStream_t s = (hipStream_t)stream;
+#define PG_W(FW)                                                                                                              \
+  case FW:                                                                                                                    \
+    return fmt == PANGNN_DTYPE_F16                                                                                            \
+               ? launch_spmm_16<FW, 4, 2>(rowptr, idx, val, x16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s)       \
+               : launch_spmm_16<FW, 4, 1>(rowptr, idx, val, x16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s)
+  switch (F) {
+    PG_W(32);
+    PG_W(64);
+    PG_W(128);
+    PG_W(256);
+    default: break;
+  }
+#undef PG_W
+  set_error("%s: F must be 32, 64, 128 or 256 (got %d)", who, (int)F);
+  return PANGNN_E_BADARG;
+}
+
 extern "C" int pangnn_spmm_csr_bf16(const int64_t* rowptr, const int32_t* idx, const float* val,
                                     const void* x_bf16, int64_t ldx, int64_t n_src_rows,
                                     const float* bias, float* out, int64_t ldo, int64_t n_rows,
                                     int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream) {
   (void)nnz;
-  PG_CHECK_ARG(n_rows >= 0 && n_src_rows >= 0 && F > 0, PANGNN_E_BADARG, "pangnn_spmm_csr_bf16: negative size");
-  if (n_rows == 0) return 0;
-  PG_CHECK_ARG(rowptr && out && (x_bf16 || n_src_rows == 0) && ldx >= F && ldo >= F, PANGNN_E_BADARG,
-               "pangnn_spmm_csr_bf16: null pointer / leading dimension smaller than F");
-  PG_CHECK_ARG((reinterpret_cast<uintptr_t>(x_bf16) & 7u) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
-                   ldx % 4 == 0 && ldo % 4 == 0,
-               PANGNN_E_ALIGN, "pangnn_spmm_csr_bf16: x must be 8-byte aligned, out / bias 16-byte, ld multiples of 4");
-  PG_CHECK_ARG((n_rows + kWavesPerBlock - 1) / kWavesPerBlock < 2147483647LL, PANGNN_E_TOOLARGE,
-               "pangnn_spmm_csr_bf16: too many rows for one launch");
-  hipStream_t s = (hipStream_t)stream;
-  switch (F) {
-    case 32:  return launch_spmm_bf16<32, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
-    case 64:  return launch_spmm_bf16<64, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
-    case 128: return launch_spmm_bf16<128, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
-    case 256: return launch_spmm_bf16<256, 4>(rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows, accumulate, s);
-    default: break;
-  }
-  set_error("pangnn_spmm_csr_bf16: F must be 32, 64, 128 or 256 (got %d)", (int)F);
-  return PANGNN_E_BADARG;
+  return spmm_csr_16("pangnn_spmm_csr_bf16", PANGNN_DTYPE_BF16, rowptr, idx, val, x_bf16, ldx, n_src_rows, bias, out, ldo, n_rows,
+                     F, accumulate, stream);
+}
+
+extern "C" int pangnn_spmm_csr_f16(const int64_t* rowptr, const int32_t* idx, const float* val,
+                                   const void* x_f16, int64_t ldx, int64_t n_src_rows,
+                                   const float* bias, float* out, int64_t ldo, int64_t n_rows,
+                                   int64_t nnz, int32_t F, int accumulate, pangnn_stream_t stream) {
+  (void)nnz;
+  return spmm_csr_16("pangnn_spmm_csr_f16", PANGNN_DTYPE_F16, rowptr, idx, val, x_f16, ldx, n_src_rows, bias, out, ldo, n_rows,
+                     F, accumulate, stream);
 }
 
 extern "C" size_t pangnn_band_propagate_workspace_bytes(int32_t F) {
@@ -414,8 +434,8 @@ extern "C" int pangnn_band_propagate(const void* x, int32_t x_dtype, int64_t ldx
   const char* who = "pangnn_band_propagate";
   PG_CHECK_ARG(n >= 0 && k >= 0 && (F == 64 || F == 128), PANGNN_E_BADARG, "%s: F must be 64 or 128, n >= 0, k >= 0 (F=%d k=%d)",
                who, (int)F, (int)k);
-  PG_CHECK_ARG(x_dtype == PANGNN_DTYPE_F32 || x_dtype == PANGNN_DTYPE_BF16, PANGNN_E_BADARG,
-               "%s: x_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  PG_CHECK_ARG(x_dtype == PANGNN_DTYPE_F32 || x_dtype == PANGNN_DTYPE_BF16 || x_dtype == PANGNN_DTYPE_F16, PANGNN_E_BADARG,
+               "%s: x_dtype is PANGNN_DTYPE_F32 / _BF16 / _F16", who);
   PG_CHECK_ARG(!colsum || (workspace && workspace_bytes >= pangnn_band_propagate_workspace_bytes(F)), PANGNN_E_WORKSPACE,
                "%s: colsum needs the workspace", who);
   if (n == 0) {
@@ -429,9 +449,9 @@ extern "C" int pangnn_band_propagate(const void* x, int32_t x_dtype, int64_t ldx
                "%s: null pointer / leading dimension", who);
   PG_CHECK_ARG((x_dtype == PANGNN_DTYPE_F32 ? aligned16(x) : (reinterpret_cast<uintptr_t>(x) & 7u) == 0) && aligned16(out) &&
                    (!bias || aligned16(bias)),
-               PANGNN_E_ALIGN, "%s: rows must start on 16 bytes (bf16 x: 8)", who);
+               PANGNN_E_ALIGN, "%s: rows must start on 16 bytes (bf16 / f16 x: 8)", who);
   hipStream_t s = (hipStream_t)stream;
-  const int xb = x_dtype == PANGNN_DTYPE_BF16;
+  const int xb = x_dtype;
   if (F == 64) return launch_band<64>(x, xb, ldx, dis, bias, out, ldo, n, (int)k, colsum, static_cast<float*>(workspace), s);
   return launch_band<128>(x, xb, ldx, dis, bias, out, ldo, n, (int)k, colsum, static_cast<float*>(workspace), s);
 }

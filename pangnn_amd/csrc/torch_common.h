@@ -56,12 +56,21 @@ const T* opt_ptr(const c10::optional<at::Tensor>& t) {
   return (t.has_value() && t->defined()) ? t->data_ptr<T>() : nullptr;
 }
 
-inline int32_t dtype_code(const at::Tensor& t) { return t.scalar_type() == at::kBFloat16 ? PANGNN_DTYPE_BF16 : PANGNN_DTYPE_F32; }
+// PANGNN_DTYPE_* of a row tensor: bfloat16 and float16 rows are read / written as stored, everything else is f32
+inline bool is_rows16(const at::Tensor& t) { return t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf; }
+inline int32_t dtype_code(const at::Tensor& t) {
+  return t.scalar_type() == at::kBFloat16 ? PANGNN_DTYPE_BF16 : t.scalar_type() == at::kHalf ? PANGNN_DTYPE_F16 : PANGNN_DTYPE_F32;
+}
+inline at::ScalarType scalar_of(int64_t code) {
+  TORCH_CHECK(code == PANGNN_DTYPE_F32 || code == PANGNN_DTYPE_BF16 || code == PANGNN_DTYPE_F16,
+              "pangnn: storage type code ", code, " (0 float32, 1 bfloat16, 2 float16)");
+  return code == PANGNN_DTYPE_BF16 ? at::kBFloat16 : code == PANGNN_DTYPE_F16 ? at::kHalf : at::kFloat;
+}
 
-// rows as the kernels read them: f32 (any other float is converted) or bfloat16 as stored, unit column stride, a row stride
+// rows as the kernels read them: f32 (any other float is converted) or bfloat16 / float16 as stored, unit column stride, a row stride
 // that keeps 16-byte loads aligned — column windows of a wider matrix pass through without a copy
 inline at::Tensor rows_any(const at::Tensor& t) {
-  if (t.scalar_type() == at::kBFloat16) {
+  if (is_rows16(t)) {
     if (t.dim() == 2 && t.stride(1) == 1 && t.stride(0) % 8 == 0 && t.stride(0) >= t.size(1) &&
         reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0)
       return t;

@@ -62,7 +62,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> gcn_norm(const at::Tensor& rowptr
   return {dis, ns, no};
 }
 
-// spmm(rowptr, other, val?, x f32|bf16 [n_src, F], bias?, n_rows) -> f32 [n_rows, F]
+// spmm(rowptr, other, val?, x f32|bf16|f16 [n_src, F], bias?, n_rows) -> f32 [n_rows, F]
 //   out[r] = bias + sum_{k in row r} val[k] x[other[k]]      forward propagate (by-target CSR) and, with the by-source
 //   CSR, its transpose (spmm_bwd of SURVEY.md §8b is this op on the other CSR)
 at::Tensor spmm(const at::Tensor& rowptr, const at::Tensor& other, const c10::optional<at::Tensor>& val,
@@ -77,20 +77,20 @@ at::Tensor spmm(const at::Tensor& rowptr, const at::Tensor& other, const c10::op
   TORCH_CHECK(!(bias.has_value() && bias->defined()) || bias->numel() == x.size(1), "pangnn::spmm: bias must be [F]");
   const DeviceGuard guard(x.device());
   const int64_t f = x.size(1);
-  const bool bf16 = x.scalar_type() == at::kBFloat16 && (f == 32 || f == 64 || f == 128 || f == 256);
-  at::Tensor xc = bf16 ? x.contiguous() : x.to(at::kFloat).contiguous();
+  const bool rows16 = is_rows16(x) && (f == 32 || f == 64 || f == 128 || f == 256);
+  at::Tensor xc = rows16 ? x.contiguous() : x.to(at::kFloat).contiguous();
   c10::optional<at::Tensor> vc, bc;
   if (val.has_value() && val->defined()) vc = val->to(at::kFloat).contiguous();
   if (bias.has_value() && bias->defined()) bc = bias->to(at::kFloat).contiguous();
   auto out = at::empty({n_rows, f}, x.options().dtype(at::kFloat));
-  const int rc = bf16 ? pangnn_spmm_csr_bf16(rowptr.data_ptr<int64_t>(), other.data_ptr<int32_t>(), opt_ptr<float>(vc),
-                                             xc.data_ptr(), xc.stride(0), xc.size(0), opt_ptr<float>(bc),
-                                             out.data_ptr<float>(), out.stride(0), n_rows, other.size(0), (int32_t)f, 0,
-                                             stream_of(x))
-                      : pangnn_spmm_csr_f32(rowptr.data_ptr<int64_t>(), other.data_ptr<int32_t>(), opt_ptr<float>(vc),
-                                            xc.data_ptr<float>(), xc.stride(0), xc.size(0), opt_ptr<float>(bc),
-                                            out.data_ptr<float>(), out.stride(0), n_rows, other.size(0), (int32_t)f, 0,
-                                            stream_of(x));
+  const auto fn16 = xc.scalar_type() == at::kHalf ? pangnn_spmm_csr_f16 : pangnn_spmm_csr_bf16;
+  const int rc = rows16 ? fn16(rowptr.data_ptr<int64_t>(), other.data_ptr<int32_t>(), opt_ptr<float>(vc), xc.data_ptr(),
+                               xc.stride(0), xc.size(0), opt_ptr<float>(bc), out.data_ptr<float>(), out.stride(0), n_rows,
+                               other.size(0), (int32_t)f, 0, stream_of(x))
+                        : pangnn_spmm_csr_f32(rowptr.data_ptr<int64_t>(), other.data_ptr<int32_t>(), opt_ptr<float>(vc),
+                                              xc.data_ptr<float>(), xc.stride(0), xc.size(0), opt_ptr<float>(bc),
+                                              out.data_ptr<float>(), out.stride(0), n_rows, other.size(0), (int32_t)f, 0,
+                                              stream_of(x));
   check_rc(rc, "pangnn_spmm_csr");
   return out;
 }
@@ -192,7 +192,7 @@ at::Tensor segment_max_bwd(const at::Tensor& g, const at::Tensor& arg, const at:
 
 // ---------------------------------------------------------------------------------------------------------------
 // Node-level dense layer (round 4: implementation AND autograd formula in C++ — no Python between the dispatcher and the
-// kernels).  linear(x f32|bf16 [N, K], w f32 [M, K], bias?, in_act, out_bf16) -> [N, M] f32|bf16:  y = act(x) w^T + bias with
+// kernels).  linear(x f32|bf16|f16 [N, K], w f32 [M, K], bias?, in_act, out_dtype) -> [N, M] of storage type out_dtype (PANGNN_DTYPE_*):  y = act(x) w^T + bias with
 // in_act = 1: act = ELU applied to the rows on their way into LDS (src/gnn.py:108 folded into the consumer).  K, M in
 // {64, 128} (pangnn_linear_supported; the Python layer sends every other shape to hipBLASLt).
 // linear_backward(g, x, w, in_act, has_bias, need_dx) -> (dx like x | empty, dw f32 [M, K], db f32 [M] | empty):
@@ -209,7 +209,7 @@ void linear_shapes(const char* op, const at::Tensor& x, const at::Tensor& w) {
 }
 
 at::Tensor linear_fwd(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t in_act,
-                      bool out_bf16) {
+                      int64_t out_dtype) {
   linear_shapes("linear", x, w);
   operand_any_float("linear", "bias", bias, x);
   TORCH_CHECK(!(bias.has_value() && bias->defined()) || bias->numel() == w.size(0), "pangnn::linear: bias must be [M]");
@@ -218,7 +218,7 @@ at::Tensor linear_fwd(const at::Tensor& x, const at::Tensor& w, const c10::optio
   c10::optional<at::Tensor> bc;
   if (bias.has_value() && bias->defined()) bc = bias->to(at::kFloat).contiguous();
   const int64_t n = xr.size(0), k = xr.size(1), m = wc.size(0);
-  auto y = at::empty({n, m}, x.options().dtype(out_bf16 ? at::kBFloat16 : at::kFloat));
+  auto y = at::empty({n, m}, x.options().dtype(scalar_of(out_dtype)));
   check_rc(pangnn_linear_act_fwd_mixed(xr.data_ptr(), dtype_code(xr), xr.stride(0), wc.data_ptr<float>(), opt_ptr<float>(bc),
                                        y.data_ptr(), dtype_code(y), y.stride(0), n, (int32_t)k, (int32_t)m, (int32_t)in_act,
                                        nullptr, 0, 0, stream_of(x)),
@@ -261,11 +261,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> linear_bwd(const at::Tensor& g, c
 // autograd formula of pangnn::linear, registered under the Autograd key: forward redispatches below autograd, backward is
 // ONE call of pangnn::linear_backward (itself a dispatcher op, so a tracer sees it)
 at::Tensor call_linear(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t in_act,
-                       bool out_bf16) {
+                       int64_t out_dtype) {
   static auto op = c10::Dispatcher::singleton()
                        .findSchemaOrThrow("pangnn::linear", "")
-                       .typed<at::Tensor(const at::Tensor&, const at::Tensor&, const c10::optional<at::Tensor>&, int64_t, bool)>();
-  return op.call(x, w, bias, in_act, out_bf16);
+                       .typed<at::Tensor(const at::Tensor&, const at::Tensor&, const c10::optional<at::Tensor>&, int64_t, int64_t)>();
+  return op.call(x, w, bias, in_act, out_dtype);
 }
 std::tuple<at::Tensor, at::Tensor, at::Tensor> call_linear_backward(const at::Tensor& g, const at::Tensor& x,
                                                                    const at::Tensor& w, int64_t in_act, bool has_bias,
@@ -280,12 +280,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> call_linear_backward(const at::Te
 class LinearFunction : public torch::autograd::Function<LinearFunction> {
  public:
   static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w,
-                            const c10::optional<at::Tensor>& bias, int64_t in_act, bool out_bf16) {
+                            const c10::optional<at::Tensor>& bias, int64_t in_act, int64_t out_dtype) {
     at::AutoDispatchBelowADInplaceOrView below;
     ctx->save_for_backward({x, w});
     ctx->saved_data["in_act"] = in_act;
     ctx->saved_data["has_bias"] = bias.has_value() && bias->defined();
-    return call_linear(x, w, bias, in_act, out_bf16);
+    return call_linear(x, w, bias, in_act, out_dtype);
   }
   static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
     const auto saved = ctx->get_saved_variables();
@@ -297,8 +297,8 @@ class LinearFunction : public torch::autograd::Function<LinearFunction> {
 };
 
 at::Tensor linear_autograd(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, int64_t in_act,
-                           bool out_bf16) {
-  return LinearFunction::apply(x, w, bias, in_act, out_bf16);
+                           int64_t out_dtype) {
+  return LinearFunction::apply(x, w, bias, in_act, out_dtype);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -451,7 +451,7 @@ TORCH_LIBRARY(pangnn, m) {
   m.def("segment_sum_rows(Tensor rowptr, Tensor perm, Tensor m, int col_off, int f, int n_rows) -> Tensor");
   m.def("segment_max_rows(Tensor rowptr, Tensor perm, Tensor m, int n_rows) -> (Tensor, Tensor)");
   m.def("segment_max_bwd(Tensor g, Tensor arg, Tensor rowptr, int num_edges) -> Tensor");
-  m.def("linear(Tensor x, Tensor w, Tensor? bias, int in_act, bool out_bf16) -> Tensor");
+  m.def("linear(Tensor x, Tensor w, Tensor? bias, int in_act, int out_dtype) -> Tensor");
   m.def("linear_backward(Tensor g, Tensor x, Tensor w, int in_act, bool has_bias, bool need_dx) -> (Tensor, Tensor, Tensor)");
   m.def("bce_with_logits(Tensor logits, Tensor y, Tensor? pos_weight, int denom) -> (Tensor, Tensor)");
 }

@@ -538,7 +538,7 @@ class HipOps:
         f = PF._f32c
         pw = None if pos_weight is None else f(pos_weight).reshape(-1)
         loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = PF._decoder_train16(
-            PF._rows_any(table), PF._rows_any(q_local), st, None if extra is None else f(extra),
+            PF._rows_dec(table), PF._rows_dec(q_local), st, None if extra is None else f(extra),
             None if cvec is None else f(cvec), f(w2), f(b2), f(w3), f(b3), y=f(y), pw=pw, denom=denom, after_p=after_p)
         return loss.view(()), logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
 

@@ -11,6 +11,8 @@ from . import _lib
 from .graph import CSR, EdgeStructure, GcnNorm
 
 
+ROWS16 = (torch.bfloat16, torch.float16)        # the two 2-byte row formats (PANGNN_DTYPE_BF16 / _F16)
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
@@ -48,8 +50,8 @@ def _timer_stop(tag, ev0):
 def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int,
              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
              accumulate: bool = False, tag: Optional[str] = None) -> torch.Tensor:
-    """out[r] (+)= bias + sum_e val[e] * x[other[e]]  — pangnn_spmm_csr_f32, or pangnn_spmm_csr_bf16 when the
-    gathered rows are stored as bfloat16 (fp32 weights / accumulation / result either way)."""
+    """out[r] (+)= bias + sum_e val[e] * x[other[e]]  — pangnn_spmm_csr_f32, or pangnn_spmm_csr_bf16 / _f16 when the
+    gathered rows are stored as bfloat16 / float16 (fp32 weights / accumulation / result either way)."""
     lib = _lib.load()
     _lib.require_device(x, csr.rowptr, val, bias)
     f = x.shape[1]
@@ -68,11 +70,11 @@ def spmm_csr(csr: CSR, val: Optional[torch.Tensor], x: torch.Tensor, n_rows: int
                                                out.stride(0), n_rows, parts.shape[0], f, int(accumulate), _lib.stream_ptr()),
                        "pangnn_spmm_csr_f32(long-row parts)")
         return out
-    bf16 = x.dtype == torch.bfloat16 and f in (32, 64, 128, 256)
-    if bf16:
+    if x.dtype in ROWS16 and f in (32, 64, 128, 256):
         if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 8:
             x = x.contiguous()
-        fn, name = lib.pangnn_spmm_csr_bf16, "pangnn_spmm_csr_bf16"
+        fn, name = (lib.pangnn_spmm_csr_bf16, "pangnn_spmm_csr_bf16") if x.dtype == torch.bfloat16 \
+            else (lib.pangnn_spmm_csr_f16, "pangnn_spmm_csr_f16")
     else:
         x = _f32c(x)
         fn, name = lib.pangnn_spmm_csr_f32, "pangnn_spmm_csr_f32"
@@ -128,7 +130,7 @@ def colsum(g: torch.Tensor) -> torch.Tensor:
     """column sums of dL/dout (GCNConv's bias gradient) in fp32: one launch for the short matrices of a mini-batch
     (torch's column reduction is a zero-fill + a reduce kernel there), torch's two-stage sum for long ones"""
     if g.is_cuda and g.dim() == 2 and g.shape[0] <= COLSUM_SMALL_ROWS and g.stride(1) == 1 and 0 < g.shape[1] <= 1024 \
-            and g.dtype in (torch.float32, torch.bfloat16):
+            and (g.dtype == torch.float32 or g.dtype in ROWS16):
         lib = _lib.load()
         out = torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
         with _lib.device_guard(g.device):
@@ -144,22 +146,23 @@ class _Propagate(torch.autograd.Function):
     leaf without grad in the reference: SURVEY.md §8 a6)."""
 
     @staticmethod
-    def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm, tag=None, out_bf16=False):
-        """`out_bf16` (bf16 autocast, a propagate-first GCNConv): the result is what an autocast Linear consumes, i.e. it is
-        cast to bfloat16 first thing — done here once and stored, so the Linear reads 2-byte rows, its dL/dx comes back as
-        bfloat16 (autograd's dtype rule; in the reference the backward of that cast hands fp32 copies of bf16 values on) and
-        the transposed propagate gathers it as stored: the same values as the reference's, half the gather bytes."""
+    def forward(ctx, x, bias, st: EdgeStructure, norm: GcnNorm, tag=None, out_dtype=None):
+        """`out_dtype` = torch.bfloat16 / torch.float16 (autocast, a propagate-first GCNConv): the result is what an autocast
+        Linear consumes, i.e. it is cast to the autocast type first thing — done here once and stored, so the Linear reads
+        2-byte rows, its dL/dx comes back in that type (autograd's dtype rule; in the reference the backward of that cast hands
+        fp32 copies of the 16-bit values on) and the transposed propagate gathers it as stored: the same values as the
+        reference's, half the gather bytes."""
         ctx.st, ctx.norm, ctx.tag = st, norm, tag
         ctx.has_bias = bias is not None
-        ctx.x_dtype = x.dtype            # bfloat16 rows are gathered as stored (half the bytes); result fp32
+        ctx.x_dtype = x.dtype            # bfloat16 / float16 rows are gathered as stored (half the bytes); result fp32
         out = spmm_csr(st.by_dst, norm.by_dst, x, st.num_nodes, bias=None if bias is None else _f32c(bias),
                        tag=None if tag is None else tag + ".fwd")
-        return out.to(torch.bfloat16) if out_bf16 else out
+        return out.to(out_dtype) if out_dtype in ROWS16 else out
 
     @staticmethod
     def backward(ctx, g):
         st, norm = ctx.st, ctx.norm
-        if not (g.dtype == torch.bfloat16 and g.shape[1] in (32, 64, 128, 256)):     # bf16 rows: gathered as stored
+        if not (g.dtype in ROWS16 and g.shape[1] in (32, 64, 128, 256)):     # 2-byte rows: gathered as stored
             g = _f32c(g)
         gx = spmm_csr(st.by_src, norm.by_src, g, st.num_src,
                       tag=None if ctx.tag is None else ctx.tag + ".bwd") if ctx.needs_input_grad[0] else None
@@ -203,12 +206,12 @@ def _via_ops(st: Optional[EdgeStructure] = None, tag=None) -> bool:
     return bool(use) and (st is None or st.num_src == st.num_nodes) and (KERNEL_TIMER is None or tag is None)
 
 
-def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None, out_bf16=False):
+def propagate(x, bias, st: EdgeStructure, norm: GcnNorm, tag=None, out_dtype=None):
     if _via_ops(st, tag) and getattr(norm, "weight_ref", norm) is not norm:
         from . import torch_ops
         _lib.require_device(x, bias)
-        return torch_ops.gcn_propagate(x, bias, st, norm, False, out_bf16)
-    return _Propagate.apply(x, bias, st, norm, tag, bool(out_bf16))
+        return torch_ops.gcn_propagate(x, bias, st, norm, False, out_dtype)
+    return _Propagate.apply(x, bias, st, norm, tag, out_dtype)
 
 
 class _BandPropagate(torch.autograd.Function):
@@ -261,17 +264,17 @@ def _band_ok(x, st: EdgeStructure, unit_weights: bool) -> bool:
         and st.band_width() > 0
 
 
-def propagate_any(x, bias, st: EdgeStructure, norm: GcnNorm, unit_weights: bool, tag=None, out_bf16=False):
+def propagate_any(x, bias, st: EdgeStructure, norm: GcnNorm, unit_weights: bool, tag=None, out_dtype=None):
     """GCNConv's message passing: the band kernel when the structure is the positional-neighbour band with unit weights
-    (whole-graph mode of the reference), the general CSR kernels otherwise.  `out_bf16`: see _Propagate.forward."""
+    (whole-graph mode of the reference), the general CSR kernels otherwise.  `out_dtype`: see _Propagate.forward."""
     if _via_ops(st, tag) and getattr(norm, "weight_ref", norm) is not norm:
         from . import torch_ops
         _lib.require_device(x, bias)
-        return torch_ops.gcn_propagate(x, bias, st, norm, unit_weights, out_bf16)   # the op makes the same band / CSR choice
+        return torch_ops.gcn_propagate(x, bias, st, norm, unit_weights, out_dtype)   # the op makes the same band / CSR choice
     if _band_ok(x, st, unit_weights) and (KERNEL_TIMER is None or tag is None or (tag + ".fwd") not in KERNEL_TIMER):
         y = band_propagate(x, bias, st, norm)
-        return y.to(torch.bfloat16) if out_bf16 else y
-    return propagate(x, bias, st, norm, tag, out_bf16)
+        return y.to(out_dtype) if out_dtype in ROWS16 else y
+    return propagate(x, bias, st, norm, tag, out_dtype)
 
 
 class _EdgeGatherConcat(torch.autograd.Function):
@@ -528,8 +531,8 @@ def _rows_f32(t: torch.Tensor) -> torch.Tensor:
 
 
 def _rows_any(t: torch.Tensor) -> torch.Tensor:
-    """_rows_f32 that lets bfloat16 storage through (the *_mixed entry points read it as stored)"""
-    if t.dtype != torch.bfloat16:
+    """_rows_f32 that lets bfloat16 / float16 storage through (the *_mixed entry points read it as stored)"""
+    if t.dtype not in ROWS16:
         return _rows_f32(t)
     if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.stride(0) >= t.shape[1] \
             and t.data_ptr() % 16 == 0:
@@ -537,14 +540,35 @@ def _rows_any(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def autocast_rows_dtype(t: torch.Tensor):
+    """torch.bfloat16 / torch.float16 when that mixed precision is on for `t`'s device (accelerate's autocast, pangnn.py:25,
+    src/setup.py:50), else None: the type the reference's autocast Linear outputs — and hence the rows PyG's propagate
+    gathers — are stored in"""
+    if t.is_cuda and torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        return dt if dt in ROWS16 else None
+    return None
+
+
+def _rows_dec(t: torch.Tensor) -> torch.Tensor:
+    """decoder tables as the decoder kernels read them: float32 or bfloat16 (float16 tables are converted: no f16 format there)"""
+    return _rows_any(t.float() if t.dtype == torch.float16 else t)
+
+
 def autocast_bf16(t: torch.Tensor) -> bool:
-    """bf16 mixed precision is on for `t`'s device (config 5: accelerate's autocast, pangnn.py:25)"""
-    return t.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    """bf16 mixed precision is on for `t`'s device (config 5).  The decoder's P | Q tables have a bfloat16 format only: under
+    float16 autocast they stay fp32 (results at the fp32 level)."""
+    return autocast_rows_dtype(t) == torch.bfloat16
+
+
+def dtype_code(dtype) -> int:
+    """PANGNN_DTYPE_* of a torch dtype (None / anything that is not a 2-byte row format: f32)"""
+    return 1 if dtype == torch.bfloat16 else 2 if dtype == torch.float16 else 0
 
 
 def _dt(t: torch.Tensor) -> int:
     """PANGNN_DTYPE_* of a tensor's storage"""
-    return 1 if t.dtype == torch.bfloat16 else 0
+    return dtype_code(t.dtype)
 
 
 class _DecoderMLP(torch.autograd.Function):
@@ -558,7 +582,7 @@ class _DecoderMLP(torch.autograd.Function):
     def forward(ctx, p, q, st: EdgeStructure, extra, cvec, w2, b2, w3, b3, pq_joint=False):
         lib = _lib.load()
         _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3)
-        rows = _rows_any if DECODER_PRECISION == 1 else _rows_f32      # bf16-stored tables: gathered as stored
+        rows = _rows_dec if DECODER_PRECISION == 1 else _rows_f32      # bf16-stored tables: gathered as stored
         if pq_joint:
             pq = rows(p)
             d = pq.shape[1] // 2
@@ -733,7 +757,7 @@ class _DecoderLoss(torch.autograd.Function):
         _lib.require_device(p, q, extra, cvec, w2, b2, w3, b3, y, pos_weight)
         if live is not None and (DECODER_PRECISION != 1 or live.dtype != torch.int64 or not live.is_cuda):
             raise ValueError("live= (a padded fixed-shape batch) needs the default decoder mode and a device int64 tensor")
-        rows = _rows_any if DECODER_PRECISION == 1 else _rows_f32      # bf16-stored tables: gathered as stored
+        rows = _rows_dec if DECODER_PRECISION == 1 else _rows_f32      # bf16-stored tables: gathered as stored
         if pq_joint:
             pq = rows(p)
             d = pq.shape[1] // 2
@@ -842,15 +866,17 @@ def linear(x, w, bias=None, in_act: int = 0, out_dtype=None):
     in_act = 1: linear(ELU(x), w, bias) with the activation folded into the kernels — forward: ELU applied to the rows on their
     way into LDS; backward: dL/dx comes out already multiplied by ELU'(x), the weight gradient re-applies ELU (no activation
     kernel, no activated tensor in HBM; pangnn::linear / linear_backward, csrc/torch_ops.cpp).
-    `x` may be stored as bfloat16 and `out_dtype=torch.bfloat16` stores the result as bfloat16 (config 5's autocast
-    Linear outputs): fp32 products and sums either way, one rounding on store; gradients of bf16 tensors are bf16."""
+    `x` may be stored as bfloat16 / float16 and `out_dtype=torch.bfloat16` / `torch.float16` stores the result in that type
+    (the autocast Linear outputs of config 5 / of `--mixed_precision fp16`): fp32 products and sums either way, one rounding
+    on store; gradients of 16-bit tensors are stored alike."""
     _lib.require_device(x, w, bias)                  # no CPU path: the torch branch below is hipBLASLt on the GPU
     k, m = w.shape[1], w.shape[0]
-    if x.dim() == 2 and _linear_supported(int(k), int(m)) and out_dtype in (None, torch.float32, torch.bfloat16):
+    if x.dim() == 2 and _linear_supported(int(k), int(m)) and (out_dtype in (None, torch.float32) or out_dtype in ROWS16) \
+            and not (x.dtype in ROWS16 and out_dtype in ROWS16 and x.dtype != out_dtype):
         # ONE route (round 4): the dispatcher op, whose HIP implementation and autograd formula are C++
         # (csrc/torch_ops.cpp) — the ctypes autograd.Function twin of rounds 1-3 is gone
         from . import torch_ops
-        return torch_ops.ops.linear(x, w, bias, int(in_act), out_dtype == torch.bfloat16)
+        return torch_ops.ops.linear(x, w, bias, int(in_act), dtype_code(out_dtype))
     if in_act:
         x = torch.nn.functional.elu(x)
     y = torch.nn.functional.linear(x.float(), w, bias)
@@ -992,7 +1018,7 @@ class _EmbedConvIn(torch.autograd.Function):
 
 def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):
     _lib.require_device(x_tab, w, b, w_in, b_in)
-    if _via_ops(st) and getattr(norm, "weight_ref", norm) is not norm and out_dtype in (None, torch.float32, torch.bfloat16):
+    if _via_ops(st) and getattr(norm, "weight_ref", norm) is not norm and (out_dtype in (None, torch.float32) or out_dtype in ROWS16):
         from . import torch_ops
         return torch_ops.embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype)
     return _EmbedConvIn.apply(x_tab, w, b, w_in, b_in, st, norm, out_dtype)

@@ -113,7 +113,7 @@ class AlternateGCN(nn.Module):
             w = graph.edge_attr
             if w is not None and w.shape[0] != st.num_edges:
                 raise ValueError(f"edge_weight has {w.shape[0]} entries for {st.num_edges} edges")
-            out_dtype = torch.bfloat16 if PF.autocast_bf16(x) else None
+            out_dtype = PF.autocast_rows_dtype(x)          # the autocast Linear's output type (bf16 / fp16 mixed precision)
             if self.fuse_embedding != "propagate":
                 # the whole layer by linearity: r a^T + s c^T + b_in, r = A_hat x and s = A_hat 1 cached per graph
                 # (functional._EmbedConvIn) — one [N, H] write per step, one pass over its gradient in backward
@@ -131,8 +131,8 @@ class AlternateGCN(nn.Module):
     def _embed_conv_in_then_dense(self, graph, ei, name, w_out, bias_out):
         """linear(ELU(conv_in(embedding(x))), w_out, bias_out) with the [N, H] rows of the first layer generated inside the
         dense layer's kernels (functional._EmbedConvInLinear) — or None where that operator does not apply: categorical
-        nodes, fuse_embedding / fuse_first_dense / fold_activation off, widths its kernels do not cover, bf16 autocast
-        (the reference's autocast stores those rows as bfloat16; the generated rows are fp32)."""
+        nodes, fuse_embedding / fuse_first_dense / fold_activation off, widths its kernels do not cover, bf16 / fp16 autocast
+        (the reference's autocast stores those rows in the autocast type; the generated rows are fp32)."""
         x, conv = graph.x, self.conv_in
         if self.categorical_nodes or not self.fuse_first_dense or not self._fold_elu() or not self.fuse_embedding \
                 or self.fuse_embedding == "propagate":
@@ -140,7 +140,7 @@ class AlternateGCN(nn.Module):
         if w_out.shape[1] != conv.out_channels or not PF.embed_linear_supported(conv.out_channels, w_out.shape[0]):
             return None
         _lib.require_device(x)
-        if PF.autocast_bf16(x):
+        if PF.autocast_rows_dtype(x) is not None:
             return None
         st = structure_of(ei, x.shape[0], holder=graph, name=name)
         w = graph.edge_attr

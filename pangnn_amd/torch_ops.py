@@ -25,6 +25,13 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_ROW_DTYPES = (torch.float32, torch.bfloat16, torch.float16)       # indexed by PANGNN_DTYPE_*
+
+
+def _code(dtype) -> int:
+    """PANGNN_DTYPE_* of a torch dtype (None: f32)"""
+    return 1 if dtype == torch.bfloat16 else 2 if dtype == torch.float16 else 0
+
 TLIB_PATH = os.environ.get("PANGNN_TORCH_LIB") or os.path.join(_HERE, "libpangnn_torch.so")   # override: the host-sanitizer build
 
 if not os.path.exists(TLIB_PATH):
@@ -107,10 +114,10 @@ _NO_AUTOCAST = torch._C.DispatchKeySet(torch._C.DispatchKey.AutocastCUDA)
 
 def _autocast_propagate(rowptr, other, val, rowptr_t, other_t, val_t, x, bias):
     """PyG under autocast: the message gather runs on rows of the autocast dtype, weights and sums stay fp32.
-    bfloat16: rows are gathered as stored (pangnn_spmm_csr_bf16); float16 has no row format here -> fp32."""
+    bfloat16 / float16: rows are gathered as stored (pangnn_spmm_csr_bf16 / _f16)."""
     dt = torch.get_autocast_dtype("cuda")
     if x.is_floating_point():
-        x = x.to(torch.bfloat16) if dt == torch.bfloat16 else x.float()
+        x = x.to(dt) if dt in (torch.bfloat16, torch.float16) else x.float()
     with torch._C._ExcludeDispatchKeyGuard(_NO_AUTOCAST):
         return ops.propagate(rowptr, other, val, rowptr_t, other_t, val_t, x, bias)
 
@@ -156,8 +163,8 @@ _hooks.impl("_prepare_structure", _prepare_structure, "CompositeExplicitAutograd
 
 # ---------------------------------------------------------------------------------------------- fake kernels
 @torch.library.register_fake("pangnn::linear")
-def _(x, w, bias, in_act, out_bf16):
-    return x.new_empty(x.shape[0], w.shape[0], dtype=torch.bfloat16 if out_bf16 else torch.float32)
+def _(x, w, bias, in_act, out_dtype):
+    return x.new_empty(x.shape[0], w.shape[0], dtype=_ROW_DTYPES[out_dtype])
 
 
 @torch.library.register_fake("pangnn::linear_backward")
@@ -172,19 +179,19 @@ def _(logits, y, pos_weight, denom):
 
 
 @torch.library.register_fake("pangnn::gcn_propagate")
-def _(x, bias, edge_index, edge_weight, allow_band, out_bf16):
-    return x.new_empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+def _(x, bias, edge_index, edge_weight, allow_band, out_dtype):
+    return x.new_empty(x.shape, dtype=_ROW_DTYPES[out_dtype])
 
 
 @torch.library.register_fake("pangnn::gcn_propagate_backward")
-def _(g, edge_index, edge_weight, allow_band, has_bias, x_bf16):
-    return (g.new_empty(g.shape, dtype=torch.bfloat16 if x_bf16 else torch.float32),
+def _(g, edge_index, edge_weight, allow_band, has_bias, x_dtype):
+    return (g.new_empty(g.shape, dtype=_ROW_DTYPES[x_dtype]),
             g.new_empty(g.shape[1] if has_bias else 0, dtype=torch.float32))
 
 
 @torch.library.register_fake("pangnn::embed_conv_in")
-def _(x, w, b, w_in, b_in, edge_index, edge_weight, out_bf16):
-    return w_in.new_empty(x.shape[0], w_in.shape[0], dtype=torch.bfloat16 if out_bf16 else torch.float32)
+def _(x, w, b, w_in, b_in, edge_index, edge_weight, out_dtype):
+    return w_in.new_empty(x.shape[0], w_in.shape[0], dtype=_ROW_DTYPES[out_dtype])
 
 
 @torch.library.register_fake("pangnn::embed_conv_in_backward")
@@ -249,15 +256,15 @@ def _ready(st, need, norm=None, x=None):
     return w
 
 
-def gcn_propagate(x, bias, st, norm, allow_band=False, out_bf16=False):
+def gcn_propagate(x, bias, st, norm, allow_band=False, out_dtype=None):
     band = bool(allow_band) and getattr(norm, "weight_ref", None) is None and x.dim() == 2 and x.shape[1] in (64, 128)
     w = _ready(st, _N.NEED_BY_DST | _N.NEED_NORM | (_N.NEED_BAND if band else 0), norm)
-    return ops.gcn_propagate(x, bias, st._key_tensor, w, bool(allow_band), bool(out_bf16))
+    return ops.gcn_propagate(x, bias, st._key_tensor, w, bool(allow_band), _code(out_dtype))
 
 
 def embed_conv_in(x_tab, w, b, w_in, b_in, st, norm, out_dtype=None):
     wt = _ready(st, _N.NEED_BY_DST | _N.NEED_NORM | _N.NEED_ACTIONS, norm, x_tab)
-    return ops.embed_conv_in(x_tab, w, b, w_in, b_in, st._key_tensor, wt, out_dtype == torch.bfloat16)
+    return ops.embed_conv_in(x_tab, w, b, w_in, b_in, st._key_tensor, wt, _code(out_dtype))
 
 
 def embed_conv_in_linear(x_tab, w, b, w_in, b_in, w_out, bias_out, st, norm):

@@ -271,12 +271,14 @@ def test_padded_fixed_shape_batch_reaches_the_fused_pass_through_the_handle():
         torch.sigmoid(model(buf))
 
 
-def test_reference_loop_under_accelerate_fp16_runs_at_fp32_level():
+def test_reference_loop_under_accelerate_fp16_tracks_the_fp32_oracle_at_f16_resolution():
     """`--mixed_precision fp16` (/root/reference/src/setup.py:50): accelerate wraps `forward` in float16 autocast and drives
-    `accelerator.backward(loss)` through a GradScaler (loss x 65 536).  This package has no float16 row format: its operators
-    keep fp32 storage under float16 autocast, so the loop's results sit at the FP32 oracle's level — better than
-    the reference's own fp16 run would — and the scaled loss exercises the in-place gradient scaling behind the fused decoder
-    pass (pangnn_scale_unless_one_f32 with a scalar that is NOT 1), unscaled again by the scaler before Adam."""
+    `accelerator.backward(loss)` through a GradScaler (loss x 65 536).  The encoder's Linear outputs / propagated rows are stored
+    as float16 (PANGNN_DTYPE_F16, round 5 — tests/test_f16_rows.py), every product and sum and the decoder's P | Q tables stay
+    fp32, so the loop tracks the FP32 oracle at float16 resolution — nearer than the reference's own fp16 arithmetic would —
+    and the scaled loss exercises the in-place gradient scaling behind the fused decoder pass (pangnn_scale_unless_one_f32 with a
+    scalar that is NOT 1), unscaled again by the scaler before Adam; float16 gradient rows carry the 65 536 x scale, as in the
+    reference."""
     import pangnn_amd
     from pangnn_amd import DeferredLogits
     g = whole_graph_from_golden("cfg2_sim_1000x5")
@@ -306,11 +308,19 @@ def test_reference_loop_under_accelerate_fp16_runs_at_fp32_level():
         accelerator.backward(loss)                      # scaler.scale(loss).backward(): upstream gradient = the scale
         optimizer.step()                                # scaler.step: unscale, inf check, Adam; scaler.update
         assert output.route == "fused" and not optimizer.step_was_skipped
-        tol = 1e-4 if step == 0 else 5e-4
-        assert torch.allclose(output.detach().cpu(), ref[step][1], atol=tol, rtol=tol), step
-        assert abs(loss.item() - ref[step][0]) <= (1e-5 if step == 0 else 1e-4) * max(1.0, abs(ref[step][0]))
+        scale = float(ref[step][1].abs().max())
+        err = float((output.detach().cpu() - ref[step][1]).abs().max())
+        print(f"fp16 loop step {step}: max |logit - fp32 oracle| = {err:.3e} (scale {scale:.3e}), "
+              f"loss {loss.item():.6f} vs {ref[step][0]:.6f}")
+        assert err < (4e-3 if step == 0 else 2e-2) * scale, (step, err, scale)          # float16 rows: 2^-11 per element
+        assert abs(loss.item() - ref[step][0]) <= (2e-3 if step == 0 else 1e-2) * max(1.0, abs(ref[step][0]))
     state = accelerator.unwrap_model(model).state_dict()
-    moved = sum(int(((v.cpu() - oracle.state_dict()[k]).abs() > 2e-5).sum()) for k, v in state.items())
-    assert moved <= 0.002 * sum(v.numel() for v in state.values())
+    assert all(v.dtype == torch.float32 for v in state.values())
+    diffs = torch.cat([(v.cpu() - oracle.state_dict()[k]).abs().flatten() for k, v in state.items()])
+    worst, off = float(diffs.max()), float((diffs > 1e-4).float().mean())
+    print(f"fp16 loop: max |parameter - fp32 oracle| after 3 Adam steps = {worst:.3e}; {100 * off:.2f} % of the entries off by > 1e-4")
+    # Adam's normalised step moves an entry by ~lr per step whatever the gradient's size: an entry whose tiny gradient changes sign
+    # under float16 rounding ends up to 2 lr x 3 steps away — a few entries, bounded in number and in distance
+    assert worst < 6.5e-3 and off < 0.02
     from accelerate.state import AcceleratorState
     AcceleratorState._reset_state(True)

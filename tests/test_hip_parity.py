@@ -866,7 +866,7 @@ def test_hip_graph_replay_equals_eager_steps():
 
 def test_propagate_with_bf16_output_rounds_once_and_its_backward_gathers_bf16_rows():
     """config 5's propagate-first GCNConv under bf16 autocast: the propagate's result is what an autocast Linear consumes,
-    i.e. bfloat16 — `out_bf16` stores it that way (one rounding of the fp32 sums) and the transposed propagate gathers the
+    i.e. bfloat16 — `out_dtype=torch.bfloat16` stores it that way (one rounding of the fp32 sums) and the transposed propagate gathers the
     bfloat16 gradient rows as stored: the same sums as gathering their fp32 copies (what the reference's cast backward hands
     on), half the bytes"""
     from pangnn_amd import functional as PF
@@ -881,7 +881,7 @@ def test_propagate_with_bf16_output_rounds_once_and_its_backward_gathers_bf16_ro
     res = {}
     for out_bf16 in (False, True):
         x = x0.clone().requires_grad_(True)
-        y = PF.propagate_any(x, None, st, norm, False, out_bf16=out_bf16)
+        y = PF.propagate_any(x, None, st, norm, False, out_dtype=torch.bfloat16 if out_bf16 else None)
         y.backward(g0 if out_bf16 else g0.float())
         res[out_bf16] = (y.detach(), x.grad)
     assert res[True][0].dtype == torch.bfloat16 and res[False][0].dtype == torch.float32

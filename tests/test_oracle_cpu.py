@@ -179,7 +179,7 @@ def test_c_abi_exports_every_declared_symbol():
     from pangnn_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared               # python binding covers the header 1:1
     lib.pangnn_abi_version.restype = ctypes.c_int
-    assert lib.pangnn_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define PANGNN_ABI_VERSION (\d+)", hdr).group(1)) == 2
+    assert lib.pangnn_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define PANGNN_ABI_VERSION (\d+)", hdr).group(1)) == 3
 
 
 def test_shipped_code_objects_pass_the_isa_gate():

@@ -1,4 +1,4 @@
-"""Diagnostic: conv_in-sized propagate (cfg 4 similarity graph) with fp32 vs bfloat16 row storage."""
+"""Diagnostic: conv_in-sized propagate (cfg 4 similarity graph) with fp32 vs bfloat16 / float16 row storage."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pangnn_amd import functional as PF
@@ -11,7 +11,7 @@ st = structure_of(g.edge_index, n, holder=g, name="sim")
 norm = st.gcn_norm(g.edge_attr)
 for F in (64, 128):
     x = torch.randn(n, F, device=dev)
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
         xx = x.to(dt)
         for _ in range(2):
             PF.spmm_csr(st.by_dst, norm.by_dst, xx, n)
