@@ -125,3 +125,31 @@ def test_sizes_beyond_the_int32_index_range_are_refused():
     args[6], args[7] = big, big                                                                       # ld, num_edges
     assert L.pangnn_decoder_train_f32(*args, F, None, E, None, F, F, F, None, None, F, F, F, None, None, F,
                                       L.pangnn_decoder_train_workspace_bytes(), None) == E_TOOLARGE
+
+
+def test_storage_type_codes_are_checked_on_the_host():
+    """PANGNN_DTYPE_F16 (2) is a storage type of the node-level entry points, not of the decoder's tables; the 2-byte operands
+    of one call share a format; an unknown code is refused everywhere — all before a pointer is touched"""
+    L = lib()
+    F32, BF16, F16 = 0, 1, 2
+    # dense layer: bfloat16 x with a float16 result / float16 g with bfloat16 x
+    assert L.pangnn_linear_act_fwd_mixed(F, BF16, 64, F, None, F, F16, 64, N, 64, 64, 0, None, F32, 0, None) == E_BADARG
+    assert b"all bfloat16 or all float16" in L.pangnn_last_error()
+    w = L.pangnn_linear_wgrad_workspace_bytes(64, 64)
+    assert L.pangnn_linear_act_wgrad_mixed(F, F16, 64, F, BF16, 64, N, 64, 64, 0, F, F, F, w, None) == E_BADARG
+    assert L.pangnn_linear_act_fwd_mixed(F, 3, 64, F, None, F, F32, 64, N, 64, 64, 0, None, F32, 0, None) == E_BADARG
+    # 2-byte rows start on 8 bytes, not 16 (F + 8 is fine for f16 x, not for f32 x)
+    assert L.pangnn_linear_act_fwd_mixed(F + 8, F32, 64, F, None, F, F32, 64, N, 64, 64, 0, None, F32, 0, None) == E_ALIGN
+    # the decoder's tables: float32 or bfloat16 only
+    args = _decoder_common(dtype_arg=True)
+    args[4] = F16
+    assert L.pangnn_decoder_mlp_infer_mixed(*args, F, None) == E_BADARG
+    assert b"pq_dtype" in L.pangnn_last_error()
+    # generated rows / column sums / band: 0, 1, 2 are the codes
+    assert L.pangnn_rank2_rows(F, F, F, F, None, F, 3, 64, N, 64, None) == E_BADARG
+    wsb = L.pangnn_weighted_colsum3_workspace_bytes(64)
+    assert L.pangnn_weighted_colsum3(F, 3, 64, F, F, N, 64, F, F, wsb, None) == E_BADARG
+    assert L.pangnn_weighted_colsum3(F + 4, F16, 64, F, F, N, 64, F, F, wsb, None) == E_ALIGN        # f16 rows: 8-byte aligned
+    assert L.pangnn_band_propagate(F, 3, 64, F, None, F, 64, N, 64, 1, None, None, 0, None) == E_BADARG
+    assert L.pangnn_spmm_csr_f16(F, F, F, F + 4, 64, N, None, F, 64, N, E, 64, 0, None) == E_ALIGN
+    assert L.pangnn_spmm_csr_f16(F, F, F, F, 64, N, None, F, 64, N, E, 48, 0, None) == E_BADARG      # F not 32 / 64 / 128 / 256
