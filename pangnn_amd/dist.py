@@ -373,13 +373,23 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
 
     `ops.decoder_train` is the one-pass training decoder (loss, logits and every gradient in forward), so like
     functional._DecoderLoss this function finishes all gradients in forward() and backward() only hands them out.
-    Inputs are this rank's blocks p_local, q_local [n_local, D]; the table [halo | own | halo] exists only inside."""
+    Inputs are this rank's blocks p_local, q_local [n_local, D]; the table [halo | own | halo] exists only inside.
+    `q_local=None`: `p_local` is the JOINT block P | Q [n_local, 2 D] of one node-level product (AlternateGCN's layout) and
+    the gradient comes back as one [n_local, 2 D] matrix — one dense layer forward and backward instead of two plus the
+    addition of their two dL/dz."""
 
     @staticmethod
     def forward(ctx, p_local, q_local, ops, plan: HaloPlan, st_loc, st_halo, extra, cvec, w2, b2, w3, b3, y,
                 pos_weight, denom):
         dev = p_local.device
-        p_local = p_local.contiguous()
+        joint = q_local is None
+        if joint:
+            pq = p_local if p_local.stride(1) == 1 else p_local.contiguous()
+            dj = pq.shape[1] // 2
+            p_local, q_local = pq[:, :dj], pq[:, dj:]
+            gpq = torch.empty(pq.shape, dtype=torch.float32, device=dev)         # [dL/dP | dL/dQ] of the own rows
+        else:
+            p_local = p_local.contiguous()
         n_low, n_loc, d = plan.n_low, plan.n_local, p_local.shape[1]
         table = p_local.new_empty((plan.n_table, d))
         with _Side(dev, p_local, table) as fwd:
@@ -392,7 +402,8 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
         ex_l, ex_h = plan.split_edge_values(extra)
         y_l, y_h = plan.split_edge_values(y)
         # own-source edges: read rows n_low .. n_low + n_local of the table only
-        r_loc = ops.decoder_train(table, q_local, st_loc, ex_l, cvec, w2, b2, w3, b3, y_l, pos_weight, denom)
+        r_loc = ops.decoder_train(table, q_local, st_loc, ex_l, cvec, w2, b2, w3, b3, y_l, pos_weight, denom,
+                                  **({"out_q": gpq[:, d:]} if joint else {}))
         fwd.done()
         box = {}
 
@@ -409,13 +420,22 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
         loss_l, logit_l, gp_l, gq_l = r_loc[:4]
         loss_h, logit_h, _, gq_h = r_halo[:4]
         gp_local = gp_l[n_low:n_low + n_loc]                     # rows of halo sources are zero in gp_l
+        if joint:
+            gpq[:, :d].copy_(gp_local)
+            gp_local = gpq[:, :d]
         box["bwd"].done()
         if box["back"].shape[0]:
             ops.accumulate_back(gp_local, box["back"].float(), plan)
-        gq = gq_l.add_(gq_h)
-        small = [None if a is None else a + b for a, b in zip(r_loc[4:], r_halo[4:])]     # g_cv, g_w2, g_b2, g_w3, g_b3
+        gq = gq_l.add_(gq_h)                                     # (joint: gq_l IS gpq[:, d:])
+        a_s, b_s = r_loc[4:], r_halo[4:]                          # g_cv, g_w2, g_b2, g_w3, g_b3 of the two ranges
+        live = [i for i, a in enumerate(a_s) if a is not None]
+        small = [None] * len(a_s)
+        for i, t in zip(live, torch._foreach_add([a_s[i] for i in live], [b_s[i] for i in live])):   # one launch
+            small[i] = t
         logits = plan.merge_edge_values(logit_l, logit_h)
-        ctx.has_cv = small[0] is not None
+        ctx.has_cv, ctx.joint = small[0] is not None, joint
+        if joint:
+            gp_local, gq = gpq, gpq.new_empty(0)
         ctx.save_for_backward(gp_local, gq, small[0] if small[0] is not None else gq.new_empty(0), *small[1:])
         ctx.mark_non_differentiable(logits)
         return (loss_l + loss_h).view(()), logits
@@ -424,8 +444,8 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
     def backward(ctx, go, _go_logits):
         gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = ctx.saved_tensors
         k = (lambda t: t) if PF.is_unit_grad(go) else (lambda t: t * go)
-        return (k(gp), k(gq), None, None, None, None, None, k(g_cv) if ctx.has_cv else None, k(g_w2), k(g_b2), k(g_w3),
-                k(g_b3), None, None, None)
+        return (k(gp), None if ctx.joint else k(gq), None, None, None, None, None, k(g_cv) if ctx.has_cv else None, k(g_w2),
+                k(g_b2), k(g_w3), k(g_b3), None, None, None)
 
 
 # --------------------------------------------------------------------------------------
@@ -532,14 +552,16 @@ class HipOps:
     def decoder_loss(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
         return PF.decoder_loss(p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
 
-    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None):
+    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None, out_q=None):
         """one-pass training decoder on (a range of) a shard: (loss, logits, dL/dtable, dL/dq, g_cvec, g_w2, g_b2, g_w3,
-        g_b3), all finished; `after_p(dL/dtable)` runs before the by-target pass is enqueued"""
+        g_b3), all finished; `after_p(dL/dtable)` runs before the by-target pass is enqueued; `out_q`: where dL/dq is written
+        (a column window of a wider matrix is fine)"""
         f = PF._f32c
         pw = None if pos_weight is None else f(pos_weight).reshape(-1)
         loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = PF._decoder_train16(
             PF._rows_dec(table), PF._rows_dec(q_local), st, None if extra is None else f(extra),
-            None if cvec is None else f(cvec), f(w2), f(b2), f(w3), f(b3), y=f(y), pw=pw, denom=denom, after_p=after_p)
+            None if cvec is None else f(cvec), f(w2), f(b2), f(w3), f(b3), y=f(y), pw=pw, denom=denom, after_p=after_p,
+            out_q=out_q)
         return loss.view(()), logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
 
     def linear(self, x, w, b, in_act: int = 0, out_dtype=None):
@@ -763,6 +785,16 @@ class DistAlternateGCN(AlternateGCN):
         cvec = w[:, 2 * d].contiguous() if fl.skip_connections else None
         return p_full, q, extra, cvec
 
+    def _dec_in_joint(self, z, shard, in_act: int = 0):
+        """(P | Q [n_local, 2 D] of this rank's rows, extra, cvec): the re-associated first decoder layer as one product"""
+        fl = self.flags
+        d = z.shape[1]
+        lin0 = self.mlp[0]
+        w_pq, b_pq, cvec = PF.pq_operands(lin0.weight, lin0.bias, d, bool(fl.skip_connections))
+        pq_dtype = torch.bfloat16 if (PF.autocast_bf16(z) and PF.DECODER_PRECISION == 1) else None
+        pq = self._linear(z, w_pq, b_pq, in_act, pq_dtype)
+        return pq, (shard.edge_attr if fl.skip_connections else None), cvec
+
     def decode_mlp(self, z, shard):
         p_full, q, extra, cvec = self._dec_in(z, shard)
         return self.ops.decoder(p_full, q, self._st(shard, "sim"), extra, cvec, self.mlp[2].weight,
@@ -778,7 +810,13 @@ class DistAlternateGCN(AlternateGCN):
         if not fold:
             z = self.activation_fct(z) if pending else z
         if torch.is_grad_enabled() and self._overlap_ok(shard):
-            p, q, extra, cvec = self._dec_in(z, shard, 1 if fold else 0, gather=False)
+            if isinstance(self.ops, HipOps) and z.shape[1] == 64:
+                # ONE node-level product z -> P | Q (AlternateGCN._decoder_inputs' layout): the decoder reads its two column
+                # halves in place and hands back one [n_local, 128] gradient
+                p, extra, cvec = self._dec_in_joint(z, shard, 1 if fold else 0)
+                q = None
+            else:
+                p, q, extra, cvec = self._dec_in(z, shard, 1 if fold else 0, gather=False)
             st_loc, st_halo = self._st_split(shard)
             return _OverlappedDecoderLoss.apply(p, q, self.ops, self._plan(shard, "sim"), st_loc, st_halo, extra, cvec,
                                                 self.mlp[2].weight, self.mlp[2].bias, self.mlp[4].weight.view(-1),
