@@ -387,7 +387,11 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
             pq = p_local if p_local.stride(1) == 1 else p_local.contiguous()
             dj = pq.shape[1] // 2
             p_local, q_local = pq[:, :dj], pq[:, dj:]
-            gpq = torch.empty(pq.shape, dtype=torch.float32, device=dev)         # [dL/dP | dL/dQ] of the own rows
+            # [dL/dP | dL/dQ] over the TABLE's rows: columns [0, D) are the by-source sums of every table row (the halo rows'
+            # part travels back to their owners), rows [n_low, n_low + n_local) of it are the own rows' joint gradient — what the
+            # dense layer's backward reads, in place (no copy of dL/dP into a joint matrix)
+            g_tab = torch.empty((plan.n_table, pq.shape[1]), dtype=torch.float32, device=dev)
+            gpq = g_tab[plan.n_low:plan.n_low + plan.n_local]
         else:
             p_local = p_local.contiguous()
         n_low, n_loc, d = plan.n_low, plan.n_local, p_local.shape[1]
@@ -403,7 +407,7 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
         y_l, y_h = plan.split_edge_values(y)
         # own-source edges: read rows n_low .. n_low + n_local of the table only
         r_loc = ops.decoder_train(table, q_local, st_loc, ex_l, cvec, w2, b2, w3, b3, y_l, pos_weight, denom,
-                                  **({"out_q": gpq[:, d:]} if joint else {}))
+                                  **({"out_q": gpq[:, d:], "out_p": g_tab[:, :d]} if joint else {}))
         fwd.done()
         box = {}
 
@@ -415,18 +419,15 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
                 bwd.keep(back)
             box["bwd"], box["back"] = bwd, back
 
+        # the halo-source range has the same targets: its by-target pass adds into the own-source range's dL/dQ
         r_halo = ops.decoder_train(table, q_local, st_halo, ex_h, cvec, w2, b2, w3, b3, y_h, pos_weight, denom,
-                                   after_p=send_back)
-        loss_l, logit_l, gp_l, gq_l = r_loc[:4]
-        loss_h, logit_h, _, gq_h = r_halo[:4]
+                                   after_p=send_back, out_q=r_loc[3], accumulate_q=True)
+        loss_l, logit_l, gp_l, gq = r_loc[:4]
+        loss_h, logit_h = r_halo[:2]
         gp_local = gp_l[n_low:n_low + n_loc]                     # rows of halo sources are zero in gp_l
-        if joint:
-            gpq[:, :d].copy_(gp_local)
-            gp_local = gpq[:, :d]
         box["bwd"].done()
         if box["back"].shape[0]:
             ops.accumulate_back(gp_local, box["back"].float(), plan)
-        gq = gq_l.add_(gq_h)                                     # (joint: gq_l IS gpq[:, d:])
         a_s, b_s = r_loc[4:], r_halo[4:]                          # g_cv, g_w2, g_b2, g_w3, g_b3 of the two ranges
         live = [i for i, a in enumerate(a_s) if a is not None]
         small = [None] * len(a_s)
@@ -552,16 +553,17 @@ class HipOps:
     def decoder_loss(self, p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom):
         return PF.decoder_loss(p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
 
-    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None, out_q=None):
+    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None, out_q=None,
+                      accumulate_q=False, out_p=None):
         """one-pass training decoder on (a range of) a shard: (loss, logits, dL/dtable, dL/dq, g_cvec, g_w2, g_b2, g_w3,
         g_b3), all finished; `after_p(dL/dtable)` runs before the by-target pass is enqueued; `out_q`: where dL/dq is written
-        (a column window of a wider matrix is fine)"""
+        (a column window of a wider matrix is fine), or ADDED to it with `accumulate_q`"""
         f = PF._f32c
         pw = None if pos_weight is None else f(pos_weight).reshape(-1)
         loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = PF._decoder_train16(
             PF._rows_dec(table), PF._rows_dec(q_local), st, None if extra is None else f(extra),
             None if cvec is None else f(cvec), f(w2), f(b2), f(w3), f(b3), y=f(y), pw=pw, denom=denom, after_p=after_p,
-            out_q=out_q)
+            out_q=out_q, accumulate_q=accumulate_q, out_p=out_p)
         return loss.view(()), logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
 
     def linear(self, x, w, b, in_act: int = 0, out_dtype=None):

@@ -420,18 +420,19 @@ def d16_chunk(num_edges: Optional[int] = None) -> int:
     return int(lib.pangnn_decoder_chunk_tiles() if num_edges is None else lib.pangnn_decoder_chunk_tiles_for(int(num_edges)))
 
 
-def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor) -> torch.Tensor:
-    """out[s] = sum of the consecutive part rows of source s (pangnn_spmm_csr_f32, idx = NULL)"""
+def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """out[s] (+)= sum of the consecutive part rows of source s (pangnn_spmm_csr_f32, idx = NULL)"""
     lib = _lib.load()
     with _lib.device_guard(part_buf.device):
         _lib.check(lib.pangnn_spmm_csr_f32(plan.part_rowptr.data_ptr(), None, None, _lib.ptr(part_buf),
                                            part_buf.stride(0), part_buf.shape[0], None, out.data_ptr(),
-                                           out.stride(0), n_rows, part_buf.shape[0], part_buf.shape[1], 0,
+                                           out.stride(0), n_rows, part_buf.shape[0], part_buf.shape[1], int(accumulate),
                                            _lib.stream_ptr()), "pangnn_spmm_csr_f32(parts)")
     return out
 
 
-def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 0, out=None, g_b2=None, live=None):
+def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 0, out=None, g_b2=None, live=None,
+               accumulate: bool = False):
     """dL/dh1 summed over the rows of CSR order `by` ("src" / "dst") from the per-edge records of the training
     kernel: pangnn_decoder_dgrad_f32 (run parts) + the short contiguous part sum.  `g_b2`: also filled with dL/db2
     (one call per step asks for it); by = None: the parameter sums alone."""
@@ -454,11 +455,13 @@ def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 
         _timer_stop("dec.dgrad", ev)
     if plan is None:
         return None
-    return _sum_parts(plan, parts, n_rows, out if out is not None else torch.empty(n_rows, 64, device=dev))
+    if out is None:
+        out, accumulate = torch.empty(n_rows, 64, device=dev), False
+    return _sum_parts(plan, parts, n_rows, out, accumulate)
 
 
 def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw=None, denom=0, g_logits=None,
-                     out_p=None, out_q=None, need_p=True, need_q=True, after_p=None, live=None):
+                     out_p=None, out_q=None, need_p=True, need_q=True, after_p=None, live=None, accumulate_q=False):
     """Two-wave-per-SIMD training decoder (csrc/decoder16.hip).  One pass over the edges in the caller's order (S):
     logits, loss (y given) or the given dL/dlogits, every parameter gradient, per-source run sums when the list is
     source-sorted, and a 32-byte record per edge; then dL/dQ (and dL/dP for unsorted lists) from the records in CSR
@@ -466,7 +469,8 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
     `after_p(gp)` is called once dL/dP is enqueued and before the T pass (the partitioned model starts the return
     exchange of the halo rows' gradients there, so that it runs under T).
     `live` (device int64[1], optional): the list is a fixed-shape padded batch whose first live[0] edges are real
-    (include/pangnn_hip.h, live_edges): the padding enters no sum and the fused loss is the mean over live[0] edges."""
+    (include/pangnn_hip.h, live_edges): the padding enters no sum and the fused loss is the mean over live[0] edges.
+    `accumulate_q` (with out_q): dL/dQ is ADDED to out_q (a second edge range of the same targets: the partitioned decoder)."""
     lib = _lib.load()
     dev = p.device
     e, d = st.num_edges, p.shape[1]
@@ -506,10 +510,11 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
         if after_p is not None:
             after_p(gp)
     if need_q:
+        acc_q = bool(accumulate_q) and out_q is not None
         if e == 0:
-            gq = (out_q if out_q is not None else torch.empty(q.shape[0], d, device=dev)).zero_()
+            gq = out_q if acc_q else (out_q if out_q is not None else torch.empty(q.shape[0], d, device=dev)).zero_()
         else:
-            gq = _dgrad_sum(rec, st, "dst", w2, w3, q.shape[0], out_q, g_b2=b2_out, live=live)
+            gq = _dgrad_sum(rec, st, "dst", w2, w3, q.shape[0], out_q, g_b2=b2_out, live=live, accumulate=acc_q)
             b2_out = None
     if b2_out is not None:
         if e == 0:
