@@ -63,8 +63,10 @@ class TorchOps:
             h = h + extra.view(-1, 1) * cvec
         return torch.relu(torch.relu(h) @ w2.t() + b2) @ w3 + b3
 
-    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None):
-        """the one-pass training decoder of HipOps, by autograd: everything finished on return"""
+    def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None, out_q=None,
+                      accumulate_q=False, out_p=None):
+        """the one-pass training decoder of HipOps, by autograd: everything finished on return (out_p / out_q: where dL/dtable and
+        dL/dq go; accumulate_q: dL/dq is added to out_q)"""
         leaves = [t.detach().clone().requires_grad_() for t in (table, q_local, w2, b2, w3, b3)]
         cv = None if cvec is None else cvec.detach().clone().requires_grad_()
         with torch.enable_grad():
@@ -74,10 +76,12 @@ class TorchOps:
                 grads = torch.autograd.grad(loss, leaves + ([cv] if cv is not None else []))
             else:
                 grads = [torch.zeros_like(t) for t in leaves + ([cv] if cv is not None else [])]
+        gp = grads[0] if out_p is None else out_p.copy_(grads[0])
         if after_p is not None:
-            after_p(grads[0])
+            after_p(gp)
+        gq = grads[1] if out_q is None else (out_q.add_(grads[1]) if accumulate_q else out_q.copy_(grads[1]))
         g_cv = grads[6] if cv is not None else None
-        return (loss.detach(), logits.detach(), grads[0], grads[1], g_cv, grads[2], grads[3], grads[4], grads[5])
+        return (loss.detach(), logits.detach(), gp, gq, g_cv, grads[2], grads[3], grads[4], grads[5])
 
     def linear(self, x, w, b, in_act=0):
         return torch.nn.functional.linear(torch.nn.functional.elu(x) if in_act else x, w, b)
