@@ -72,23 +72,44 @@ def summary_from_confusion(conf) -> dict:
                 accuracy=(tp + tn) / total if total else 0.0)
 
 
+_LAST_CURVE = None
+
+
+def forget_curve():
+    """drop the kept curve (and the references to the tensors it was computed from)"""
+    global _LAST_CURVE
+    _LAST_CURVE = None
+
+
 class _RankingMetric:
     """keeps (score, label) of every update on the device, like torchmetrics with thresholds=None"""
 
     def __init__(self):
-        self.scores, self.labels = [], []
+        self.scores, self.labels, self._src = [], [], []
 
     def update(self, preds, target):
         self.scores.append(preds.detach().reshape(-1).to(torch.float32))
         self.labels.append((target.detach().reshape(-1) > 0.5))
+        self._src.append((preds, target, preds._version, target._version))
 
     def reset(self):
-        self.scores, self.labels = [], []
+        self.scores, self.labels, self._src = [], [], []
 
     def _curve(self):
-        """(tps, fps) at every distinct threshold, scores descending; int64"""
-        s = torch.cat(self.scores)
-        y = torch.cat(self.labels)
+        """(tps, fps) at every distinct threshold, scores descending; int64.  The curve of the LAST computed data set is kept:
+        ROC-AUC and PR-AUC of one validation pass (pangnn.py:255-285) are updated with the same tensors, and the second metric
+        then reuses the first one's sort (7.5e7 scores at config 4: the sort is most of the pass)."""
+        global _LAST_CURVE
+        hit = _LAST_CURVE
+        if hit is not None and len(hit[0]) == len(self._src) and all(
+                a[0] is b[0] and a[1] is b[1] and a[2] == b[2] and a[3] == b[3] for a, b in zip(hit[0], self._src)):
+            return hit[1], hit[2]
+        tps, fps = self._curve_of(torch.cat(self.scores), torch.cat(self.labels))
+        _LAST_CURVE = (list(self._src), tps, fps)         # holds the source tensors: their identity cannot be recycled
+        return tps, fps
+
+    @staticmethod
+    def _curve_of(s, y):
         s, order = torch.sort(s, descending=True, stable=True)
         y = y[order].to(torch.int64)
         n = s.shape[0]

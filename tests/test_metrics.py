@@ -33,6 +33,38 @@ def test_ranking_metrics_match_sklearn_on_host_tensors(n, ties):
     assert float(auroc.compute()) == 0.0
 
 
+def test_two_ranking_metrics_fed_the_same_tensors_share_one_sorted_curve(monkeypatch):
+    """ROC-AUC and PR-AUC of one validation pass get the same (probabilities, labels) tensors: the second compute() must reuse
+    the first one's curve (one sort), and must NOT reuse it for other tensors or after an in-place change"""
+    from pangnn_amd import metrics as M
+    s, y = _scores(3000, 7, True)
+    y[0], y[1] = 0.0, 1.0
+    p = torch.from_numpy(1.0 / (1.0 + np.exp(-s)))
+    t = torch.from_numpy(y)
+    calls = []
+    real = M._RankingMetric._curve_of
+    monkeypatch.setattr(M._RankingMetric, "_curve_of", staticmethod(lambda a, b: (calls.append(1), real(a, b))[1]))
+    M.forget_curve()
+    auroc, ap = BinaryAUROC(), BinaryAveragePrecision()
+    auroc.update(p, t)
+    ap.update(p, t)
+    assert abs(float(auroc.compute()) - roc_auc_score(y, p.numpy())) < 1e-6
+    assert abs(float(ap.compute()) - average_precision_score(y, p.numpy())) < 1e-6
+    assert len(calls) == 1
+    p2 = p.clone()
+    other = BinaryAveragePrecision()
+    other.update(p2, t)                                   # equal values, another tensor: computed afresh
+    other.compute()
+    assert len(calls) == 2
+    p2.mul_(0.5)                                          # the same tensor changed in place: the version counter differs
+    again = BinaryAUROC()
+    again.update(p2, t)
+    again.compute()
+    assert len(calls) == 3
+    M.forget_curve()
+    assert M._LAST_CURVE is None
+
+
 def test_ranking_metrics_degenerate_classes():
     a, p = BinaryAUROC(), BinaryAveragePrecision()
     a.update(torch.tensor([0.2, 0.7]), torch.tensor([0.0, 0.0]))
