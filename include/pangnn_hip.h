@@ -39,9 +39,9 @@ extern "C" {
 /* storage types of the *_mixed entry points: the arithmetic is fp32 either way, a matrix may be STORED as bfloat16 */
 #define PANGNN_DTYPE_F32  0
 #define PANGNN_DTYPE_BF16 1
-#define PANGNN_DTYPE_F16  2   /* IEEE half rows (--mixed_precision fp16): accepted wherever a *_dtype argument of the node-level
-                               * entry points (dense layers, propagate gathers, generated rows, column sums) accepts _BF16; the
-                               * 2-byte operands of one call are all bfloat16 or all float16.  The decoder's pq_dtype is F32 / BF16. */
+#define PANGNN_DTYPE_F16  2   /* IEEE half rows (--mixed_precision fp16): accepted wherever a *_dtype argument accepts _BF16
+                               * (dense layers, propagate gathers, generated rows, column sums, the decoder's P | Q tables); the
+                               * 2-byte operands of one call are all bfloat16 or all float16. */
 
 typedef void* pangnn_stream_t;   /* hipStream_t */
 

@@ -25,6 +25,19 @@
 // ONE tile body, every lane is active in every MFMA / transposing LDS read, and only global stores are predicated.
 #include "common.h"
 
+// This file is compiled TWICE (csrc/Makefile): as decoder16.o — everything, the 2-byte table format of the PQ16 instances being
+// bfloat16 — and, with -DPANGNN_D16_TABLES_F16, as decoder16_f16.o: the S and inference kernels again with PQ16 = IEEE half
+// (`--mixed_precision fp16`), under their own names, plus their two launchers; nothing else of the file.  The float32 /
+// bfloat16 kernels of decoder16.o are thereby exactly what they were before the float16 format existed (same source, same
+// template signatures, same code object).
+#ifdef PANGNN_D16_TABLES_F16
+#define decoder_train16_kernel decoder_train16_f16_kernel
+#define decoder_infer16_kernel decoder_infer16_f16_kernel
+#define D16_TABLES16(name) name##_f16
+#else
+#define D16_TABLES16(name) name##_bf16
+#endif
+
 namespace pangnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -50,7 +63,7 @@ constexpr int S_WAVES = 8;                            // 512 threads, one workgr
 // waves instead of 4 (S 138 -> 19 us, T 63 -> 15 us at E = 2 000: its waves walked 16 tiles each, one after the other).
 constexpr int D16_CHUNK_LOG_MAX = 4;
 constexpr int64_t D16_MIN_CHUNKS = 2048;               // waves of one full launch (256 CUs x 8)
-static inline int chunk_log_for(int64_t n_tiles) {
+__attribute__((unused)) static inline int chunk_log_for(int64_t n_tiles) {
   int c = D16_CHUNK_LOG_MAX;
   while (c > 0 && (n_tiles >> c) < D16_MIN_CHUNKS) --c;
   return c;
@@ -646,8 +659,15 @@ __device__ __forceinline__ void sum_rows(const HalfRowsT<true>& rows, float (&h)
     const uint32_t qw[4] = {rows.q[ks].x, rows.q[ks].y, rows.q[ks].z, rows.q[ks].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#ifdef PANGNN_D16_TABLES_F16
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));              // IEEE half: v_cvt_f32_f16, exact
+      const h2 pv = __builtin_bit_cast(h2, pw[j]), qv = __builtin_bit_cast(h2, qw[j]);
+      h[ks][2 * j] = (float)pv[0] + (float)qv[0];
+      h[ks][2 * j + 1] = (float)pv[1] + (float)qv[1];
+#else
       h[ks][2 * j] = __builtin_bit_cast(float, pw[j] << 16) + __builtin_bit_cast(float, qw[j] << 16);
       h[ks][2 * j + 1] = __builtin_bit_cast(float, pw[j] & 0xffff0000u) + __builtin_bit_cast(float, qw[j] & 0xffff0000u);
+#endif
     }
   }
 }
@@ -1308,6 +1328,40 @@ __global__ __launch_bounds__(I_WAVES * 64) void decoder_infer16_kernel(D16Params
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 namespace pangnn {
+// launchers of the PQ16 instances (2-byte tables): launch_train16_tables_bf16 / launch_infer16_tables_bf16 in decoder16.o,
+// ..._f16 in decoder16_f16.o.  `a` carries the row strides in bytes; y / part_buf / extra select the instance.
+int D16_TABLES16(launch_train16_tables)(const D16Params& a, const float* g_logits, const D16Loss& lp, float* logits,
+                                        const D16Run& rs, uint32_t* rec, float* ws, int64_t n_tiles, unsigned grid,
+                                        hipStream_t s) {
+  const dim3 gd(grid), bd(S_WAVES * 64);
+#define PG_S16(F, R)                                                                                                  \
+  do {                                                                                                                \
+    if (a.extra)                                                                                                      \
+      hipLaunchKernelGGL((decoder_train16_kernel<F, R, true, true>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);   \
+    else                                                                                                              \
+      hipLaunchKernelGGL((decoder_train16_kernel<F, R, true, false>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles);  \
+  } while (0)
+  if (lp.y && rs.part) PG_S16(true, true);
+  else if (lp.y) PG_S16(true, false);
+  else if (rs.part) PG_S16(false, true);
+  else PG_S16(false, false);
+#undef PG_S16
+  return 0;
+}
+int D16_TABLES16(launch_infer16_tables)(const D16Params& a, float* logits, int64_t n_tiles, unsigned grid, hipStream_t s) {
+  if (a.extra)
+    hipLaunchKernelGGL((decoder_infer16_kernel<true, true>), dim3(grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles);
+  else
+    hipLaunchKernelGGL((decoder_infer16_kernel<true, false>), dim3(grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles);
+  return 0;
+}
+}  // namespace pangnn
+
+#ifndef PANGNN_D16_TABLES_F16        // ---- everything below: decoder16.o only
+namespace pangnn {
+int launch_train16_tables_f16(const D16Params& a, const float* g_logits, const D16Loss& lp, float* logits, const D16Run& rs,
+                              uint32_t* rec, float* ws, int64_t n_tiles, unsigned grid, hipStream_t s);      // decoder16_f16.o
+int launch_infer16_tables_f16(const D16Params& a, float* logits, int64_t n_tiles, unsigned grid, hipStream_t s);
 // decoder.hip: sums the per-workgroup slabs (layout SLAB16) in index order
 int launch_decoder_reduce(const float* slabs, int n_slabs, float* g_w2, float* g_b2, float* g_w3, float* g_cvec,
                           float* g_b3, float* loss, hipStream_t s);
@@ -1331,18 +1385,19 @@ static int cu_count() {
 
 namespace pangnn {
 // decoder.hip (pangnn_decoder_mlp_infer_f32, precision = 1) -> the 16-edge-tile inference kernel of this file
-static int launch_infer16_any(const void* p, int64_t ldp, const void* q, int64_t ldq, bool pq16, const int64_t* edge_index,
+static int launch_infer16_any(const void* p, int64_t ldp, const void* q, int64_t ldq, int pq_fmt, const int64_t* edge_index,
                               int64_t ld, int64_t num_edges, const float* extra, const float* cvec, const float* w2,
                               const float* b2, const float* w3, const float* b3, float* logits, hipStream_t s) {
   const int64_t n_tiles = (num_edges + 15) / 16;
   int64_t grid = (n_tiles + I_WAVES - 1) / I_WAVES;
   const int cus = cu_count();
   if (grid > cus) grid = cus;
-  const uint32_t esz = pq16 ? 2u : 4u;
+  const uint32_t esz = pq_fmt ? 2u : 4u;                 // pq_fmt: PANGNN_DTYPE_F32 / _BF16 / _F16
   D16Params a{p, q, (uint32_t)ldp * esz, (uint32_t)ldq * esz, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3,
               nullptr};
 #define PG_I(H, X) hipLaunchKernelGGL((decoder_infer16_kernel<H, X>), dim3((unsigned)grid), dim3(I_WAVES * 64), 0, s, a, logits, n_tiles)
-  if (pq16) { if (extra) PG_I(true, true); else PG_I(true, false); }
+  if (pq_fmt == PANGNN_DTYPE_F16) launch_infer16_tables_f16(a, logits, n_tiles, (unsigned)grid, s);
+  else if (pq_fmt) launch_infer16_tables_bf16(a, logits, n_tiles, (unsigned)grid, s);
   else { if (extra) PG_I(false, true); else PG_I(false, false); }
 #undef PG_I
   PG_CHECK_LAUNCH("pangnn_decoder_mlp_infer");
@@ -1351,7 +1406,7 @@ static int launch_infer16_any(const void* p, int64_t ldp, const void* q, int64_t
 int launch_decoder_infer16(const float* p, int64_t ldp, const float* q, int64_t ldq, const int64_t* edge_index, int64_t ld,
                            int64_t num_edges, const float* extra, const float* cvec, const float* w2, const float* b2,
                            const float* w3, const float* b3, float* logits, hipStream_t s) {
-  return launch_infer16_any(p, ldp, q, ldq, false, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3, logits, s);
+  return launch_infer16_any(p, ldp, q, ldq, PANGNN_DTYPE_F32, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3, logits, s);
 }
 }  // namespace pangnn
 
@@ -1386,8 +1441,8 @@ extern "C" int pangnn_decoder_mlp_infer_mixed(const void* p, int64_t ldp, const 
                                              const float* w3, const float* b3, int32_t D, float* logits,
                                              pangnn_stream_t stream) {
   const char* who = "pangnn_decoder_mlp_infer_mixed";
-  const bool pq16 = pq_dtype == PANGNN_DTYPE_BF16;
-  PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  const bool pq16 = pq_dtype == PANGNN_DTYPE_BF16 || pq_dtype == PANGNN_DTYPE_F16;          // a 2-byte table format
+  PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16 / _F16", who);
   PG_CHECK_ARG(D == D16, PANGNN_E_BADARG, "%s: built for node_dim 64, got %d", who, (int)D);
   PG_CHECK_ARG(num_edges >= 0 && ld >= num_edges && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
   PG_CHECK_ARG(ldp >= D16 && ldq >= D16 && ldp % 8 == 0 && ldq % 8 == 0, PANGNN_E_BADARG,
@@ -1398,7 +1453,7 @@ extern "C" int pangnn_decoder_mlp_infer_mixed(const void* p, int64_t ldp, const 
   PG_CHECK_ARG(p && q && edge_index && w2 && b2 && w3 && b3 && logits && (!extra || cvec), PANGNN_E_BADARG,
                "%s: null pointer", who);
   PG_CHECK_ARG(aligned16(p) && aligned16(q) && aligned16(w2), PANGNN_E_ALIGN, "%s: p / q / w2 must be 16-byte aligned", who);
-  return launch_infer16_any(p, ldp, q, ldq, pq16, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3, logits,
+  return launch_infer16_any(p, ldp, q, ldq, pq_dtype, edge_index, ld, num_edges, extra, cvec, w2, b2, w3, b3, logits,
                             (hipStream_t)stream);
 }
 
@@ -1412,14 +1467,14 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
                                           const int64_t* live_edges, void* workspace, size_t workspace_bytes,
                                           pangnn_stream_t stream) {
   const char* who = "pangnn_decoder_train";
-  const bool pq16 = pq_dtype == PANGNN_DTYPE_BF16;
-  PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16", who);
+  const bool pq16 = pq_dtype == PANGNN_DTYPE_BF16 || pq_dtype == PANGNN_DTYPE_F16;          // a 2-byte table format
+  PG_CHECK_ARG(pq16 || pq_dtype == PANGNN_DTYPE_F32, PANGNN_E_BADARG, "%s: pq_dtype is PANGNN_DTYPE_F32 / _BF16 / _F16", who);
   PG_CHECK_ARG(D == D16, PANGNN_E_BADARG, "%s: built for node_dim 64, got %d", who, (int)D);
   PG_CHECK_ARG(num_edges >= 0 && ld >= num_edges && num_nodes >= 0, PANGNN_E_BADARG, "%s: bad size", who);
   // the records this pass writes are read back by pangnn_decoder_dgrad_f32 through int32 edge ids
   PG_CHECK_ARG(num_edges < 2147483647LL, PANGNN_E_TOOLARGE, "%s: num_edges must fit int32 (partition the graph first)", who);
   PG_CHECK_ARG(ldp >= D16 && ldq >= D16 && ldp % (pq16 ? 8 : 4) == 0 && ldq % (pq16 ? 8 : 4) == 0, PANGNN_E_BADARG,
-               "%s: ldp / ldq must be multiples of 4 (f32) / 8 (bf16) and >= 64", who);
+               "%s: ldp / ldq must be multiples of 4 (f32) / 8 (bf16, f16) and >= 64", who);
   PG_CHECK_ARG((double)num_nodes * (double)(ldp > ldq ? ldp : ldq) * (pq16 ? 2.0 : 4.0) < 4294967296.0, PANGNN_E_TOOLARGE,
                "%s: node tables must stay under 4 GiB (32-bit gather offsets)", who);
   PG_CHECK_ARG(g_w2 && g_w3 && g_b3, PANGNN_E_BADARG, "%s: null gradient output", who);
@@ -1462,11 +1517,10 @@ extern "C" int pangnn_decoder_train_mixed(const void* p, int64_t ldp, const void
       hipLaunchKernelGGL((decoder_train16_kernel<F, R, H, false>), gd, bd, 0, s, a, g_logits, lp, logits, rs, rec, ws, n_tiles); \
   } while (0)
 #define PG_S(F, R, H) PG_S2(F, R, H)
-    if (pq16) {
-      if (y && part_buf) PG_S(true, true, true);
-      else if (y) PG_S(true, false, true);
-      else if (part_buf) PG_S(false, true, true);
-      else PG_S(false, false, true);
+    if (pq_dtype == PANGNN_DTYPE_F16) {
+      launch_train16_tables_f16(a, g_logits, lp, logits, rs, rec, ws, n_tiles, (unsigned)grid, s);
+    } else if (pq16) {
+      launch_train16_tables_bf16(a, g_logits, lp, logits, rs, rec, ws, n_tiles, (unsigned)grid, s);
     } else {
       if (y && part_buf) PG_S(true, true, false);
       else if (y) PG_S(true, false, false);
@@ -1540,3 +1594,4 @@ extern "C" int pangnn_decoder_dgrad_f32(const uint32_t* rec, const int32_t* perm
   }
   return 0;
 }
+#endif  // !PANGNN_D16_TABLES_F16

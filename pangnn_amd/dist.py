@@ -778,8 +778,7 @@ class DistAlternateGCN(AlternateGCN):
         lin0 = self.mlp[0]
         w = lin0.weight
         # bf16 mixed precision (config 5): P and Q are stored as bfloat16 — the halo exchange of P moves half the bytes
-        pq_dtype = torch.bfloat16 if (isinstance(self.ops, HipOps) and PF.autocast_bf16(z) and d == 64
-                                      and PF.DECODER_PRECISION == 1) else None
+        pq_dtype = PF.autocast_rows_dtype(z) if (isinstance(self.ops, HipOps) and d == 64 and PF.DECODER_PRECISION == 1) else None
         p = self._linear(z, w[:, :d].contiguous(), None, in_act, pq_dtype)
         q = self._linear(z, w[:, d:2 * d].contiguous(), lin0.bias, in_act, pq_dtype)
         p_full = self._table(p, shard, "sim") if gather else p
@@ -793,7 +792,7 @@ class DistAlternateGCN(AlternateGCN):
         d = z.shape[1]
         lin0 = self.mlp[0]
         w_pq, b_pq, cvec = PF.pq_operands(lin0.weight, lin0.bias, d, bool(fl.skip_connections))
-        pq_dtype = torch.bfloat16 if (PF.autocast_bf16(z) and PF.DECODER_PRECISION == 1) else None
+        pq_dtype = PF.autocast_rows_dtype(z) if PF.DECODER_PRECISION == 1 else None
         pq = self._linear(z, w_pq, b_pq, in_act, pq_dtype)
         return pq, (shard.edge_attr if fl.skip_connections else None), cvec
 

@@ -488,7 +488,7 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         ev = _timer_start("dec.bwd")
         if p.dtype != q.dtype:
-            raise ValueError("p and q must be stored alike (both float32 or both bfloat16)")
+            raise ValueError("p and q must be stored alike (both float32, both bfloat16 or both float16)")
         _lib.check(lib.pangnn_decoder_train_mixed(
             p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), _dt(p), max(p.shape[0], q.shape[0]),
             st.edge_index.data_ptr(), e, e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
@@ -556,13 +556,12 @@ def autocast_rows_dtype(t: torch.Tensor):
 
 
 def _rows_dec(t: torch.Tensor) -> torch.Tensor:
-    """decoder tables as the decoder kernels read them: float32 or bfloat16 (float16 tables are converted: no f16 format there)"""
-    return _rows_any(t.float() if t.dtype == torch.float16 else t)
+    """decoder tables as the decoder kernels read them: float32, or bfloat16 / float16 as stored"""
+    return _rows_any(t)
 
 
 def autocast_bf16(t: torch.Tensor) -> bool:
-    """bf16 mixed precision is on for `t`'s device (config 5).  The decoder's P | Q tables have a bfloat16 format only: under
-    float16 autocast they stay fp32 (results at the fp32 level)."""
+    """bf16 mixed precision is on for `t`'s device (config 5)"""
     return autocast_rows_dtype(t) == torch.bfloat16
 
 
@@ -603,8 +602,8 @@ class _DecoderMLP(torch.autograd.Function):
         logits = torch.empty(e, dtype=torch.float32, device=p.device)
         with _lib.device_guard(p.device):
             ev = _timer_start("dec.fwd")
-            if p.dtype == torch.bfloat16:
-                _lib.check(lib.pangnn_decoder_mlp_infer_mixed(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), 1,
+            if p.dtype in ROWS16:
+                _lib.check(lib.pangnn_decoder_mlp_infer_mixed(p.data_ptr(), p.stride(0), q.data_ptr(), q.stride(0), _dt(p),
                                                               max(p.shape[0], q.shape[0]), st.edge_index.data_ptr(), e,
                                                               e, _lib.ptr(ex), _lib.ptr(cv), w2.data_ptr(),
                                                               b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), d,

@@ -206,8 +206,8 @@ class AlternateGCN(nn.Module):
         extra = graph.edge_attr[: ei.shape[1]] if fl.skip_connections else None
         w = self.mlp[0].weight
         w_pq, b_pq, cvec = PF.pq_operands(w, self.mlp[0].bias, d, bool(fl.skip_connections))
-        # bf16 mixed precision: mlp[0] is an autocast Linear, its node-level halves are stored (and gathered) as bfloat16
-        pq_dtype = torch.bfloat16 if (PF.autocast_bf16(z) and d == 64 and PF.DECODER_PRECISION == 1) else None
+        # bf16 / fp16 mixed precision: mlp[0] is an autocast Linear, its node-level halves are stored (and gathered) in that type
+        pq_dtype = PF.autocast_rows_dtype(z) if (d == 64 and PF.DECODER_PRECISION == 1) else None
         return PF.linear(z, w_pq, b_pq, in_act, pq_dtype), st, extra, cvec
 
     def _fused_decoder_operands(self, graph):
@@ -272,7 +272,7 @@ class AlternateGCN(nn.Module):
             # one node-level product gives P | Q = z [W_a ; W_b]^T + [0 ; b1]
             w_pq, b_pq, cvec = PF.pq_operands(w, lin0.bias, d, bool(fl.skip_connections))
             fused = d == 64 and self.fused_decoder != "pair_add"
-            pq_dtype = torch.bfloat16 if (fused and PF.autocast_bf16(z) and PF.DECODER_PRECISION == 1) else None
+            pq_dtype = PF.autocast_rows_dtype(z) if (fused and PF.DECODER_PRECISION == 1) else None
             pq = PF.linear(z, w_pq, b_pq, 0, pq_dtype)
             if fused:
                 # whole per-edge MLP in one HIP kernel (f32 MFMA), no [E, D] tensor in HBM on the way

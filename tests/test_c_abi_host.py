@@ -128,8 +128,8 @@ def test_sizes_beyond_the_int32_index_range_are_refused():
 
 
 def test_storage_type_codes_are_checked_on_the_host():
-    """PANGNN_DTYPE_F16 (2) is a storage type of the node-level entry points, not of the decoder's tables; the 2-byte operands
-    of one call share a format; an unknown code is refused everywhere — all before a pointer is touched"""
+    """PANGNN_DTYPE_F16 (2) is a storage type next to bfloat16; the 2-byte operands of one call share a format; an unknown code
+    is refused everywhere — all before a pointer is touched"""
     L = lib()
     F32, BF16, F16 = 0, 1, 2
     # dense layer: bfloat16 x with a float16 result / float16 g with bfloat16 x
@@ -140,11 +140,13 @@ def test_storage_type_codes_are_checked_on_the_host():
     assert L.pangnn_linear_act_fwd_mixed(F, 3, 64, F, None, F, F32, 64, N, 64, 64, 0, None, F32, 0, None) == E_BADARG
     # 2-byte rows start on 8 bytes, not 16 (F + 8 is fine for f16 x, not for f32 x)
     assert L.pangnn_linear_act_fwd_mixed(F + 8, F32, 64, F, None, F, F32, 64, N, 64, 64, 0, None, F32, 0, None) == E_ALIGN
-    # the decoder's tables: float32 or bfloat16 only
+    # the decoder's tables: float32, bfloat16 or float16 (2-byte tables: row strides in multiples of 8 elements)
     args = _decoder_common(dtype_arg=True)
-    args[4] = F16
+    args[4] = 3
     assert L.pangnn_decoder_mlp_infer_mixed(*args, F, None) == E_BADARG
     assert b"pq_dtype" in L.pangnn_last_error()
+    args[4], args[1] = F16, 68
+    assert L.pangnn_decoder_mlp_infer_mixed(*args, F, None) == E_BADARG
     # generated rows / column sums / band: 0, 1, 2 are the codes
     assert L.pangnn_rank2_rows(F, F, F, F, None, F, 3, 64, N, 64, None) == E_BADARG
     wsb = L.pangnn_weighted_colsum3_workspace_bytes(64)

@@ -192,10 +192,10 @@ def test_propagate_with_f16_output_rounds_once_and_its_backward_gathers_f16_rows
                          ids=["default", "union", "base", "skip"])
 def test_model_under_fp16_autocast_stores_linear_outputs_as_f16(flags):
     """Under float16 autocast the reference's Linear layers return float16 tensors (src/gnn.py:93,111 with accelerate's fp16
-    mixed precision): the rows conv_in writes, the x W^T rows that are propagated — WRITTEN as float16 by the kernels that
-    produce them and read as stored by the next one.  The decoder's P | Q stay fp32 (no float16 table format in the decoder
-    kernels).  Logits and gradients sit at float16 resolution of the fp32 run — nearer to it than the oracle under float16
-    CPU autocast (the reference's own arithmetic) is."""
+    mixed precision): the rows conv_in writes, the x W^T rows that are propagated, the decoder's P | Q — WRITTEN as float16 by
+    the kernels that produce them and read as stored by the next one (linear / propagate / decoder gather).  Logits and
+    gradients sit at float16 resolution of the fp32 run — nearer to it than the oracle under float16 CPU autocast (the
+    reference's own arithmetic) is."""
     import pangnn_amd
     from torch.utils._python_dispatch import TorchDispatchMode
     g = whole_graph_from_golden("cfg2_sim_1000x5")
@@ -227,7 +227,7 @@ def test_model_under_fp16_autocast_stores_linear_outputs_as_f16(flags):
     assert first == [F16]
     if not flags.get("base_model"):
         assert any(o == F16 for _, _, o in seen), seen            # a GCNConv's dense part wrote float16 rows
-    assert (F32, (128, 64), F32) in seen                          # P | Q = z [W_a ; W_b]^T: fp32 in, fp32 out
+    assert (F32, (128, 64), F16) in seen                          # P | Q = z [W_a ; W_b]^T: fp32 z in, float16 tables out
     assert logits.dtype == F32 and all(p.grad is None or p.grad.dtype == F32 for p in model.parameters())
     grads16 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
     model.zero_grad()
@@ -249,3 +249,49 @@ def test_model_under_fp16_autocast_stores_linear_outputs_as_f16(flags):
     if ref is not None:
         exact = oracle(g)
         assert float((logits.cpu() - exact).abs().max()) <= float((ref - exact).abs().max()) + 1e-3 * scale
+
+
+@pytest.mark.parametrize("e", [1, 33, 1000, 70001])
+@pytest.mark.parametrize("skip", [False, True])
+def test_decoder_on_f16_tables_equals_decoder_on_upconverted_tables(e, skip):
+    """pangnn_decoder_train_mixed / pangnn_decoder_mlp_infer_mixed with float16 P | Q (the S and inference kernels compiled for
+    IEEE-half tables, decoder16_f16.o): the gather reads half the bytes, the arithmetic is unchanged — logits, loss and every
+    gradient are bit-identical to the f32 entry points on the up-converted tables (sorted lists: run-sum path; unsorted:
+    generic path); the table's gradient comes back as float16 = the f32 gradient rounded once"""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    torch.manual_seed(e + skip)
+    n, d = 97, 64
+    ei, w = random_graph(n, e, seed=e, isolated=0.0)
+    ei = ei[:, torch.argsort(ei[0] * n + ei[1])] if e % 2 else ei
+    pq = torch.randn(n, 2 * d, device=dev()).to(F16)
+    W2, b2, w3, b3, cv = (t.to(dev()) for t in (torch.randn(d, d) / 8, torch.randn(d), torch.randn(d), torch.randn(1),
+                                                 torch.randn(d)))
+    extra = (w / 40).to(dev()) if skip else None
+    y = (torch.rand(e) < 0.3).float().to(dev())
+    pw = torch.tensor(2.5, device=dev())
+    st = EdgeStructure(ei.to(dev()), n)
+    res = []
+    for tab in (pq, pq.float()):
+        leaf = tab.clone().requires_grad_(True)
+        ws = [t.clone().requires_grad_(True) for t in (W2, b2, w3, b3, cv)]
+        loss, logits = PF.decoder_loss_pq(leaf, st, extra, ws[4] if skip else None, ws[0], ws[1], ws[2], ws[3], y, pw, e)
+        loss.backward()
+        with torch.no_grad():
+            inf = PF.decoder_mlp_pq(tab, st, extra, cv if skip else None, W2, b2, w3, b3)
+        res.append((loss.detach(), logits, inf, leaf.grad, [t.grad for t in ws[: 5 if skip else 4]]))
+    (l16, lg16, inf16, g16, gw16), (l32, lg32, inf32, g32, gw32) = res
+    assert torch.equal(l16, l32) and torch.equal(lg16, lg32) and torch.equal(inf16, inf32) and torch.equal(inf16, lg16)
+    assert g16.dtype == F16 and torch.equal(g16, g32.to(F16))
+    for a, b in zip(gw16, gw32):
+        assert torch.equal(a, b)
+    p16, q16 = pq[:, :d].contiguous(), pq[:, d:].contiguous()
+    lsep, lgsep = PF.decoder_loss(p16, q16, st, extra, cv if skip else None, W2, b2, w3, b3, y, pw, e)
+    assert torch.equal(lgsep, lg16) and torch.equal(lsep, l16)
+    # the bfloat16 tables of the same values (8 significant bits fit both formats) give the same bits: only the conversion differs
+    pq8 = pq.to(BF16)
+    if bool((pq8.to(F16).float() == pq8.float()).all()):
+        with torch.no_grad():
+            a = PF.decoder_mlp_pq(pq8, st, extra, cv if skip else None, W2, b2, w3, b3)
+            b = PF.decoder_mlp_pq(pq8.to(F16), st, extra, cv if skip else None, W2, b2, w3, b3)
+        assert torch.equal(a, b)
