@@ -14,6 +14,7 @@ definitions it documents, and tests pin them against scikit-learn (`confusion_ma
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -72,41 +73,40 @@ def summary_from_confusion(conf) -> dict:
                 accuracy=(tp + tn) / total if total else 0.0)
 
 
-_LAST_CURVE = None
-
-
-def forget_curve():
-    """drop the kept curve (and the references to the tensors it was computed from)"""
-    global _LAST_CURVE
-    _LAST_CURVE = None
-
-
 class _RankingMetric:
-    """keeps (score, label) of every update on the device, like torchmetrics with thresholds=None"""
+    """keeps (score, label) of every update on the device, like torchmetrics with thresholds=None.
+    `share_curve_with=other`: the two metrics are going to be fed the same tensors (ROC-AUC and PR-AUC of one validation pass,
+    pangnn.py:255-285) — whichever computes second reuses the sorted curve of the first instead of sorting the 7.5e7 scores of
+    config 4 again (the sort is most of the pass).  The curve lives on the metric objects and goes with them."""
 
-    def __init__(self):
-        self.scores, self.labels, self._src = [], [], []
+    def __init__(self, share_curve_with=None):
+        self.scores, self.labels, self._src, self._curve_kept = [], [], [], None
+        self._partner = None if share_curve_with is None else weakref.ref(share_curve_with)     # weak both ways: no cycle
+        if share_curve_with is not None:
+            share_curve_with._partner = weakref.ref(self)
 
     def update(self, preds, target):
         self.scores.append(preds.detach().reshape(-1).to(torch.float32))
         self.labels.append((target.detach().reshape(-1) > 0.5))
         self._src.append((preds, target, preds._version, target._version))
+        self._curve_kept = None
 
     def reset(self):
-        self.scores, self.labels, self._src = [], [], []
+        self.scores, self.labels, self._src, self._curve_kept = [], [], [], None
+
+    def _same_data(self, other) -> bool:
+        return len(self._src) == len(other._src) and all(
+            a[0] is b[0] and a[1] is b[1] and a[2] == b[2] and a[3] == b[3] for a, b in zip(self._src, other._src))
 
     def _curve(self):
-        """(tps, fps) at every distinct threshold, scores descending; int64.  The curve of the LAST computed data set is kept:
-        ROC-AUC and PR-AUC of one validation pass (pangnn.py:255-285) are updated with the same tensors, and the second metric
-        then reuses the first one's sort (7.5e7 scores at config 4: the sort is most of the pass)."""
-        global _LAST_CURVE
-        hit = _LAST_CURVE
-        if hit is not None and len(hit[0]) == len(self._src) and all(
-                a[0] is b[0] and a[1] is b[1] and a[2] == b[2] and a[3] == b[3] for a, b in zip(hit[0], self._src)):
-            return hit[1], hit[2]
-        tps, fps = self._curve_of(torch.cat(self.scores), torch.cat(self.labels))
-        _LAST_CURVE = (list(self._src), tps, fps)         # holds the source tensors: their identity cannot be recycled
-        return tps, fps
+        """(tps, fps) at every distinct threshold, scores descending; int64"""
+        if self._curve_kept is None:
+            p = None if self._partner is None else self._partner()
+            if p is not None and p._curve_kept is not None and self._same_data(p):
+                self._curve_kept = p._curve_kept
+            else:
+                self._curve_kept = self._curve_of(torch.cat(self.scores), torch.cat(self.labels))
+        return self._curve_kept
 
     @staticmethod
     def _curve_of(s, y):

@@ -55,8 +55,9 @@ def evaluate(model, batches, pos_weight, threshold: float = 0.5) -> dict:
     """The validation pass of pangnn.py:241-290: mean loss over the batches, confusion counts at
     `threshold`, precision / recall / f1 / accuracy, ROC-AUC and PR-AUC.  Everything accumulates on the
     GPU; the only host synchronisation is the final read-out."""
-    from .metrics import BinaryAUROC, BinaryAveragePrecision, BinaryConfusionMatrix, forget_curve, summary_from_confusion
-    conf, auroc, ap = None, BinaryAUROC(), BinaryAveragePrecision()
+    from .metrics import BinaryAUROC, BinaryAveragePrecision, BinaryConfusionMatrix, summary_from_confusion
+    conf, auroc = None, BinaryAUROC()
+    ap = BinaryAveragePrecision(share_curve_with=auroc)      # fed the same tensors: one sort serves both
     loss_sum, n_batches = None, 0
     was_training = model.training
     model.eval()
@@ -75,9 +76,7 @@ def evaluate(model, batches, pos_weight, threshold: float = 0.5) -> dict:
     if conf is None:
         raise ValueError("evaluate() needs at least one batch")
     res = summary_from_confusion(conf.compute())
-    # ROC-AUC and PR-AUC were fed the same tensors: the second compute() reuses the first one's sorted curve (metrics._curve)
     res.update(loss=float(loss_sum) / n_batches, roc_auc=float(auroc.compute()), pr_auc=float(ap.compute()))
-    forget_curve()
     return res
 
 

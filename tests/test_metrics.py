@@ -34,8 +34,8 @@ def test_ranking_metrics_match_sklearn_on_host_tensors(n, ties):
 
 
 def test_two_ranking_metrics_fed_the_same_tensors_share_one_sorted_curve(monkeypatch):
-    """ROC-AUC and PR-AUC of one validation pass get the same (probabilities, labels) tensors: the second compute() must reuse
-    the first one's curve (one sort), and must NOT reuse it for other tensors or after an in-place change"""
+    """ROC-AUC and PR-AUC of one validation pass get the same (probabilities, labels) tensors: with share_curve_with the second
+    compute() reuses the first one's curve (one sort) — and does NOT for other tensors, after an in-place change, or unpaired"""
     from pangnn_amd import metrics as M
     s, y = _scores(3000, 7, True)
     y[0], y[1] = 0.0, 1.0
@@ -44,25 +44,34 @@ def test_two_ranking_metrics_fed_the_same_tensors_share_one_sorted_curve(monkeyp
     calls = []
     real = M._RankingMetric._curve_of
     monkeypatch.setattr(M._RankingMetric, "_curve_of", staticmethod(lambda a, b: (calls.append(1), real(a, b))[1]))
-    M.forget_curve()
-    auroc, ap = BinaryAUROC(), BinaryAveragePrecision()
+    auroc = BinaryAUROC()
+    ap = BinaryAveragePrecision(share_curve_with=auroc)
     auroc.update(p, t)
     ap.update(p, t)
+    assert abs(float(ap.compute()) - average_precision_score(y, p.numpy())) < 1e-6          # either order
     assert abs(float(auroc.compute()) - roc_auc_score(y, p.numpy())) < 1e-6
-    assert abs(float(ap.compute()) - average_precision_score(y, p.numpy())) < 1e-6
     assert len(calls) == 1
-    p2 = p.clone()
-    other = BinaryAveragePrecision()
-    other.update(p2, t)                                   # equal values, another tensor: computed afresh
-    other.compute()
+    lone = BinaryAveragePrecision()                       # unpaired: its own sort
+    lone.update(p, t)
+    lone.compute()
     assert len(calls) == 2
-    p2.mul_(0.5)                                          # the same tensor changed in place: the version counter differs
-    again = BinaryAUROC()
-    again.update(p2, t)
-    again.compute()
-    assert len(calls) == 3
-    M.forget_curve()
-    assert M._LAST_CURVE is None
+    a2 = BinaryAUROC()
+    b2 = BinaryAveragePrecision(share_curve_with=a2)
+    a2.update(p, t)
+    b2.update(p.clone(), t)                               # equal values, another tensor: computed afresh
+    a2.compute(), b2.compute()
+    assert len(calls) == 4
+    a3 = BinaryAUROC()
+    b3 = BinaryAveragePrecision(share_curve_with=a3)
+    p3 = p.clone()
+    a3.update(p3, t)
+    a3.compute()
+    p3.mul_(0.5)                                          # the same tensor changed in place before the partner saw it
+    b3.update(p3, t)
+    b3.compute()
+    assert len(calls) == 6
+    a3.reset()
+    assert a3._curve_kept is None
 
 
 def test_ranking_metrics_degenerate_classes():
