@@ -62,7 +62,9 @@ def _worker(rank, world, init_file, exchange, out_dir, overlap=True, backend="gl
                                    **flags)
     model.load_full_state_dict(oracle.state_dict())
     model.overlap = overlap
-    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if bf16 else contextlib.nullcontext
+    # bf16: True (bfloat16 autocast, config 5) / "f16" (float16 autocast: P | Q and their halo rows travel as float16) / False
+    amp_dtype = torch.float16 if bf16 == "f16" else torch.bfloat16
+    amp = (lambda: torch.autocast("cuda", dtype=amp_dtype)) if bf16 else contextlib.nullcontext
     # halo exchange on a source-sorted shard: both exchanges of the decoder run on the side stream, under the
     # own-source pass and the by-target pass (dist._OverlappedDecoderLoss)
     assert model._overlap_ok(shard) == (overlap and exchange == "halo")
@@ -96,6 +98,13 @@ def _worker(rank, world, init_file, exchange, out_dir, overlap=True, backend="gl
                 continue
             scale = float(q.grad.abs().max()) + 1e-12
             tol = 3e-2 if bf16 else 2e-4
+            if bf16 == "f16":
+                # the single-GPU model stores its encoder rows as float16 too, the partitioned one only P | Q (its encoder rows
+                # stay fp32): two roundings apart, and the first layer's gradients are sums of cancelling class terms
+                # (measured: <= 3.5e-2 of the gradient's scale over the three steps, 1e-3 ... 8e-3 on the first)
+                dev_ = float((p.grad - q.grad).abs().max()) / scale
+                assert dev_ < 8e-2, (step, k, dev_)
+                continue
             assert torch.allclose(p.grad, q.grad, atol=tol * scale + 1e-8, rtol=tol if bf16 else 1e-3), (step, k)
     if exchange == "halo" and forced:
         plan = model._plan(shard, "sim")
@@ -123,8 +132,9 @@ def test_ranks_on_one_gpu_match_the_single_gpu_model(world, exchange, overlap):
 @pytest.mark.parametrize("exchange,overlap,flags,bf16", [
     ("halo", True, dict(), False), ("halo", False, dict(), False), ("allgather", True, dict(), False),
     ("halo", True, dict(skip_connections=True), False),
-    ("halo", True, dict(skip_connections=True, categorical_nodes=True), True)],
-    ids=["halo-overlapped", "halo-gather-first", "allgather", "skip", "cfg5-skip-categorical-bf16"])
+    ("halo", True, dict(skip_connections=True, categorical_nodes=True), True),
+    ("halo", True, dict(), "f16")],
+    ids=["halo-overlapped", "halo-gather-first", "allgather", "skip", "cfg5-skip-categorical-bf16", "halo-overlapped-f16"])
 def test_partitioned_path_over_rccl_with_forced_self_exchange(exchange, overlap, flags, bf16):
     """The N > 1 code on the RCCL back end with the one GPU this box has: PANGNN_FORCE_EXCHANGE=1 makes the single rank
     treat the outer quarters of its node range as remote rows owned by itself, so `all_to_all_single` with split lists,
