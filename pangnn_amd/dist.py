@@ -387,11 +387,12 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
             pq = p_local if p_local.stride(1) == 1 else p_local.contiguous()
             dj = pq.shape[1] // 2
             p_local, q_local = pq[:, :dj], pq[:, dj:]
-            # [dL/dP | dL/dQ] over the TABLE's rows: columns [0, D) are the by-source sums of every table row (the halo rows'
-            # part travels back to their owners), rows [n_low, n_low + n_local) of it are the own rows' joint gradient — what the
-            # dense layer's backward reads, in place (no copy of dL/dP into a joint matrix)
-            g_tab = torch.empty((plan.n_table, pq.shape[1]), dtype=torch.float32, device=dev)
-            gpq = g_tab[plan.n_low:plan.n_low + plan.n_local]
+            # [dL/dP | dL/dQ] of the own rows — what the dense layer's backward reads: the own-source range's by-source sums are
+            # written for the own rows only, straight into its left half; the halo-source range's for the halo rows only, into the
+            # compact buffer that travels back to their owners (no sum over rows a range cannot touch, no copy, no concatenation)
+            gpq = torch.empty((plan.n_local, pq.shape[1]), dtype=torch.float32, device=dev)
+            g_halo32 = torch.empty((plan.n_halo, dj), dtype=torch.float32, device=dev)
+            merged = torch.empty(plan.edge_index.shape[1], dtype=torch.float32, device=dev)      # logits in the shard's edge order
         else:
             p_local = p_local.contiguous()
         n_low, n_loc, d = plan.n_low, plan.n_local, p_local.shape[1]
@@ -407,13 +408,15 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
         y_l, y_h = plan.split_edge_values(y)
         # own-source edges: read rows n_low .. n_low + n_local of the table only
         r_loc = ops.decoder_train(table, q_local, st_loc, ex_l, cvec, w2, b2, w3, b3, y_l, pos_weight, denom,
-                                  **({"out_q": gpq[:, d:], "out_p": g_tab[:, :d]} if joint else {}))
+                                  **({"out_q": gpq[:, d:], "p_windows": [(n_low, n_low + n_loc, gpq[:, :d])],
+                                      "out_logits": merged[plan.e_lo:plan.e_hi]} if joint else {}))
         fwd.done()
         box = {}
 
         def send_back(gp_table):
-            with _Side(dev, gp_table) as bwd:
-                g_halo = torch.cat([gp_table[:n_low], gp_table[n_low + n_loc:]], dim=0).to(p_local.dtype)
+            with _Side(dev, *(gp_table if joint else [gp_table])) as bwd:
+                g_halo = g_halo32.to(p_local.dtype) if joint else \
+                    torch.cat([gp_table[:n_low], gp_table[n_low + n_loc:]], dim=0).to(p_local.dtype)
                 back = p_local.new_empty((plan.send_idx.numel(), d))    # travels in the table's storage type
                 _all_to_all_v(back, g_halo, plan.send_splits, plan.recv_splits, plan.group)
                 bwd.keep(back)
@@ -421,10 +424,12 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
 
         # the halo-source range has the same targets: its by-target pass adds into the own-source range's dL/dQ
         r_halo = ops.decoder_train(table, q_local, st_halo, ex_h, cvec, w2, b2, w3, b3, y_h, pos_weight, denom,
-                                   after_p=send_back, out_q=r_loc[3], accumulate_q=True)
+                                   after_p=send_back, out_q=r_loc[3], accumulate_q=True,
+                                   **({"p_windows": [(0, n_low, g_halo32[:n_low]), (n_low + n_loc, plan.n_table, g_halo32[n_low:])]}
+                                      if joint else {}))
         loss_l, logit_l, gp_l, gq = r_loc[:4]
         loss_h, logit_h = r_halo[:2]
-        gp_local = gp_l[n_low:n_low + n_loc]                     # rows of halo sources are zero in gp_l
+        gp_local = gpq[:, :d] if joint else gp_l[n_low:n_low + n_loc]     # rows of halo sources are zero in gp_l
         box["bwd"].done()
         if box["back"].shape[0]:
             ops.accumulate_back(gp_local, box["back"].float(), plan)
@@ -433,7 +438,12 @@ class _OverlappedDecoderLoss(torch.autograd.Function):
         small = [None] * len(a_s)
         for i, t in zip(live, torch._foreach_add([a_s[i] for i in live], [b_s[i] for i in live])):   # one launch
             small[i] = t
-        logits = plan.merge_edge_values(logit_l, logit_h)
+        if joint:                                   # the own-source range wrote its logits in place: the halo part is copied in
+            merged[:plan.e_lo].copy_(logit_h[:plan.e_lo])
+            merged[plan.e_hi:].copy_(logit_h[plan.e_lo:])
+            logits = merged
+        else:
+            logits = plan.merge_edge_values(logit_l, logit_h)
         ctx.has_cv, ctx.joint = small[0] is not None, joint
         if joint:
             gp_local, gq = gpq, gpq.new_empty(0)
@@ -554,7 +564,7 @@ class HipOps:
         return PF.decoder_loss(p_full, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom)
 
     def decoder_train(self, table, q_local, st, extra, cvec, w2, b2, w3, b3, y, pos_weight, denom, after_p=None, out_q=None,
-                      accumulate_q=False, out_p=None):
+                      accumulate_q=False, out_p=None, p_windows=None, out_logits=None):
         """one-pass training decoder on (a range of) a shard: (loss, logits, dL/dtable, dL/dq, g_cvec, g_w2, g_b2, g_w3,
         g_b3), all finished; `after_p(dL/dtable)` runs before the by-target pass is enqueued; `out_q`: where dL/dq is written
         (a column window of a wider matrix is fine), or ADDED to it with `accumulate_q`"""
@@ -563,7 +573,7 @@ class HipOps:
         loss, logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3 = PF._decoder_train16(
             PF._rows_dec(table), PF._rows_dec(q_local), st, None if extra is None else f(extra),
             None if cvec is None else f(cvec), f(w2), f(b2), f(w3), f(b3), y=f(y), pw=pw, denom=denom, after_p=after_p,
-            out_q=out_q, accumulate_q=accumulate_q, out_p=out_p)
+            out_q=out_q, accumulate_q=accumulate_q, out_p=out_p, p_windows=p_windows, out_logits=out_logits)
         return loss.view(()), logits, gp, gq, g_cv, g_w2, g_b2, g_w3, g_b3
 
     def linear(self, x, w, b, in_act: int = 0, out_dtype=None):

@@ -420,11 +420,16 @@ def d16_chunk(num_edges: Optional[int] = None) -> int:
     return int(lib.pangnn_decoder_chunk_tiles() if num_edges is None else lib.pangnn_decoder_chunk_tiles_for(int(num_edges)))
 
 
-def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
-    """out[s] (+)= sum of the consecutive part rows of source s (pangnn_spmm_csr_f32, idx = NULL)"""
+def _sum_parts(plan, part_buf: torch.Tensor, n_rows: int, out: torch.Tensor, accumulate: bool = False,
+               row_lo: int = 0) -> torch.Tensor:
+    """out[s - row_lo] (+)= sum of the consecutive part rows of source s, s in [row_lo, row_lo + n_rows)
+    (pangnn_spmm_csr_f32, idx = NULL; the row pointer's entries are absolute part positions, so a window of rows is the same
+    call on the shifted pointer)"""
     lib = _lib.load()
+    if n_rows <= 0:
+        return out
     with _lib.device_guard(part_buf.device):
-        _lib.check(lib.pangnn_spmm_csr_f32(plan.part_rowptr.data_ptr(), None, None, _lib.ptr(part_buf),
+        _lib.check(lib.pangnn_spmm_csr_f32(plan.part_rowptr.data_ptr() + 8 * int(row_lo), None, None, _lib.ptr(part_buf),
                                            part_buf.stride(0), part_buf.shape[0], None, out.data_ptr(),
                                            out.stride(0), n_rows, part_buf.shape[0], part_buf.shape[1], int(accumulate),
                                            _lib.stream_ptr()), "pangnn_spmm_csr_f32(parts)")
@@ -461,7 +466,8 @@ def _dgrad_sum(rec, st: EdgeStructure, by: Optional[str], w2, w3, n_rows: int = 
 
 
 def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw=None, denom=0, g_logits=None,
-                     out_p=None, out_q=None, need_p=True, need_q=True, after_p=None, live=None, accumulate_q=False):
+                     out_p=None, out_q=None, need_p=True, need_q=True, after_p=None, live=None, accumulate_q=False,
+                     p_windows=None, out_logits=None):
     """Two-wave-per-SIMD training decoder (csrc/decoder16.hip).  One pass over the edges in the caller's order (S):
     logits, loss (y given) or the given dL/dlogits, every parameter gradient, per-source run sums when the list is
     source-sorted, and a 32-byte record per edge; then dL/dQ (and dL/dP for unsorted lists) from the records in CSR
@@ -470,12 +476,15 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
     exchange of the halo rows' gradients there, so that it runs under T).
     `live` (device int64[1], optional): the list is a fixed-shape padded batch whose first live[0] edges are real
     (include/pangnn_hip.h, live_edges): the padding enters no sum and the fused loss is the mean over live[0] edges.
-    `accumulate_q` (with out_q): dL/dQ is ADDED to out_q (a second edge range of the same targets: the partitioned decoder)."""
+    `accumulate_q` (with out_q): dL/dQ is ADDED to out_q (a second edge range of the same targets: the partitioned decoder).
+    `p_windows` (source-sorted lists only): [(row_lo, row_hi, out [row_hi - row_lo, 64]), ...] — dL/dP is wanted for these row
+    ranges only, each written to its own tensor (an edge range whose sources lie in known row ranges: nothing is written for
+    the rows in between); the returned gp is then the list of those tensors.  `out_logits`: where the fused-loss logits go."""
     lib = _lib.load()
     dev = p.device
     e, d = st.num_edges, p.shape[1]
     fused = y is not None
-    logits = torch.empty(e, dtype=torch.float32, device=dev) if fused else None
+    logits = (out_logits if out_logits is not None else torch.empty(e, dtype=torch.float32, device=dev)) if fused else None
     loss = torch.empty(1, dtype=torch.float32, device=dev) if fused else None
     g_w2 = torch.empty_like(w2)
     g_b2, g_w3, g_b3 = torch.empty_like(b2), torch.empty_like(w3), torch.empty_like(b3)
@@ -500,13 +509,19 @@ def _decoder_train16(p, q, st: EdgeStructure, ex, cv, w2, b2, w3, b3, y=None, pw
     gp = gq = None
     b2_out = g_b2          # dL/db2 comes out of exactly one dgrad call
     if need_p:
-        if e == 0:
+        if e == 0 and p_windows is not None:
+            gp = [o.zero_() for _, _, o in p_windows]
+        elif e == 0:
             gp = (out_p if out_p is not None else torch.empty(p.shape[0], d, device=dev)).zero_()
+        elif plan is not None and p_windows is not None:
+            gp = [_sum_parts(plan, parts, hi - lo, o, row_lo=lo) for lo, hi, o in p_windows]
         elif plan is not None:
             gp = _sum_parts(plan, parts, p.shape[0], out_p if out_p is not None else torch.empty(p.shape[0], d, device=dev))
         else:
             gp = _dgrad_sum(rec, st, "src", w2, w3, p.shape[0], out_p, g_b2=b2_out, live=live)
             b2_out = None
+            if p_windows is not None:                       # an unsorted list: all rows were summed, hand out the windows
+                gp = [o.copy_(gp[lo:hi]) for lo, hi, o in p_windows]
         if after_p is not None:
             after_p(gp)
     if need_q:
