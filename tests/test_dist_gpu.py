@@ -113,6 +113,9 @@ def _worker(rank, world, init_file, exchange, out_dir, overlap=True, backend="gl
     elif exchange == "halo":
         plan = model._plan(shard, "sim")
         assert plan.n_halo > 0 and plan.n_table < shard.n_pad        # genuinely smaller than an all-gather
+        # the positional-neighbour graph of a shard: band kernel over the own rows + the boundary rows (dist._BandTinyHalo)
+        band = shard.__dict__.get("_dist_band", {}).get("nb")
+        assert band is not None and band[2] >= 1 and model._plan(shard, "nb").n_halo <= 2 * band[2]
         # table order = global id order: the source-sorted edge list stays sorted on the shard, so the
         # decoder's per-source partial sums are used here too
         assert model._st(shard, "sim").runsum_plan() is not None
