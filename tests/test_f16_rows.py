@@ -295,3 +295,38 @@ def test_decoder_on_f16_tables_equals_decoder_on_upconverted_tables(e, skip):
             a = PF.decoder_mlp_pq(pq8, st, extra, cv if skip else None, W2, b2, w3, b3)
             b = PF.decoder_mlp_pq(pq8.to(F16), st, extra, cv if skip else None, W2, b2, w3, b3)
         assert torch.equal(a, b)
+
+
+def test_by_source_sums_over_row_windows_equal_the_rows_of_the_full_sum():
+    """functional._decoder_train16(p_windows=...) (the partitioned decoder: an edge range whose sources lie in known row ranges):
+    the windows' sums are the corresponding rows of the full dL/dP, nothing is written in between; out_logits / out_q +
+    accumulate_q write where they are told"""
+    from pangnn_amd import functional as PF
+    from pangnn_amd.graph import EdgeStructure
+    torch.manual_seed(0)
+    n, d, e = 400, 64, 30000
+    src = torch.sort(torch.randint(100, 300, (e,))).values            # sources only in rows [100, 300): source-sorted
+    dst = torch.randint(0, n, (e,))
+    ei = torch.stack([src, dst]).to(dev())
+    st = EdgeStructure(ei, n, n)
+    p, q = torch.randn(n, d, device=dev()), torch.randn(n, d, device=dev())
+    w2, b2, w3, b3 = (torch.randn(d, d, device=dev()) / 8, torch.randn(d, device=dev()), torch.randn(d, device=dev()),
+                      torch.randn(1, device=dev()))
+    y = (torch.rand(e, device=dev()) < 0.3).float()
+    pw = torch.tensor([2.0], device=dev())
+    full = PF._decoder_train16(p, q, st, None, None, w2, b2, w3, b3, y=y, pw=pw, denom=e)
+    lo_w, hi_w = torch.full((50, d), 7.0, device=dev()), torch.full((120, d), 7.0, device=dev())
+    logits = torch.full((e + 8,), 9.0, device=dev())
+    gq0 = torch.randn(n, d, device=dev())
+    gq = gq0.clone()
+    win = PF._decoder_train16(p, q, st, None, None, w2, b2, w3, b3, y=y, pw=pw, denom=e,
+                              p_windows=[(100, 150, lo_w), (180, 300, hi_w)], out_logits=logits[4:e + 4], out_q=gq, accumulate_q=True)
+    assert isinstance(win[2], list) and win[2][0] is lo_w and win[2][1] is hi_w
+    # (a row's parts are added by whichever propagate kernel the entry density of the call selects — wave per row or lane group
+    # per row —, so a window and the full call may associate a multi-part row's few terms differently: fp32 rounding apart)
+    scale = float(full[2].abs().max())
+    assert close(lo_w, full[2][100:150], atol=1e-6 * scale, rtol=1e-5) and close(hi_w, full[2][180:300], atol=1e-6 * scale, rtol=1e-5)
+    assert torch.equal(logits[4:e + 4], full[1]) and bool((logits[:4] == 9.0).all()) and bool((logits[e + 4:] == 9.0).all())
+    assert torch.equal(win[0], full[0])
+    assert torch.allclose(gq, gq0 + full[3], atol=1e-6, rtol=1e-6)
+    assert bool((full[2][:100] == 0).all()) and bool((full[2][300:] == 0).all())      # rows without edges: zero in the full sum
